@@ -1,0 +1,33 @@
+# Build of the host library, the HIP core (C-ABI) and -- separately -- the test oracle.
+# `python -c "import __graft_entry__ as g; g.build()"` drives these targets.
+ROOT      := $(abspath .)
+CXX       ?= g++
+HIPCC     ?= /opt/rocm/bin/hipcc
+CXXFLAGS  := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -DTUNGSTEN_AMD_DEFAULT_ASSETS='"$(ROOT)/assets"'
+HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function
+
+HOST_SRC  := tungsten_amd/host/scene.cpp tungsten_amd/host/capi.cpp
+HOST_LIB  := tungsten_amd/libtungsten_host.so
+CORE_SRC  := tungsten_amd/csrc/tgpu_api.hip
+CORE_DEPS := $(wildcard tungsten_amd/csrc/*.h tungsten_amd/csrc/*.hip include/*.h)
+CORE_LIB  := tungsten_amd/libtungsten_amd.so
+ORACLE_LIB:= oracle/liboracle.so
+
+all: host core oracle
+host: $(HOST_LIB)
+core: $(CORE_LIB)
+oracle: $(ORACLE_LIB)
+
+$(HOST_LIB): $(HOST_SRC) $(wildcard tungsten_amd/host/*.hpp) include/tungsten_amd.h
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lpthread
+
+$(CORE_LIB): $(CORE_DEPS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CORE_SRC)
+
+# the oracle uses explicit fmaf in include/tgpu_math.h: -mfma keeps it a single instruction
+$(ORACLE_LIB): oracle/oracle.cpp oracle/oracle.h include/tungsten_amd.h include/tgpu_math.h
+	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -mfma -shared -o $@ oracle/oracle.cpp -lpthread
+
+clean:
+	rm -f $(HOST_LIB) $(CORE_LIB) $(ORACLE_LIB)
+.PHONY: all host core oracle clean

@@ -1,0 +1,256 @@
+/*
+ * tungsten_amd.h -- C ABI of the MI355X wavefront path-tracing core.
+ *
+ * This is the drop-in boundary for Tungsten's unidirectional `path_tracer`
+ * integrator.  The reference interface it sits behind is the abstract class
+ * Tungsten::Integrator (src/core/integrators/Integrator.hpp:16-63); each entry
+ * point below names the reference member it replaces.  The host-side C++ class
+ * `tungsten_amd::PathTraceIntegrator` (tungsten_amd/host/integrator.hpp) wraps
+ * these calls back into the reference's Integrator shape; INTEGRATION.md shows
+ * the binding a Tungsten maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only, no C++/torch types; return 0 on
+ * success, negative tgpu_status on error (never throws across the ABI);
+ * tgpu_last_error() returns a human readable message for the last failure on a
+ * context.  All scene buffers are caller-owned and copied during
+ * tgpu_upload_scene().  One host thread drives one context; contexts are
+ * independent.  All arithmetic is IEEE binary32 unless marked.
+ */
+#ifndef TUNGSTEN_AMD_H_
+#define TUNGSTEN_AMD_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGPU_ABI_VERSION 1
+
+typedef enum tgpu_status {
+    TGPU_OK = 0,
+    TGPU_ERR_INVALID = -1,     /* bad argument / inconsistent scene description   */
+    TGPU_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init      */
+    TGPU_ERR_HIP = -3,         /* a HIP call failed (message in tgpu_last_error)   */
+    TGPU_ERR_UNSUPPORTED = -4, /* scene uses a feature outside the hot-path scope  */
+    TGPU_ERR_STATE = -5,       /* call order violated (e.g. render before upload)  */
+    TGPU_ERR_ABORTED = -6      /* pass was aborted via tgpu_abort                  */
+} tgpu_status;
+
+/* ---- textures (src/core/textures: ConstantTexture, CheckerTexture.cpp:64-69,
+ *      BitmapTexture.cpp:298-352) ------------------------------------------- */
+enum { TGPU_TEX_CONSTANT = 0, TGPU_TEX_CHECKER = 1, TGPU_TEX_BITMAP = 2 };
+
+typedef struct tgpu_texture {
+    int32_t type;
+    float   value[3];      /* constant                                     */
+    float   on_color[3];   /* checker                                      */
+    float   off_color[3];
+    int32_t res_u, res_v;
+    int32_t bitmap;        /* index into tgpu_scene_desc::bitmaps          */
+} tgpu_texture;
+
+typedef struct tgpu_bitmap {
+    int32_t      w, h;
+    int32_t      clamp;    /* 0 = wrap (reference default for bare string) */
+    int32_t      linear;   /* bilinear interpolation                       */
+    float        scale;
+    const float *texels;   /* w*h*3 RGB f32, row 0 = top (ImageIO.cpp:340) */
+} tgpu_bitmap;
+
+/* ---- BSDFs (src/core/bsdfs) -------------------------------------------- */
+enum {
+    TGPU_BSDF_LAMBERT = 0,          /* LambertBsdf.cpp:27-68            */
+    TGPU_BSDF_ROUGH_CONDUCTOR = 1,  /* RoughConductorBsdf.cpp:60-143    */
+    TGPU_BSDF_SMOOTH_COAT = 2,      /* SmoothCoatBsdf.cpp:41-223        */
+    TGPU_BSDF_NULL = 3,             /* NullBsdf.cpp (light carriers)    */
+    TGPU_BSDF_NUM_CLASSES = 4
+};
+enum { TGPU_DIST_BECKMANN = 0, TGPU_DIST_PHONG = 1, TGPU_DIST_GGX = 2 };
+
+typedef struct tgpu_bsdf {
+    int32_t type;
+    int32_t albedo_tex;    /* index into textures                           */
+    int32_t roughness_tex; /* rough_conductor: scalar (x channel)           */
+    int32_t distribution;  /* TGPU_DIST_*                                   */
+    float   eta[3], k[3];  /* conductor complex IOR                         */
+    float   ior;           /* smooth_coat                                   */
+    float   thickness;
+    float   sigma_a[3];
+    int32_t substrate;     /* smooth_coat: index of substrate bsdf          */
+    float   scaled_sigma_a[3];   /* thickness*sigma_a   (SmoothCoatBsdf.cpp:217-223, */
+    float   avg_transmittance;   /* exp(-2*avg(scaled)) baked at prepareForRender)   */
+} tgpu_bsdf;
+
+/* ---- analytic primitives ------------------------------------------------ */
+/* Quad after prepareForRender (src/core/primitives/Quad.cpp:298-316).        */
+typedef struct tgpu_quad {
+    float   base[3], edge0[3], edge1[3];
+    float   normal[3], tangent[3], bitangent[3]; /* TangentFrame(n, e0^, e1^) */
+    float   inv_uv_sq[2];
+    float   area;
+    int32_t bsdf;
+    int32_t emission_tex;  /* -1 = not emissive                             */
+} tgpu_quad;
+
+/* Cube after prepareForRender (src/core/primitives/Cube.cpp:353-370).        */
+typedef struct tgpu_cube {
+    float   rot[9];        /* row-major 3x3 rotation                        */
+    float   inv_rot[9];
+    float   pos[3];
+    float   scale[3];
+    int32_t bsdf;
+    int32_t emission_tex;
+} tgpu_cube;
+
+/* Infinite sphere / environment light (InfiniteSphere.cpp:27-50,161-244) and
+ * the Distribution2D of its emission bitmap (Distribution2D.hpp:18-83,
+ * BitmapTexture.cpp:400-455).  Tables are NULL for a constant emission.      */
+typedef struct tgpu_env {
+    int32_t      present;
+    int32_t      samplable;      /* "sample": true                          */
+    int32_t      emission_tex;   /* constant or bitmap                      */
+    float        rot[9];         /* _rotTransform, row-major                */
+    float        inv_rot[9];     /* its transpose                           */
+    int32_t      dist_w, dist_h;
+    const float *pdf;            /* dist_w*dist_h                           */
+    const float *cdf;            /* dist_h*(dist_w+1)                       */
+    const float *marginal_pdf;   /* dist_h                                  */
+    const float *marginal_cdf;   /* dist_h+1                                */
+} tgpu_env;
+
+/* ---- camera (PinholeCamera.cpp:28-35,70-86; ReconstructionFilter) ------- */
+enum { TGPU_FILTER_DIRAC = 0, TGPU_FILTER_BOX = 1, TGPU_FILTER_TABULATED = 2 };
+
+typedef struct tgpu_camera {
+    float    pos[3];
+    float    rot[9];          /* upper 3x3 of _transform (right flipped)     */
+    uint32_t res_x, res_y;
+    float    plane_dist;
+    float    ratio;           /* res_y / float(res_x)                        */
+    float    pixel_size_x;    /* 1 / res_x (used for both axes)              */
+    int32_t  filter_type;
+    float    filter_bin_size;
+    float    filter_cdf[32];  /* RFILTER_RESOLUTION + 1                      */
+} tgpu_camera;
+
+/* ---- integrator settings (TraceSettings.hpp:23-29, PathTracerSettings) --- */
+typedef struct tgpu_settings {
+    int32_t min_bounces, max_bounces;
+    int32_t enable_light_sampling;
+    int32_t enable_two_sided_shading;
+    int32_t enable_consistency_checks;
+    int32_t use_sobol;        /* renderer "stratified_sampler"               */
+} tgpu_settings;
+
+/* A light is an emissive, samplable primitive, in scene order
+ * (TraceableScene.hpp:86-102).                                              */
+enum { TGPU_LIGHT_ENV = 0, TGPU_LIGHT_QUAD = 1 };
+typedef struct tgpu_light { int32_t kind; int32_t index; } tgpu_light;
+
+typedef struct tgpu_scene_desc {
+    uint32_t abi_version;     /* TGPU_ABI_VERSION */
+
+    tgpu_camera   camera;
+    tgpu_settings settings;
+
+    /* triangle soup: every mesh baked to world space (TriangleMesh.cpp:542-552) */
+    uint32_t       n_tris;
+    const float   *tri_pos;     /* n_tris*9 : p0 p1 p2                        */
+    const float   *tri_normal;  /* n_tris*9 : n0 n1 n2 (normal-matrix, unnormalised) */
+    const float   *tri_uv;      /* n_tris*6                                   */
+    const int32_t *tri_bsdf;    /* n_tris   : index into bsdfs                */
+    const uint8_t *tri_smooth;  /* n_tris   : mesh "smooth" flag              */
+
+    uint32_t         n_quads;   const tgpu_quad    *quads;
+    uint32_t         n_cubes;   const tgpu_cube    *cubes;
+    uint32_t         n_bsdfs;   const tgpu_bsdf    *bsdfs;
+    uint32_t         n_textures;const tgpu_texture *textures;
+    uint32_t         n_bitmaps; const tgpu_bitmap  *bitmaps;
+    uint32_t         n_lights;  const tgpu_light   *lights;
+    tgpu_env         env;
+
+    /* Joe-Kuo Sobol' generator matrices, 1024 dimensions x 32 columns
+     * (thirdparty/sobol/sobol.h:28-53; columns >= 32 are unreachable with a
+     * 32-bit sample index).                                                  */
+    const uint32_t *sobol_matrices;
+} tgpu_scene_desc;
+
+/* The image-plane shard this context renders: a list of pixels in the order
+ * the host wants them processed plus the seed of the 16x16 tile each pixel
+ * belongs to (PathTraceIntegrator.cpp:27-42 dices tiles and draws the seeds;
+ * SobolPathSampler.hpp:47-52 derives scramble = seed ^ hash32(pixelId)).     */
+typedef struct tgpu_shard_desc {
+    uint32_t        n_pixels;
+    const uint32_t *pixel_index;  /* x + y*res_x                             */
+    const uint32_t *tile_seed;    /* per listed pixel                        */
+} tgpu_shard_desc;
+
+typedef struct tgpu_stats {
+    uint64_t samples;          /* camera paths traced since upload            */
+    uint64_t extend_rays;      /* closest-hit rays                            */
+    uint64_t shadow_rays;      /* any-hit rays                                */
+    uint64_t extend_node_visits, extend_tri_tests;   /* 0 unless counting on  */
+    uint64_t shadow_node_visits, shadow_tri_tests;
+    uint64_t surface_events;
+    double   extend_ms, shadow_ms, shade_ms, other_ms; /* HIP-event kernel time, when timing on */
+    uint64_t extend_launches, shadow_launches;
+} tgpu_stats;
+
+typedef struct tgpu_ctx tgpu_ctx;
+
+/* Create a context on HIP device `device`.  Replaces nothing in the reference
+ * (EmbreeUtil::initDevice, Shared.hpp:165 is the nearest analogue).          */
+int tgpu_init(int device, tgpu_ctx **out);
+void tgpu_destroy(tgpu_ctx *ctx);
+const char *tgpu_last_error(const tgpu_ctx *ctx);
+
+/* TraceableScene ctor + Integrator::prepareForRender
+ * (TraceableScene.hpp:57-137, PathTraceIntegrator.cpp:184-201): copies the
+ * flattened scene to HBM, builds the BVH, allocates the wavefront queues for
+ * `max_paths_in_flight` paths (0 = pick from shard size).                    */
+int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *scene,
+                      const tgpu_shard_desc *shard, uint64_t max_paths_in_flight);
+
+/* Integrator::startRender (PathTraceIntegrator.cpp:220-239): enqueue one pass
+ * tracing samples [spp_begin, spp_begin+spp_count) of every pixel of the shard
+ * and folding them into the running per-pixel mean in the order
+ * OutputBuffer::addSample would (OutputBuffer.hpp:104-132).  Asynchronous with
+ * respect to the host up to internal queue-drain checks; `stream` is a
+ * hipStream_t (NULL = the context's own stream).                             */
+int tgpu_render_pass(tgpu_ctx *ctx, uint32_t spp_begin, uint32_t spp_count, void *stream);
+
+/* Integrator::waitForCompletion (PathTraceIntegrator.cpp:241-247).           */
+int tgpu_wait(tgpu_ctx *ctx);
+/* Integrator::abortRender (PathTraceIntegrator.cpp:249-256); callable from
+ * another host thread while tgpu_render_pass runs.                           */
+int tgpu_abort(tgpu_ctx *ctx);
+
+/* Camera::colorBuffer() contents for the shard (OutputBuffer.hpp:134-144):
+ * rgb_mean is n_pixels*3 floats, sample_count n_pixels, both in shard order.
+ * Either pointer may be NULL.  Host destination.                             */
+int tgpu_download(tgpu_ctx *ctx, float *rgb_mean, uint32_t *sample_count);
+/* Same data written to DEVICE memory the caller owns (e.g. a torch tensor that
+ * is then gathered over RCCL): n_pixels*3 floats.                            */
+int tgpu_resolve_to_device(tgpu_ctx *ctx, void *device_rgb, void *stream);
+/* Integrator::resumeRender support: restore running means + counts.          */
+int tgpu_upload_framebuffer(tgpu_ctx *ctx, const float *rgb_mean, const uint32_t *sample_count);
+
+/* Ray-level entry points used by the parity tests (TraceableScene::intersect /
+ * generalizedShadowRay on dumped ray batches).  rays: n*8 floats
+ * (ox,oy,oz,tnear,dx,dy,dz,tfar) in host memory; hits: n*4 floats
+ * (t,u,v,bitcast prim id; prim id 0xFFFFFFFF = miss); occluded: n bytes.     */
+int tgpu_trace_closest(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits);
+int tgpu_trace_occluded(tgpu_ctx *ctx, const float *rays, uint32_t n, uint8_t *occluded);
+
+/* Counters (rays, visits, kernel ms).  flags bit0 = count BVH visits (slower
+ * kernels), bit1 = time kernels with HIP events.                             */
+int tgpu_set_profiling(tgpu_ctx *ctx, uint32_t flags);
+int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out);
+int tgpu_reset_stats(tgpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUNGSTEN_AMD_H_ */

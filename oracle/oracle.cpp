@@ -1,0 +1,1643 @@
+// oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle.h).
+//
+// CPU restatement of daseyb/tungsten's path_tracer hot path.  Every function
+// cites the reference file:line it follows (paths relative to
+// /root/reference/src/core unless noted).  Arithmetic is written in the
+// reference's operation order; build with -ffp-contract=off (the reference
+// build has no FMA contraction).
+#include "oracle.h"
+#include "../include/tgpu_math.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+#if defined(__SSE__)
+#include <xmmintrin.h>
+#endif
+
+namespace {
+
+// ---- constants (math/Angle.hpp:8-16) ------------------------------------------------
+constexpr float PI = 3.1415926536f;
+constexpr float TWO_PI = PI*2.0f;
+constexpr float INV_PI = 1.0f/PI;
+constexpr float INV_TWO_PI = 0.5f*INV_PI;
+constexpr float INV_FOUR_PI = 0.25f*INV_PI;
+const float INF = std::numeric_limits<float>::infinity();
+
+// ---- Vec3f (math/Vec.hpp:127-193) ---------------------------------------------------
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    explicit V3(float a) : x(a), y(a), z(a) {}
+    V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    explicit V3(const float *p) : x(p[0]), y(p[1]), z(p[2]) {}
+    float operator[](int i) const { return (&x)[i]; }
+    float &operator[](int i) { return (&x)[i]; }
+    V3 operator+(const V3 &o) const { return V3(x + o.x, y + o.y, z + o.z); }
+    V3 operator-(const V3 &o) const { return V3(x - o.x, y - o.y, z - o.z); }
+    V3 operator*(const V3 &o) const { return V3(x*o.x, y*o.y, z*o.z); }
+    V3 operator/(const V3 &o) const { return V3(x/o.x, y/o.y, z/o.z); }
+    V3 operator*(float s) const { return V3(x*s, y*s, z*s); }
+    V3 operator/(float s) const { return V3(x/s, y/s, z/s); }
+    V3 operator+(float s) const { return V3(x + s, y + s, z + s); }
+    V3 operator-(float s) const { return V3(x - s, y - s, z - s); }
+    V3 operator-() const { return V3(-x, -y, -z); }
+    V3 &operator+=(const V3 &o) { x += o.x; y += o.y; z += o.z; return *this; }
+    V3 &operator*=(const V3 &o) { x *= o.x; y *= o.y; z *= o.z; return *this; }
+    V3 &operator*=(float s) { x *= s; y *= s; z *= s; return *this; }
+    V3 &operator/=(float s) { x /= s; y /= s; z /= s; return *this; }
+    bool operator==(float s) const { return x == s && y == s && z == s; }
+    float dot(const V3 &o) const { float s = x*o.x; s += y*o.y; s += z*o.z; return s; }
+    float lengthSq() const { float r = 0.0f; r += x*x; r += y*y; r += z*z; return r; }
+    float length() const { return std::sqrt(lengthSq()); }
+    V3 normalized() const { float inv = 1.0f/length(); return V3(x*inv, y*inv, z*inv); }
+    V3 cross(const V3 &o) const { return V3(y*o.z - z*o.y, z*o.x - x*o.z, x*o.y - y*o.x); }
+    float sum() const { float r = x; r += y; r += z; return r; }
+    float avg() const { return sum()*(1.0f/3.0f); }
+    float max() const { float m = x; if (y > m) m = y; if (z > m) m = z; return m; }
+    float luminance() const { return x*0.2126f + y*0.7152f + z*0.0722f; }
+};
+inline V3 operator*(float s, const V3 &v) { return V3(v.x*s, v.y*s, v.z*s); }
+inline V3 vabs(const V3 &v) { return V3(std::abs(v.x), std::abs(v.y), std::abs(v.z)); }
+inline float fmin2(float a, float b) { return a < b ? a : b; } // Tungsten::min (MathUtil.hpp)
+inline float fmax2(float a, float b) { return a > b ? a : b; }
+inline float clampf(float v, float lo, float hi) { return fmin2(fmax2(v, lo), hi); } // clamp = min(max(val,minVal),maxVal)
+inline bool isnanV(const V3 &v) { return std::isnan(v.x) || std::isnan(v.y) || std::isnan(v.z); }
+inline bool isinfV(const V3 &v) { return std::isinf(v.x) || std::isinf(v.y) || std::isinf(v.z); }
+
+// Mat4f*Vec3f with zero translation column (math/Mat4f.hpp:320-327): the "+ 0" is kept.
+inline V3 mulPoint0(const float *m, const V3 &b)
+{
+    return V3(m[0]*b.x + m[1]*b.y + m[2]*b.z + 0.0f, m[3]*b.x + m[4]*b.y + m[5]*b.z + 0.0f, m[6]*b.x + m[7]*b.y + m[8]*b.z + 0.0f);
+}
+inline V3 mulVector(const float *m, const V3 &b) // Mat4f::transformVector (Mat4f.hpp:159-166)
+{
+    return V3(m[0]*b.x + m[1]*b.y + m[2]*b.z, m[3]*b.x + m[4]*b.y + m[5]*b.z, m[6]*b.x + m[7]*b.y + m[8]*b.z);
+}
+
+// ---- BsdfLobes (bsdfs/BsdfLobes.hpp) --------------------------------------------------
+enum : uint32_t {
+    GlossyReflectionLobe = 1u << 0, GlossyTransmissionLobe = 1u << 1, DiffuseReflectionLobe = 1u << 2,
+    DiffuseTransmissionLobe = 1u << 3, SpecularReflectionLobe = 1u << 4, SpecularTransmissionLobe = 1u << 5,
+    AnisotropicLobe = 1u << 6, ForwardLobe = 1u << 7,
+    SpecularLobe = SpecularReflectionLobe | SpecularTransmissionLobe,
+    TransmissiveLobe = GlossyTransmissionLobe | DiffuseTransmissionLobe | SpecularTransmissionLobe,
+    ReflectiveLobe = GlossyReflectionLobe | DiffuseReflectionLobe | SpecularReflectionLobe,
+    AllLobes = TransmissiveLobe | ReflectiveLobe | AnisotropicLobe,
+    AllButSpecular = ~(SpecularLobe | ForwardLobe),
+};
+
+// ---- sampler --------------------------------------------------------------------------
+inline uint32_t hash32(uint32_t x) // math/MathUtil.hpp:120-128
+{
+    x = ~x + (x << 15);
+    x = x ^ (x >> 12);
+    x = x + (x << 2);
+    x = x ^ (x >> 4);
+    x = x*2057;
+    x = x ^ (x >> 16);
+    return x;
+}
+inline float normalizedUint(uint32_t i) // math/BitManip.hpp:47-50
+{
+    return tgpu_bits_to_float((i >> 9u) | 0x3F800000u) - 1.0f;
+}
+struct Pcg32 { // sampling/UniformSampler.hpp:22-52
+    uint64_t state = 0xBA5EBA11ull, sequence = 0;
+    Pcg32() {}
+    explicit Pcg32(uint64_t seed, uint64_t seq = 0) : state(seed), sequence(seq) {}
+    uint32_t nextI()
+    {
+        uint64_t oldState = state;
+        state = oldState*6364136223846793005ULL + (sequence | 1);
+        uint32_t xorShifted = uint32_t(((oldState >> 18u) ^ oldState) >> 27u);
+        uint32_t rot = uint32_t(oldState >> 59u);
+        return (xorShifted >> rot) | (xorShifted << (uint32_t(-int32_t(rot)) & 31));
+    }
+    float next1D() { return normalizedUint(nextI()); }
+};
+
+struct Sampler { // sampling/SobolPathSampler.hpp:20-84 and sampling/UniformPathSampler.hpp
+    const uint32_t *matrices = nullptr;
+    bool sobol = true;
+    Pcg32 *supplemental = nullptr; // the tile's stream (rng 0) or the path's own (rng 1)
+    Pcg32 local;
+    uint32_t seed = 0, scramble = 0, index = 0, dimension = 0;
+
+    uint32_t permutedIndex() const { return (index & ~0xFFu) | ((index + scramble) & 0xFFu); }
+    void startPath(uint32_t pixelId, uint32_t sample)
+    {
+        scramble = seed ^ hash32(pixelId);
+        index = sample;
+        dimension = 0;
+    }
+    bool nextBoolean(float pTrue) { return supplemental->next1D() < pTrue; }
+    float next1D()
+    {
+        if (!sobol || dimension >= 1024) return supplemental->next1D();
+        // thirdparty/sobol/sobol.h:40-53 (only the first 32 columns are reachable with a 32-bit index)
+        uint32_t result = scramble;
+        uint32_t idx = permutedIndex();
+        for (uint32_t i = dimension*32u; idx; idx >>= 1, ++i)
+            if (idx & 1) result ^= matrices[i];
+        dimension++;
+        return normalizedUint(result);
+    }
+};
+
+// path-local supplemental stream: pcg32_srandom(seed = scramble:sampleIndex, inc = 1)
+inline Pcg32 pathLocalPcg(uint32_t scramble, uint32_t sampleIndex)
+{
+    Pcg32 p(0, 0);
+    p.nextI();
+    p.state += (uint64_t(scramble) << 32) | uint64_t(sampleIndex);
+    p.nextI();
+    return p;
+}
+
+// ---- records ---------------------------------------------------------------------------
+struct Ray { V3 pos, dir; float nearT, farT; };
+enum PrimKind : int { PRIM_NONE = 0, PRIM_TRI = 1, PRIM_QUAD = 2, PRIM_CUBE = 3, PRIM_ENV = 4 };
+struct Temp { // IntersectionTemporary
+    int kind = PRIM_NONE;
+    uint32_t index = 0;
+    float u = 0, v = 0;
+    V3 p, w, Ng; // quad hit point / env origin ; env direction ; mesh unnormalised geometric normal
+    bool backSide = false;
+};
+struct Info { // primitives/IntersectionInfo.hpp
+    V3 Ng, Ns, p, w;
+    float uvx = 0, uvy = 0;
+    float epsilon = 0;
+    int kind = PRIM_NONE;
+    uint32_t index = 0;
+    int bsdf = -1;
+};
+struct Frame { V3 normal, tangent, bitangent; // math/TangentFrame.hpp:22-45
+    V3 toLocal(const V3 &p) const { return V3(tangent.dot(p), bitangent.dot(p), normal.dot(p)); }
+    V3 toGlobal(const V3 &p) const { return tangent*p.x + bitangent*p.y + normal*p.z; }
+};
+inline Frame duffFrame(const V3 &n)
+{
+    Frame f;
+    f.normal = n;
+    float sign = copysignf(1.0f, n.z);
+    const float a = -1.0f/(sign + n.z);
+    const float b = n.x*n.y*a;
+    f.tangent = V3(1.0f + sign*n.x*n.x*a, sign*b, -sign*n.x);
+    f.bitangent = V3(b, sign + n.y*n.y*a, -n.y);
+    return f;
+}
+struct Event { // samplerecords/SurfaceScatterEvent.hpp:14-66
+    const Info *info;
+    Sampler *sampler;
+    Frame frame;
+    V3 wi, wo, weight;
+    float pdf;
+    uint32_t requestedLobe, sampledLobe;
+    bool flippedFrame;
+};
+struct LightSample { V3 d; float dist, pdf; };
+
+struct BvhNode { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; };
+struct TriIsect { V3 v0, e1, e2, Ng; };
+
+} // namespace
+
+// ========================================================================================
+struct oracle_ctx {
+    tgpu_scene_desc sc;
+    int rngMode, mathMode, rcpMode;
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> triOrder;
+    std::vector<TriIsect> tris;
+    std::vector<Pcg32> tilePcg;
+    uint32_t tileSeedBase = 0;
+    bool tilesInit = false;
+    std::atomic<uint64_t> stSamples{0}, stExtend{0}, stShadow{0}, stSurface{0}, stNodes{0}, stTris{0};
+
+    // ---- libm dispatch -----------------------------------------------------------------
+    float msin(float x) const { return mathMode ? tgpu_sinf(x) : std::sin(x); }
+    float mcos(float x) const { return mathMode ? tgpu_cosf(x) : std::cos(x); }
+    float mexp(float x) const { return mathMode ? tgpu_expf(x) : std::exp(x); }
+    float mlog(float x) const { return mathMode ? tgpu_logf(x) : std::log(x); }
+    float matan2(float y, float x) const { return mathMode ? tgpu_atan2f(y, x) : std::atan2(y, x); }
+    float macos(float x) const { return mathMode ? tgpu_acosf(x) : std::acos(x); }
+
+    struct Counters { uint64_t extend = 0, shadow = 0, surface = 0, nodes = 0, tris = 0, samples = 0; };
+
+    // ---- BVH ---------------------------------------------------------------------------
+    void buildBvh();
+    void intersectTris(const Ray &ray, float &bestT, float &bestU, float &bestV, uint32_t &bestPrim, Counters &c) const;
+    bool occludedTris(const Ray &ray, Counters &c) const;
+
+    // ---- textures ----------------------------------------------------------------------
+    V3 bitmapEval(const tgpu_bitmap &bm, float ux, float uy) const;
+    V3 texEval(int tex, float ux, float uy) const;
+
+    // ---- primitives / lights -----------------------------------------------------------
+    bool quadIntersect(const tgpu_quad &q, uint32_t idx, Ray &ray, Temp &data) const;
+    bool cubeIntersect(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const;
+    void intersectionInfo(const Temp &data, Info &info) const;
+    bool intersect(Ray &ray, Temp &data, Info &info, Counters &c) const;
+    void directionToUV(const V3 &wi, float &ux, float &uy, float *sinTheta) const;
+    V3 uvToDirection(float ux, float uy, float &sinTheta) const;
+    float envPdf(float ux, float uy) const;
+
+    bool lightSampleDirect(const tgpu_light &l, const V3 &p, Sampler &s, LightSample &out) const;
+    bool lightIntersect(const tgpu_light &l, Ray &ray, Temp &data) const;
+    float lightDirectPdf(const tgpu_light &l, const Temp &data, const Info &info, const V3 &p) const;
+    V3 primEvalDirect(const Temp &data, const Info &info) const;
+    bool primEmissive(int kind, uint32_t index) const;
+    bool primSamplable(int kind, uint32_t index) const;
+    float lightApproximateRadiance(const tgpu_light &l, const V3 &p) const;
+
+    // ---- BSDFs -------------------------------------------------------------------------
+    uint32_t bsdfLobes(int b) const;
+    V3 bsdfEval(int b, const Event &e) const;
+    bool bsdfSample(int b, Event &e) const;
+    float bsdfPdf(int b, const Event &e) const;
+
+    // ---- integrator --------------------------------------------------------------------
+    Event makeLocalScatterEvent(const Temp &data, const Info &info, const Ray &ray, Sampler *sampler) const;
+    V3 shadowRay(Ray &ray, int endKind, uint32_t endIndex, int bounce, Counters &c) const;
+    V3 attenuatedEmission(const tgpu_light &l, float expectedDist, Temp &data, Info &info, int bounce, Ray &ray, Counters &c) const;
+    V3 lightSample(const tgpu_light &l, Event &event, int bounce, const Ray &parent, Counters &c) const;
+    V3 bsdfSampleNee(const tgpu_light &l, Event &event, int bounce, const Ray &parent, Counters &c) const;
+    V3 estimateDirect(Event &event, int bounce, const Ray &parent, Counters &c) const;
+    bool handleSurface(Event &event, Temp &data, Info &info, int bounce, bool enableLightSampling, Ray &ray,
+                       V3 &throughput, V3 &emission, bool &wasSpecular, Counters &c) const;
+    V3 traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c) const;
+    void cameraRay(uint32_t px, uint32_t py, float xi0, float xi1, Ray &ray) const;
+};
+
+// ========================================================================================
+// BVH over the triangle soup (own builder: binned SAH, leaves <= 4; the reference's
+// Embree BVH4 is replaced, nearest-hit results do not depend on the tree)
+// ========================================================================================
+void oracle_ctx::buildBvh()
+{
+    uint32_t n = sc.n_tris;
+    tris.resize(n);
+    triOrder.resize(n);
+    std::vector<float> cmin(size_t(n)*3), cmax(size_t(n)*3), cen(size_t(n)*3);
+    for (uint32_t i = 0; i < n; ++i) {
+        triOrder[i] = i;
+        V3 p0(sc.tri_pos + size_t(i)*9), p1(sc.tri_pos + size_t(i)*9 + 3), p2(sc.tri_pos + size_t(i)*9 + 6);
+        // Embree TriangleM: v0, e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e1, e2)
+        // (thirdparty/embree/kernels/geometry/triangle.h:53-54, triangle_intersector_moeller.h:118-120)
+        tris[i].v0 = p0;
+        tris[i].e1 = p0 - p1;
+        tris[i].e2 = p2 - p0;
+        tris[i].Ng = tris[i].e1.cross(tris[i].e2);
+        for (int k = 0; k < 3; ++k) {
+            cmin[size_t(i)*3 + k] = std::min(p0[k], std::min(p1[k], p2[k]));
+            cmax[size_t(i)*3 + k] = std::max(p0[k], std::max(p1[k], p2[k]));
+            cen[size_t(i)*3 + k] = 0.5f*(cmin[size_t(i)*3 + k] + cmax[size_t(i)*3 + k]);
+        }
+    }
+    nodes.clear();
+    if (n == 0) return;
+    nodes.reserve(size_t(n));
+    struct Task { uint32_t node, first, count; };
+    std::vector<Task> stack;
+    nodes.push_back(BvhNode{});
+    stack.push_back({0, 0, n});
+    while (!stack.empty()) {
+        Task t = stack.back();
+        stack.pop_back();
+        float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF}, clo[3] = {INF, INF, INF}, chi[3] = {-INF, -INF, -INF};
+        for (uint32_t i = t.first; i < t.first + t.count; ++i) {
+            uint32_t id = triOrder[i];
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], cmin[size_t(id)*3 + k]);
+                hi[k] = std::max(hi[k], cmax[size_t(id)*3 + k]);
+                clo[k] = std::min(clo[k], cen[size_t(id)*3 + k]);
+                chi[k] = std::max(chi[k], cen[size_t(id)*3 + k]);
+            }
+        }
+        BvhNode nd{};
+        for (int k = 0; k < 3; ++k) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
+        nd.left = nd.right = -1;
+        nd.first = t.first;
+        nd.count = t.count;
+        uint32_t mid = 0;
+        bool split = false;
+        if (t.count > 4) {
+            const int B = 16;
+            float bestCost = INF;
+            int bestAxis = -1, bestBin = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                float ext = chi[ax] - clo[ax];
+                if (!(ext > 0.0f)) continue;
+                uint32_t cnt[B] = {0};
+                float blo[B][3], bhi[B][3];
+                for (int b = 0; b < B; ++b)
+                    for (int k = 0; k < 3; ++k) { blo[b][k] = INF; bhi[b][k] = -INF; }
+                for (uint32_t i = t.first; i < t.first + t.count; ++i) {
+                    uint32_t id = triOrder[i];
+                    int b = std::min(B - 1, int((cen[size_t(id)*3 + ax] - clo[ax])/ext*B));
+                    cnt[b]++;
+                    for (int k = 0; k < 3; ++k) {
+                        blo[b][k] = std::min(blo[b][k], cmin[size_t(id)*3 + k]);
+                        bhi[b][k] = std::max(bhi[b][k], cmax[size_t(id)*3 + k]);
+                    }
+                }
+                float rArea[B];
+                uint32_t rCnt[B];
+                float alo[3] = {INF, INF, INF}, ahi[3] = {-INF, -INF, -INF};
+                uint32_t acc = 0;
+                for (int b = B - 1; b > 0; --b) {
+                    for (int k = 0; k < 3; ++k) { alo[k] = std::min(alo[k], blo[b][k]); ahi[k] = std::max(ahi[k], bhi[b][k]); }
+                    acc += cnt[b];
+                    float dx = ahi[0] - alo[0], dy = ahi[1] - alo[1], dz = ahi[2] - alo[2];
+                    rArea[b] = acc ? dx*dy + dy*dz + dz*dx : 0.0f;
+                    rCnt[b] = acc;
+                }
+                for (int k = 0; k < 3; ++k) { alo[k] = INF; ahi[k] = -INF; }
+                acc = 0;
+                for (int b = 0; b < B - 1; ++b) {
+                    for (int k = 0; k < 3; ++k) { alo[k] = std::min(alo[k], blo[b][k]); ahi[k] = std::max(ahi[k], bhi[b][k]); }
+                    acc += cnt[b];
+                    if (acc == 0 || rCnt[b + 1] == 0) continue;
+                    float dx = ahi[0] - alo[0], dy = ahi[1] - alo[1], dz = ahi[2] - alo[2];
+                    float cost = (dx*dy + dy*dz + dz*dx)*acc + rArea[b + 1]*rCnt[b + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = b; }
+                }
+            }
+            if (bestAxis >= 0) {
+                float ext = chi[bestAxis] - clo[bestAxis];
+                auto it = std::partition(triOrder.begin() + t.first, triOrder.begin() + t.first + t.count, [&](uint32_t id) {
+                    int b = std::min(B - 1, int((cen[size_t(id)*3 + bestAxis] - clo[bestAxis])/ext*B));
+                    return b <= bestBin;
+                });
+                mid = uint32_t(it - triOrder.begin());
+                split = mid > t.first && mid < t.first + t.count;
+            }
+            if (!split) { // degenerate: median split by index
+                mid = t.first + t.count/2;
+                split = true;
+            }
+        }
+        if (split) {
+            nd.left = int32_t(nodes.size());
+            nd.right = nd.left + 1;
+            nd.count = 0;
+            nodes.push_back(BvhNode{});
+            nodes.push_back(BvhNode{});
+            stack.push_back({uint32_t(nd.left), t.first, mid - t.first});
+            stack.push_back({uint32_t(nd.right), mid, t.first + t.count - mid});
+        }
+        nodes[t.node] = nd;
+    }
+}
+
+static inline bool slab(const BvhNode &n, const V3 &o, const V3 &inv, float tnear, float tfar)
+{
+    // conservative slab test: a ray parallel to a slab only has to start inside it
+    float t0 = tnear, t1 = tfar;
+    for (int k = 0; k < 3; ++k) {
+        if (std::isinf(inv[k])) {
+            if (o[k] < n.lo[k] || o[k] > n.hi[k]) return false;
+            continue;
+        }
+        float a = (n.lo[k] - o[k])*inv[k], b = (n.hi[k] - o[k])*inv[k];
+        float mn = a < b ? a : b, mx = a < b ? b : a;
+        if (mn > t0) t0 = mn;
+        if (mx < t1) t1 = mx;
+    }
+    return t0 <= t1*1.0000004f;
+}
+
+namespace {
+struct TriHit { bool valid; float t, u, v; };
+}
+
+// Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113,
+// finalize :43-49; dot/cross order common/math/vec3.h:182,187)
+static inline TriHit triTest(const TriIsect &tri, const Ray &ray, float tfar0, int rcpMode)
+{
+    auto edot = [](const V3 &a, const V3 &b) { return a.x*b.x + (a.y*b.y + a.z*b.z); };
+    TriHit h{false, 0, 0, 0};
+    const V3 &O = ray.pos, &D = ray.dir;
+    V3 C = tri.v0 - O;
+    V3 R = D.cross(C);
+    float den = edot(tri.Ng, D);
+    float absDen = std::abs(den);
+    uint32_t sgn = tgpu_float_to_bits(den) & 0x80000000u;
+    float U = tgpu_bits_to_float(tgpu_float_to_bits(edot(R, tri.e2)) ^ sgn);
+    float V = tgpu_bits_to_float(tgpu_float_to_bits(edot(R, tri.e1)) ^ sgn);
+    if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen)) return h;
+    float T = tgpu_bits_to_float(tgpu_float_to_bits(edot(tri.Ng, C)) ^ sgn);
+    if (!(T > absDen*ray.nearT && T < absDen*tfar0)) return h;
+    h.valid = true;
+#if defined(__SSE__)
+    if (rcpMode) {
+        float r = _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(absDen)));
+        float rcp = r*(2.0f - r*absDen);
+        h.t = T*rcp; h.u = U*rcp; h.v = V*rcp;
+        return h;
+    }
+#endif
+    (void)rcpMode;
+    h.t = T/absDen; h.u = U/absDen; h.v = V/absDen;
+    return h;
+}
+
+// nearest hit = lexicographic minimum of (t, triangle id) over all valid triangles
+void oracle_ctx::intersectTris(const Ray &ray, float &bestT, float &bestU, float &bestV, uint32_t &bestPrim, Counters &c) const
+{
+    if (nodes.empty()) return;
+    const float tfar0 = bestT;
+    V3 inv(1.0f/ray.dir.x, 1.0f/ray.dir.y, 1.0f/ray.dir.z);
+    int stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const BvhNode &n = nodes[size_t(stack[--sp])];
+        c.nodes++;
+        if (!slab(n, ray.pos, inv, ray.nearT, bestT)) continue;
+        if (n.left < 0) {
+            for (uint32_t i = n.first; i < n.first + n.count; ++i) {
+                uint32_t id = triOrder[i];
+                c.tris++;
+                TriHit h = triTest(tris[id], ray, tfar0, rcpMode);
+                if (h.valid && (h.t < bestT || (h.t == bestT && id < bestPrim))) {
+                    bestT = h.t; bestU = h.u; bestV = h.v; bestPrim = id;
+                }
+            }
+        } else {
+            if (sp + 2 > 128) continue; // cannot happen for depth < 64
+            stack[sp++] = n.left;
+            stack[sp++] = n.right;
+        }
+    }
+}
+
+bool oracle_ctx::occludedTris(const Ray &ray, Counters &c) const
+{
+    if (nodes.empty()) return false;
+    V3 inv(1.0f/ray.dir.x, 1.0f/ray.dir.y, 1.0f/ray.dir.z);
+    int stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const BvhNode &n = nodes[size_t(stack[--sp])];
+        c.nodes++;
+        if (!slab(n, ray.pos, inv, ray.nearT, ray.farT)) continue;
+        if (n.left < 0) {
+            for (uint32_t i = n.first; i < n.first + n.count; ++i) {
+                c.tris++;
+                if (triTest(tris[triOrder[i]], ray, ray.farT, rcpMode).valid) return true;
+            }
+        } else {
+            if (sp + 2 > 128) continue;
+            stack[sp++] = n.left;
+            stack[sp++] = n.right;
+        }
+    }
+    return false;
+}
+
+// ========================================================================================
+// textures
+// ========================================================================================
+V3 oracle_ctx::bitmapEval(const tgpu_bitmap &bm, float ux, float uy) const // textures/BitmapTexture.cpp:298-352
+{
+    int w = bm.w, h = bm.h;
+    float u = ux*w;
+    float v = (1.0f - uy)*h;
+    bool linear = bm.linear != 0;
+    if (linear) {
+        u -= 0.5f;
+        v -= 0.5f;
+    }
+    int iu0 = u < 0.0f ? -int(-u) - 1 : int(u);
+    int iv0 = v < 0.0f ? -int(-v) - 1 : int(v);
+    int iu1 = iu0 + 1;
+    int iv1 = iv0 + 1;
+    u -= iu0;
+    v -= iv0;
+    if (!bm.clamp) {
+        iu0 = ((iu0 % w) + w) % w;
+        iu1 = ((iu1 % w) + w) % w;
+        iv0 = ((iv0 % h) + h) % h;
+        iv1 = ((iv1 % h) + h) % h;
+    } else {
+        iu0 = std::min(std::max(iu0, 0), w - 1);
+        iu1 = std::min(std::max(iu1, 0), w - 1);
+        iv0 = std::min(std::max(iv0, 0), h - 1);
+        iv1 = std::min(std::max(iv1, 0), h - 1);
+    }
+    auto rgb = [&](int x, int y) { return V3(bm.texels + (size_t(x) + size_t(y)*w)*3); };
+    if (!linear) return rgb(iu0, iv0);
+    V3 x00 = rgb(iu0, iv0), x01 = rgb(iu1, iv0), x10 = rgb(iu0, iv1), x11 = rgb(iu1, iv1);
+    V3 l = (x00*(1.0f - u) + x01*u)*(1.0f - v) + (x10*(1.0f - u) + x11*u)*v; // :124-128
+    return bm.scale*l;
+}
+
+V3 oracle_ctx::texEval(int tex, float ux, float uy) const
+{
+    const tgpu_texture &t = sc.textures[tex];
+    switch (t.type) {
+    case TGPU_TEX_CONSTANT: return V3(t.value);
+    case TGPU_TEX_CHECKER: { // textures/CheckerTexture.cpp:64-69
+        int ui = int(ux*float(t.res_u)), vi = int(uy*float(t.res_v));
+        bool on = (ui ^ vi) & 1;
+        return on ? V3(t.on_color) : V3(t.off_color);
+    }
+    default: return bitmapEval(sc.bitmaps[t.bitmap], ux, uy);
+    }
+}
+
+// ========================================================================================
+// primitives
+// ========================================================================================
+bool oracle_ctx::quadIntersect(const tgpu_quad &q, uint32_t idx, Ray &ray, Temp &data) const // primitives/Quad.cpp:71-98
+{
+    V3 normal(q.normal), base(q.base), edge0(q.edge0), edge1(q.edge1);
+    float nDotW = ray.dir.dot(normal);
+    if (std::abs(nDotW) < 1e-6f) return false;
+    float t = normal.dot(base - ray.pos)/nDotW;
+    if (t < ray.nearT || t > ray.farT) return false;
+    V3 qp = ray.pos + t*ray.dir;
+    V3 v = qp - base;
+    float l0 = v.dot(edge0)*q.inv_uv_sq[0];
+    float l1 = v.dot(edge1)*q.inv_uv_sq[1];
+    if (l0 < 0.0f || l0 > 1.0f || l1 < 0.0f || l1 > 1.0f) return false;
+    ray.farT = t;
+    data.kind = PRIM_QUAD;
+    data.index = idx;
+    data.p = qp;
+    data.u = l0;
+    data.v = l1;
+    data.backSide = nDotW >= 0.0f;
+    return true;
+}
+
+bool oracle_ctx::cubeIntersect(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const // primitives/Cube.cpp:94-127
+{
+    V3 p = mulPoint0(cb.inv_rot, ray.pos - V3(cb.pos));
+    V3 d = mulPoint0(cb.inv_rot, ray.dir);
+    V3 invD = V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    V3 scale(cb.scale);
+    V3 relMin = -scale - p;
+    V3 relMax = scale - p;
+    float ttMin = ray.nearT, ttMax = ray.farT;
+    for (int i = 0; i < 3; ++i) {
+        if (invD[i] >= 0.0f) {
+            ttMin = fmax2(ttMin, relMin[i]*invD[i]);
+            ttMax = fmin2(ttMax, relMax[i]*invD[i]);
+        } else {
+            ttMax = fmin2(ttMax, relMin[i]*invD[i]);
+            ttMin = fmax2(ttMin, relMax[i]*invD[i]);
+        }
+    }
+    if (ttMin <= ttMax) {
+        if (ttMin > ray.nearT && ttMin < ray.farT) {
+            data.kind = PRIM_CUBE; data.index = idx;
+            ray.farT = ttMin;
+            data.backSide = false;
+        } else if (ttMax > ray.nearT && ttMax < ray.farT) {
+            data.kind = PRIM_CUBE; data.index = idx;
+            ray.farT = ttMax;
+            data.backSide = true;
+        }
+        return true;
+    }
+    return false;
+}
+
+void oracle_ctx::intersectionInfo(const Temp &data, Info &info) const
+{
+    info.kind = data.kind;
+    info.index = data.index;
+    switch (data.kind) {
+    case PRIM_TRI: { // primitives/TriangleMesh.cpp:344-355, :90-106
+        uint32_t i = data.index;
+        info.Ng = data.Ng.normalized();
+        if (sc.tri_smooth[i]) {
+            const float *n = sc.tri_normal + size_t(i)*9;
+            V3 n0(n), n1(n + 3), n2(n + 6);
+            info.Ns = ((1.0f - data.u - data.v)*n0 + data.u*n1 + data.v*n2).normalized();
+        } else {
+            info.Ns = info.Ng;
+        }
+        const float *uv = sc.tri_uv + size_t(i)*6;
+        float w0 = 1.0f - data.u - data.v;
+        info.uvx = w0*uv[0] + data.u*uv[2] + data.v*uv[4];
+        info.uvy = w0*uv[1] + data.u*uv[3] + data.v*uv[5];
+        info.bsdf = sc.tri_bsdf[i];
+        break;
+    }
+    case PRIM_QUAD: { // primitives/Quad.cpp:123-131
+        const tgpu_quad &q = sc.quads[data.index];
+        info.Ng = info.Ns = V3(q.normal);
+        info.p = data.p;
+        info.uvx = data.u; info.uvy = data.v;
+        info.bsdf = q.bsdf;
+        break;
+    }
+    case PRIM_CUBE: { // primitives/Cube.cpp:157-170
+        const tgpu_cube &cb = sc.cubes[data.index];
+        V3 p = mulPoint0(cb.inv_rot, info.p - V3(cb.pos));
+        V3 n(0.0f);
+        V3 a = vabs(p) - V3(cb.scale);
+        int dim = 0; // Vec::maxDim
+        if (a.y > a[dim]) dim = 1;
+        if (a.z > a[dim]) dim = 2;
+        n[dim] = p[dim] < 0.0f ? -1.0f : 1.0f;
+        V3 uvw = (p/V3(cb.scale))*0.5f + 0.5f;
+        info.Ns = info.Ng = mulPoint0(cb.rot, n);
+        info.uvx = uvw[(dim + 1) % 3];
+        info.uvy = uvw[(dim + 2) % 3];
+        info.bsdf = cb.bsdf;
+        break;
+    }
+    case PRIM_ENV: { // primitives/InfiniteSphere.cpp:96-104
+        info.Ng = info.Ns = -data.w;
+        info.p = data.p;
+        directionToUV(data.w, info.uvx, info.uvy, nullptr);
+        info.bsdf = -1;
+        break;
+    }
+    default: break;
+    }
+}
+
+bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const // renderer/TraceableScene.hpp:170-192
+{
+    info.kind = PRIM_NONE;
+    data.kind = PRIM_NONE;
+    for (uint32_t i = 0; i < sc.n_quads; ++i) quadIntersect(sc.quads[i], i, ray, data);
+    for (uint32_t i = 0; i < sc.n_cubes; ++i) cubeIntersect(sc.cubes[i], i, ray, data);
+    float t = ray.farT, u = 0, v = 0;
+    uint32_t prim = 0xFFFFFFFFu;
+    intersectTris(ray, t, u, v, prim, c);
+    if (prim != 0xFFFFFFFFu) { // primitives/TriangleMesh.cpp:317-335
+        ray.farT = t;
+        data.kind = PRIM_TRI;
+        data.index = prim;
+        data.u = u;
+        data.v = v;
+        const float *p = sc.tri_pos + size_t(prim)*9;
+        V3 p0(p), p1(p + 3), p2(p + 6);
+        data.Ng = (p1 - p0).cross(p2 - p0); // unnormalizedGeometricNormalAt :81-88
+        data.backSide = data.Ng.dot(ray.dir) > 0.0f;
+    }
+    if (data.kind != PRIM_NONE) {
+        info.p = ray.pos + ray.dir*ray.farT;
+        info.w = ray.dir;
+        info.epsilon = 5e-4f;
+        intersectionInfo(data, info);
+        return true;
+    }
+    return false;
+}
+
+void oracle_ctx::directionToUV(const V3 &wi, float &ux, float &uy, float *sinTheta) const // InfiniteSphere.cpp:27-38
+{
+    V3 wLocal = mulPoint0(sc.env.inv_rot, wi);
+    if (sinTheta) *sinTheta = std::sqrt(fmax2(1.0f - wLocal.y*wLocal.y, 0.0f));
+    ux = matan2(wLocal.z, wLocal.x)*INV_TWO_PI + 0.5f;
+    uy = macos(-wLocal.y)*INV_PI;
+}
+
+V3 oracle_ctx::uvToDirection(float ux, float uy, float &sinTheta) const // InfiniteSphere.cpp:40-50
+{
+    float phi = (ux - 0.5f)*TWO_PI;
+    float theta = uy*PI;
+    sinTheta = msin(theta);
+    return mulPoint0(sc.env.rot, V3(mcos(phi)*sinTheta, -mcos(theta), msin(phi)*sinTheta));
+}
+
+float oracle_ctx::envPdf(float ux, float uy) const // BitmapTexture.cpp:452-455, Distribution2D.hpp:66-71
+{
+    int w = sc.env.dist_w, h = sc.env.dist_h;
+    int row = int((1.0f - uy)*h), column = int(ux*w);
+    row = std::min(std::max(row, 0), h - 1);
+    column = std::min(std::max(column, 0), w - 1);
+    return sc.env.pdf[size_t(row)*w + column]*sc.env.marginal_pdf[row]*w*h;
+}
+
+bool oracle_ctx::primEmissive(int kind, uint32_t index) const
+{
+    if (kind == PRIM_QUAD) return sc.quads[index].emission_tex >= 0;
+    if (kind == PRIM_CUBE) return sc.cubes[index].emission_tex >= 0;
+    if (kind == PRIM_ENV) return true;
+    return false;
+}
+bool oracle_ctx::primSamplable(int kind, uint32_t /*index*/) const
+{
+    if (kind == PRIM_QUAD) return true;
+    if (kind == PRIM_ENV) return sc.env.samplable != 0;
+    return true; // meshes/cubes: isSamplable() true, but never emissive in scope
+}
+
+V3 oracle_ctx::primEvalDirect(const Temp &data, const Info &info) const
+{
+    switch (data.kind) {
+    case PRIM_QUAD: { // Quad.cpp:235-238
+        const tgpu_quad &q = sc.quads[data.index];
+        if (q.emission_tex < 0 || data.backSide) return V3(0.0f);
+        return texEval(q.emission_tex, info.uvx, info.uvy);
+    }
+    case PRIM_ENV: return texEval(sc.env.emission_tex, info.uvx, info.uvy); // InfiniteSphere.cpp:241-244
+    default: return V3(0.0f); // Primitive::evalDirect with no emission (Primitive.cpp:104-111)
+    }
+}
+
+bool oracle_ctx::lightSampleDirect(const tgpu_light &l, const V3 &p, Sampler &s, LightSample &out) const
+{
+    if (l.kind == TGPU_LIGHT_ENV) { // InfiniteSphere.cpp:161-176
+        const tgpu_texture &tex = sc.textures[sc.env.emission_tex];
+        if (tex.type == TGPU_TEX_CONSTANT) {
+            float xi0 = s.next1D(), xi1 = s.next1D();
+            float phi = xi0*TWO_PI; // SampleWarp::uniformSphere (SampleWarp.hpp:96-107)
+            float z = xi1*2.0f - 1.0f;
+            float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
+            out.d = V3(mcos(phi)*r, msin(phi)*r, z);
+            out.dist = INF;
+            out.pdf = INV_FOUR_PI;
+            return true;
+        }
+        float uvx = s.next1D(), uvy = s.next1D();
+        // BitmapTexture::sample (:433-439) -> Distribution2D::warp (Distribution2D.hpp:66-76)
+        int w = sc.env.dist_w, h = sc.env.dist_h;
+        const float *mc = sc.env.marginal_cdf;
+        int row = int(std::upper_bound(mc, mc + h + 1, uvy) - mc) - 1;
+        uvy = clampf((uvy - mc[row])/sc.env.marginal_pdf[row], 0.0f, 1.0f);
+        const float *rs = sc.env.cdf + size_t(row)*(w + 1);
+        int column = int(std::upper_bound(rs, rs + w + 1, uvx) - rs) - 1;
+        uvx = clampf((uvx - rs[column])/sc.env.pdf[size_t(row)*w + column], 0.0f, 1.0f);
+        float ux = (uvx + column)/w;
+        float uy = 1.0f - (uvy + row)/h;
+        float sinTheta;
+        out.d = uvToDirection(ux, uy, sinTheta);
+        out.pdf = INV_PI*INV_TWO_PI*envPdf(ux, uy)/sinTheta;
+        out.dist = INF;
+        return out.pdf != 0.0f;
+    }
+    // Quad.cpp:172-187
+    const tgpu_quad &q = sc.quads[l.index];
+    V3 normal(q.normal), base(q.base);
+    if (normal.dot(p - base) <= 0.0f) return false;
+    float xi0 = s.next1D(), xi1 = s.next1D();
+    V3 qp = base + xi0*V3(q.edge0) + xi1*V3(q.edge1);
+    out.d = qp - p;
+    float rSq = out.d.lengthSq();
+    out.dist = std::sqrt(rSq);
+    out.d /= out.dist;
+    float cosTheta = -normal.dot(out.d);
+    out.pdf = rSq/(cosTheta*q.area);
+    return true;
+}
+
+bool oracle_ctx::lightIntersect(const tgpu_light &l, Ray &ray, Temp &data) const
+{
+    if (l.kind == TGPU_LIGHT_ENV) { // InfiniteSphere.cpp:77-84 (farT is left untouched)
+        data.kind = PRIM_ENV;
+        data.index = 0;
+        data.p = ray.pos;
+        data.w = ray.dir;
+        return true;
+    }
+    return quadIntersect(sc.quads[l.index], uint32_t(l.index), ray, data);
+}
+
+float oracle_ctx::lightDirectPdf(const tgpu_light &l, const Temp &data, const Info &info, const V3 &p) const
+{
+    if (l.kind == TGPU_LIGHT_ENV) { // InfiniteSphere.cpp:218-229
+        if (sc.textures[sc.env.emission_tex].type == TGPU_TEX_CONSTANT) return INV_FOUR_PI;
+        float sinTheta, ux, uy;
+        directionToUV(data.w, ux, uy, &sinTheta);
+        return INV_PI*INV_TWO_PI*envPdf(ux, uy)/sinTheta;
+    }
+    const tgpu_quad &q = sc.quads[l.index]; // Quad.cpp:216-223
+    V3 normal(q.normal);
+    float cosTheta = std::abs(normal.dot(info.w));
+    float t = normal.dot(V3(q.base) - p)/normal.dot(info.w);
+    return t*t/(cosTheta*q.area);
+}
+
+float oracle_ctx::lightApproximateRadiance(const tgpu_light &l, const V3 &p) const
+{
+    if (l.kind == TGPU_LIGHT_ENV) return -1.0f; // only reached with > 1 light; see chooseLight
+    const tgpu_quad &q = sc.quads[l.index]; // Quad.cpp:256-279
+    V3 R0 = V3(q.base) - p;
+    if (R0.dot(V3(q.normal)) >= 0.0f) return 0.0f;
+    V3 R1 = R0 + V3(q.edge0), R2 = R1 + V3(q.edge1), R3 = R0 + V3(q.edge1);
+    V3 n0 = R0.cross(R1).normalized(), n1 = R1.cross(R2).normalized(), n2 = R2.cross(R3).normalized(), n3 = R3.cross(R0).normalized();
+    float Q = macos(n0.dot(n1)) + macos(n1.dot(n2)) + macos(n2.dot(n3)) + macos(n3.dot(n0));
+    const tgpu_texture &t = sc.textures[q.emission_tex];
+    V3 avg = t.type == TGPU_TEX_CONSTANT ? V3(t.value) : V3(0.5f);
+    return (TWO_PI - std::abs(Q))*avg.max();
+}
+
+// ========================================================================================
+// BSDFs
+// ========================================================================================
+uint32_t oracle_ctx::bsdfLobes(int b) const
+{
+    if (b < 0) return 0;
+    const tgpu_bsdf &d = sc.bsdfs[b];
+    switch (d.type) {
+    case TGPU_BSDF_LAMBERT: return DiffuseReflectionLobe;
+    case TGPU_BSDF_ROUGH_CONDUCTOR: return GlossyReflectionLobe;
+    case TGPU_BSDF_SMOOTH_COAT: return SpecularReflectionLobe | bsdfLobes(d.substrate);
+    default: return 0;
+    }
+}
+
+namespace {
+// bsdfs/Microfacet.hpp:27-130 (Beckmann and GGX; Phong is outside the configs)
+inline float roughnessToAlpha(float roughness) { return fmax2(roughness, 1e-3f); }
+struct MF {
+    const oracle_ctx *o;
+    int dist;
+    float D(float alpha, const V3 &m) const
+    {
+        if (m.z <= 0.0f) return 0.0f;
+        float alphaSq = alpha*alpha;
+        float cosThetaSq = m.z*m.z;
+        float tanThetaSq = fmax2(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+        float cosThetaQu = cosThetaSq*cosThetaSq;
+        if (dist == TGPU_DIST_BECKMANN)
+            return INV_PI*o->mexp(-tanThetaSq/alphaSq)/(alphaSq*cosThetaQu);
+        float s = alphaSq + tanThetaSq;
+        return alphaSq*INV_PI/(cosThetaQu*(s*s));
+    }
+    float G1(float alpha, const V3 &v, const V3 &m) const
+    {
+        if (v.dot(m)*v.z <= 0.0f) return 0.0f;
+        if (dist == TGPU_DIST_BECKMANN) {
+            float cosThetaSq = v.z*v.z;
+            float tanTheta = std::abs(std::sqrt(fmax2(1.0f - cosThetaSq, 0.0f))/v.z);
+            float a = 1.0f/(alpha*tanTheta);
+            if (a < 1.6f)
+                return (3.535f*a + 2.181f*a*a)/(1.0f + 2.276f*a + 2.577f*a*a);
+            else
+                return 1.0f;
+        }
+        float alphaSq = alpha*alpha;
+        float cosThetaSq = v.z*v.z;
+        float tanThetaSq = fmax2(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+        return 2.0f/(1.0f + std::sqrt(1.0f + alphaSq*tanThetaSq));
+    }
+    float G(float alpha, const V3 &i, const V3 &oo, const V3 &m) const { return G1(alpha, i, m)*G1(alpha, oo, m); }
+    float pdf(float alpha, const V3 &m) const { return D(alpha, m)*m.z; }
+    V3 sample(float alpha, float xix, float xiy) const
+    {
+        float phi = xiy*TWO_PI;
+        float cosTheta = 0.0f;
+        if (dist == TGPU_DIST_BECKMANN) {
+            float tanThetaSq = -alpha*alpha*o->mlog(1.0f - xix);
+            cosTheta = 1.0f/std::sqrt(1.0f + tanThetaSq);
+        } else {
+            float tanThetaSq = alpha*alpha*xix/(1.0f - xix);
+            cosTheta = 1.0f/std::sqrt(1.0f + tanThetaSq);
+        }
+        float r = std::sqrt(fmax2(1.0f - cosTheta*cosTheta, 0.0f));
+        return V3(o->mcos(phi)*r, o->msin(phi)*r, cosTheta);
+    }
+};
+
+// bsdfs/Fresnel.hpp:102-125
+inline float conductorReflectance(float eta, float k, float cosThetaI)
+{
+    float cosThetaISq = cosThetaI*cosThetaI;
+    float sinThetaISq = fmax2(1.0f - cosThetaISq, 0.0f);
+    float sinThetaIQu = sinThetaISq*sinThetaISq;
+    float innerTerm = eta*eta - k*k - sinThetaISq;
+    float aSqPlusBSq = std::sqrt(fmax2(innerTerm*innerTerm + 4.0f*eta*eta*k*k, 0.0f));
+    float a = std::sqrt(fmax2((aSqPlusBSq + innerTerm)*0.5f, 0.0f));
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f*a*cosThetaI))/((aSqPlusBSq + cosThetaISq) + (2.0f*a*cosThetaI));
+    float Rp = ((cosThetaISq*aSqPlusBSq + sinThetaIQu) - (2.0f*a*cosThetaI*sinThetaISq))/
+               ((cosThetaISq*aSqPlusBSq + sinThetaIQu) + (2.0f*a*cosThetaI*sinThetaISq));
+    return 0.5f*(Rs + Rs*Rp);
+}
+inline V3 conductorReflectance3(const float *eta, const float *k, float c)
+{
+    return V3(conductorReflectance(eta[0], k[0], c), conductorReflectance(eta[1], k[1], c), conductorReflectance(eta[2], k[2], c));
+}
+// bsdfs/Fresnel.hpp:75-92
+inline float dielectricReflectance(float eta, float cosThetaI, float &cosThetaT)
+{
+    if (cosThetaI < 0.0f) {
+        eta = 1.0f/eta;
+        cosThetaI = -cosThetaI;
+    }
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    cosThetaT = std::sqrt(fmax2(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT);
+    float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
+    return (Rs*Rs + Rp*Rp)*0.5f;
+}
+inline bool checkReflectionConstraint(const V3 &wi, const V3 &wo) // bsdfs/Bsdf.hpp:44-47
+{
+    return std::abs(wi.z*wo.z - wi.x*wo.x - wi.y*wo.y - 1.0f) < 1e-3f;
+}
+inline Event warped(const Event &e, const V3 &wi, const V3 &wo) { Event c = e; c.wi = wi; c.wo = wo; return c; }
+} // namespace
+
+V3 oracle_ctx::bsdfEval(int b, const Event &e) const
+{
+    if (b < 0) return V3(0.0f);
+    const tgpu_bsdf &d = sc.bsdfs[b];
+    switch (d.type) {
+    case TGPU_BSDF_LAMBERT: { // bsdfs/LambertBsdf.cpp:40-47
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return V3(0.0f);
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*INV_PI*e.wo.z;
+    }
+    case TGPU_BSDF_ROUGH_CONDUCTOR: { // bsdfs/RoughConductorBsdf.cpp:93-110
+        if (!(e.requestedLobe & GlossyReflectionLobe)) return V3(0.0f);
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        MF mf{this, d.distribution};
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float alpha = roughnessToAlpha(roughness);
+        V3 hr = (e.wi + e.wo).normalized();
+        float cosThetaM = e.wi.dot(hr);
+        V3 F = conductorReflectance3(d.eta, d.k, cosThetaM);
+        float G = mf.G(alpha, e.wi, e.wo, hr);
+        float D = mf.D(alpha, hr);
+        float fr = (G*D*0.25f)/e.wi.z;
+        return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*fr);
+    }
+    case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:146-178
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        uint32_t subLobes = bsdfLobes(d.substrate);
+        bool evalR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool evalT = (e.requestedLobe & subLobes) != 0;
+        const V3 &wi = e.wi, &wo = e.wo;
+        float eta = 1.0f/d.ior;
+        float cosThetaTi, cosThetaTo;
+        float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+        float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+        if (evalR && checkReflectionConstraint(e.wi, e.wo)) {
+            return V3(Fi);
+        } else if (evalT) {
+            V3 wiSubstrate(wi.x*eta, wi.y*eta, std::copysign(cosThetaTi, wi.z));
+            V3 woSubstrate(wo.x*eta, wo.y*eta, std::copysign(cosThetaTo, wo.z));
+            float laplacian = eta*eta*wo.z/cosThetaTo;
+            V3 substrateF = bsdfEval(d.substrate, warped(e, wiSubstrate, woSubstrate));
+            V3 ss(d.scaled_sigma_a);
+            if (ss.max() > 0.0f) {
+                V3 a = ss*(-1.0f/cosThetaTo - 1.0f/cosThetaTi);
+                substrateF *= V3(mexp(a.x), mexp(a.y), mexp(a.z));
+            }
+            return laplacian*(1.0f - Fi)*(1.0f - Fo)*substrateF;
+        }
+        return V3(0.0f);
+    }
+    default: return V3(0.0f);
+    }
+}
+
+bool oracle_ctx::bsdfSample(int b, Event &e) const
+{
+    if (b < 0) return false;
+    const tgpu_bsdf &d = sc.bsdfs[b];
+    switch (d.type) {
+    case TGPU_BSDF_LAMBERT: { // bsdfs/LambertBsdf.cpp:27-38
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return false;
+        if (e.wi.z <= 0.0f) return false;
+        float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+        float phi = xix*TWO_PI; // SampleWarp::cosineHemisphere (sampling/SampleWarp.hpp:42-52)
+        float r = std::sqrt(xiy);
+        e.wo = V3(mcos(phi)*r, msin(phi)*r, std::sqrt(fmax2(1.0f - xiy, 0.0f)));
+        e.pdf = std::abs(e.wo.z)*INV_PI;
+        e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        e.sampledLobe = DiffuseReflectionLobe;
+        return true;
+    }
+    case TGPU_BSDF_ROUGH_CONDUCTOR: { // bsdfs/RoughConductorBsdf.cpp:60-91
+        if (!(e.requestedLobe & GlossyReflectionLobe)) return false;
+        if (e.wi.z <= 0.0f) return false;
+        MF mf{this, d.distribution};
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float sampleRoughness = roughness;
+        float alpha = roughnessToAlpha(roughness);
+        float sampleAlpha = roughnessToAlpha(sampleRoughness);
+        float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+        V3 m = mf.sample(sampleAlpha, xix, xiy);
+        float wiDotM = e.wi.dot(m);
+        e.wo = 2.0f*wiDotM*m - e.wi;
+        if (wiDotM <= 0.0f || e.wo.z <= 0.0f) return false;
+        float G = mf.G(alpha, e.wi, e.wo, m);
+        float D = mf.D(alpha, m);
+        float mPdf = mf.pdf(sampleAlpha, m);
+        float pdf = mPdf*0.25f/wiDotM;
+        float weight = wiDotM*G*D/(e.wi.z*mPdf);
+        V3 F = conductorReflectance3(d.eta, d.k, wiDotM);
+        e.pdf = pdf;
+        e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*weight);
+        e.sampledLobe = GlossyReflectionLobe;
+        return true;
+    }
+    case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:41-100
+        if (e.wi.z <= 0.0f) return false;
+        uint32_t subLobes = bsdfLobes(d.substrate);
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & subLobes) != 0;
+        if (!sampleR && !sampleT) return false;
+        const V3 wi = e.wi;
+        float eta = 1.0f/d.ior;
+        float cosThetaTi;
+        float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+        float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability;
+        if (sampleR && sampleT)
+            specularProbability = specularWeight/(specularWeight + substrateWeight);
+        else if (sampleR)
+            specularProbability = 1.0f;
+        else
+            specularProbability = 0.0f;
+        if (sampleR && e.sampler->nextBoolean(specularProbability)) {
+            e.wo = V3(-wi.x, -wi.y, wi.z);
+            e.pdf = specularProbability;
+            e.weight = V3(Fi/specularProbability);
+            e.sampledLobe = SpecularReflectionLobe;
+        } else {
+            V3 originalWi(wi);
+            V3 wiSubstrate(wi.x*eta, wi.y*eta, cosThetaTi);
+            e.wi = wiSubstrate;
+            bool success = bsdfSample(d.substrate, e);
+            e.wi = originalWi;
+            if (!success) return false;
+            float cosThetaTo;
+            float Fo = dielectricReflectance(d.ior, e.wo.z, cosThetaTo);
+            if (Fo == 1.0f) return false;
+            float cosThetaSubstrate = e.wo.z;
+            e.wo = V3(e.wo.x*d.ior, e.wo.y*d.ior, cosThetaTo);
+            e.weight *= (1.0f - Fi)*(1.0f - Fo);
+            V3 ss(d.scaled_sigma_a);
+            if (ss.max() > 0.0f) {
+                V3 a = ss*(-1.0f/cosThetaSubstrate - 1.0f/cosThetaTi);
+                e.weight *= V3(mexp(a.x), mexp(a.y), mexp(a.z));
+            }
+            e.weight /= 1.0f - specularProbability;
+            e.pdf *= 1.0f - specularProbability;
+            e.pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+        }
+        return true;
+    }
+    default: return false;
+    }
+}
+
+float oracle_ctx::bsdfPdf(int b, const Event &e) const
+{
+    if (b < 0) return 0.0f;
+    const tgpu_bsdf &d = sc.bsdfs[b];
+    switch (d.type) {
+    case TGPU_BSDF_LAMBERT: // bsdfs/LambertBsdf.cpp:61-68
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return 0.0f;
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        return std::abs(e.wo.z)*INV_PI;
+    case TGPU_BSDF_ROUGH_CONDUCTOR: { // bsdfs/RoughConductorBsdf.cpp:127-143
+        if (!(e.requestedLobe & GlossyReflectionLobe)) return 0.0f;
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        MF mf{this, d.distribution};
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float sampleAlpha = roughnessToAlpha(roughness);
+        V3 hr = (e.wi + e.wo).normalized();
+        return mf.pdf(sampleAlpha, hr)*0.25f/e.wi.dot(hr);
+    }
+    case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:180-215
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        uint32_t subLobes = bsdfLobes(d.substrate);
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & subLobes) != 0;
+        const V3 &wi = e.wi, &wo = e.wo;
+        float eta = 1.0f/d.ior;
+        float cosThetaTi, cosThetaTo;
+        float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+        dielectricReflectance(eta, wo.z, cosThetaTo);
+        V3 wiSubstrate(wi.x*eta, wi.y*eta, std::copysign(cosThetaTi, wi.z));
+        V3 woSubstrate(wo.x*eta, wo.y*eta, std::copysign(cosThetaTo, wo.z));
+        if (sampleR && sampleT) {
+            float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            if (checkReflectionConstraint(e.wi, e.wo))
+                return specularProbability;
+            else
+                return bsdfPdf(d.substrate, warped(e, wiSubstrate, woSubstrate))*(1.0f - specularProbability)*eta*eta*std::abs(wo.z/cosThetaTo);
+        } else if (sampleT) {
+            return bsdfPdf(d.substrate, warped(e, wiSubstrate, woSubstrate))*eta*eta*std::abs(wo.z/cosThetaTo);
+        } else if (sampleR) {
+            return checkReflectionConstraint(e.wi, e.wo) ? 1.0f : 0.0f;
+        }
+        return 0.0f;
+    }
+    default: return 0.0f;
+    }
+}
+
+// ========================================================================================
+// integrator (integrators/TraceBase.cpp, integrators/path_tracer/PathTracer.cpp)
+// ========================================================================================
+Event oracle_ctx::makeLocalScatterEvent(const Temp & /*data*/, const Info &info, const Ray &ray, Sampler *sampler) const
+{   // TraceBase.cpp:24-51 ; Primitive::setupTangentFrame (Primitive.cpp:125-163) without bump/anisotropy
+    Frame frame = duffFrame(info.Ns);
+    bool hitBackside = frame.normal.dot(ray.dir) > 0.0f;
+    bool isTransmissive = (bsdfLobes(info.bsdf) & TransmissiveLobe) != 0;
+    bool flipFrame = sc.settings.enable_two_sided_shading && hitBackside && !isTransmissive;
+    if (flipFrame) {
+        frame.normal = -frame.normal;
+        frame.tangent = -frame.tangent;
+    }
+    Event e;
+    e.info = &info;
+    e.sampler = sampler;
+    e.frame = frame;
+    e.wi = frame.toLocal(-ray.dir);
+    e.wo = V3(0.0f);
+    e.weight = V3(1.0f);
+    e.pdf = 1.0f;
+    e.requestedLobe = AllLobes;
+    e.sampledLobe = 0;
+    e.flippedFrame = flipFrame;
+    return e;
+}
+
+V3 oracle_ctx::shadowRay(Ray &ray, int endKind, uint32_t endIndex, int bounce, Counters &c) const
+{   // TraceBase.cpp:62-125 (generalizedShadowRayImpl<false>) without media; none of the BSDFs in
+    // scope has a ForwardLobe, so the first non-end-cap hit blocks.
+    c.shadow++;
+    Temp data;
+    Info info;
+    bool didHit = intersect(ray, data, info, c) && !(info.kind == endKind && info.index == endIndex);
+    if (didHit) {
+        if (!(bsdfLobes(info.bsdf) & ForwardLobe)) return V3(0.0f);
+    }
+    return bounce >= sc.settings.min_bounces ? V3(1.0f) : V3(0.0f);
+}
+
+V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, float expectedDist, Temp &data, Info &info, int bounce, Ray &ray, Counters &c) const
+{   // TraceBase.cpp:144-174
+    constexpr float fudgeFactor = 1.0f + 1e-3f;
+    if (!lightIntersect(l, ray, data) || ray.farT*fudgeFactor < expectedDist) return V3(0.0f);
+    info.p = ray.pos + ray.dir*ray.farT;
+    info.w = ray.dir;
+    intersectionInfo(data, info);
+    int endKind = l.kind == TGPU_LIGHT_ENV ? PRIM_ENV : PRIM_QUAD;
+    V3 shadow = shadowRay(ray, endKind, uint32_t(l.index), bounce, c);
+    if (shadow == 0.0f) return V3(0.0f);
+    return shadow*primEvalDirect(data, info);
+}
+
+V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int bounce, const Ray &parent, Counters &c) const
+{   // TraceBase.cpp:246-285
+    LightSample sample;
+    if (!lightSampleDirect(l, event.info->p, *event.sampler, sample)) return V3(0.0f);
+    event.wo = event.frame.toLocal(sample.d);
+    if (sc.settings.enable_consistency_checks) {
+        bool geometricBackside = sample.d.dot(event.info->Ng) < 0.0f;
+        bool shadingBackside = (event.wo.z < 0.0f) ^ event.flippedFrame;
+        if (geometricBackside != shadingBackside) return V3(0.0f);
+    }
+    event.requestedLobe = AllButSpecular;
+    V3 f = bsdfEval(event.info->bsdf, event); // eval(event, false): *= sqr(eta) == 1
+    if (f == 0.0f) return V3(0.0f);
+    Ray ray{event.info->p, sample.d, event.info->epsilon, INF};
+    (void)parent;
+    Temp data;
+    Info info;
+    V3 e = attenuatedEmission(l, sample.dist, data, info, bounce, ray, c);
+    if (e == 0.0f) return V3(0.0f);
+    V3 lightF = f*e/sample.pdf;
+    float bp = bsdfPdf(event.info->bsdf, event);
+    lightF *= (sample.pdf*sample.pdf)/(sample.pdf*sample.pdf + bp*bp); // SampleWarp::powerHeuristic (SampleWarp.hpp:189-192)
+    return lightF;
+}
+
+V3 oracle_ctx::bsdfSampleNee(const tgpu_light &l, Event &event, int bounce, const Ray & /*parent*/, Counters &c) const
+{   // TraceBase.cpp:287-321
+    event.requestedLobe = AllButSpecular;
+    if (!bsdfSample(event.info->bsdf, event)) return V3(0.0f);
+    if (event.weight == 0.0f) return V3(0.0f);
+    V3 wo = event.frame.toGlobal(event.wo);
+    if (sc.settings.enable_consistency_checks) {
+        bool geometricBackside = wo.dot(event.info->Ng) < 0.0f;
+        bool shadingBackside = (event.wo.z < 0.0f) ^ event.flippedFrame;
+        if (geometricBackside != shadingBackside) return V3(0.0f);
+    }
+    Ray ray{event.info->p, wo, event.info->epsilon, INF};
+    Temp data;
+    Info info;
+    V3 e = attenuatedEmission(l, -1.0f, data, info, bounce, ray, c);
+    if (e == 0.0f) return V3(0.0f);
+    V3 bsdfF = e*event.weight;
+    float lp = lightDirectPdf(l, data, info, event.info->p);
+    bsdfF *= (event.pdf*event.pdf)/(event.pdf*event.pdf + lp*lp);
+    return bsdfF;
+}
+
+V3 oracle_ctx::estimateDirect(Event &event, int bounce, const Ray &parent, Counters &c) const
+{   // TraceBase.cpp:483-494 -> chooseLight :416-459 -> sampleDirect :383-400
+    if (sc.n_lights == 0) return V3(0.0f);
+    float weight;
+    const tgpu_light *light;
+    if (sc.n_lights == 1) {
+        weight = 1.0f;
+        light = &sc.lights[0];
+    } else {
+        float lightPdf[64];
+        uint32_t n = std::min<uint32_t>(sc.n_lights, 64);
+        float total = 0.0f;
+        unsigned numNonNegative = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            lightPdf[i] = lightApproximateRadiance(sc.lights[i], event.info->p);
+            if (lightPdf[i] >= 0.0f) {
+                total += lightPdf[i];
+                numNonNegative++;
+            }
+        }
+        if (numNonNegative == 0) {
+            for (uint32_t i = 0; i < n; ++i) lightPdf[i] = 1.0f;
+            total = float(n);
+        } else if (numNonNegative < n) {
+            for (uint32_t i = 0; i < n; ++i) {
+                float uniformWeight = (total == 0.0f ? 1.0f : total)/numNonNegative;
+                if (lightPdf[i] < 0.0f) {
+                    lightPdf[i] = uniformWeight;
+                    total += uniformWeight;
+                }
+            }
+        }
+        if (total == 0.0f) return V3(0.0f);
+        float t = event.sampler->next1D()*total;
+        light = nullptr;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (t < lightPdf[i] || i == n - 1) {
+                weight = total/lightPdf[i];
+                light = &sc.lights[i];
+                break;
+            } else {
+                t -= lightPdf[i];
+            }
+        }
+        if (!light) return V3(0.0f);
+    }
+    // sampleDirect
+    V3 result(0.0f);
+    uint32_t lobes = bsdfLobes(event.info->bsdf);
+    bool pureSpecular = lobes != 0 && (lobes & ~uint32_t(SpecularLobe)) == 0;
+    if (pureSpecular || lobes == ForwardLobe) return V3(0.0f);
+    result += lightSample(*light, event, bounce, parent, c);
+    result += bsdfSampleNee(*light, event, bounce, parent, c); // lights in scope are never Dirac
+    return result*weight;
+}
+
+bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int bounce, bool enableLightSampling, Ray &ray,
+                               V3 &throughput, V3 &emission, bool &wasSpecular, Counters &c) const
+{   // TraceBase.cpp:516-568 (adjoint = false, no media)
+    c.surface++;
+    Event fwd = event; // makeForwardEvent
+    fwd.wo = -fwd.wi;
+    fwd.requestedLobe = ForwardLobe;
+    V3 transparency = bsdfEval(info.bsdf, fwd);
+    float transparencyScalar = transparency.avg();
+
+    V3 wo;
+    if (event.sampler->nextBoolean(transparencyScalar)) {
+        wo = ray.dir;
+        event.pdf = transparencyScalar;
+        event.weight = transparency/transparencyScalar;
+        event.sampledLobe = ForwardLobe;
+        throughput *= event.weight;
+    } else {
+        if (enableLightSampling && bounce < sc.settings.max_bounces - 1)
+            emission += estimateDirect(event, bounce + 1, ray, c)*throughput;
+        if (primEmissive(info.kind, info.index) && bounce >= sc.settings.min_bounces) {
+            if (!enableLightSampling || wasSpecular || !primSamplable(info.kind, info.index))
+                emission += primEvalDirect(data, info)*throughput;
+        }
+        event.requestedLobe = AllLobes;
+        if (!bsdfSample(info.bsdf, event)) return false;
+        wo = event.frame.toGlobal(event.wo);
+        if (sc.settings.enable_consistency_checks) {
+            bool geometricBackside = wo.dot(info.Ng) < 0.0f;
+            bool shadingBackside = (event.wo.z < 0.0f) ^ event.flippedFrame;
+            if (geometricBackside != shadingBackside) return false;
+        }
+        throughput *= event.weight;
+        wasSpecular = (event.sampledLobe & SpecularLobe) != 0;
+    }
+    V3 hitpoint = ray.pos + ray.dir*ray.farT;
+    ray = Ray{hitpoint, wo, info.epsilon, INF};
+    return true;
+}
+
+void oracle_ctx::cameraRay(uint32_t px, uint32_t py, float xi0, float xi1, Ray &ray) const
+{   // cameras/PinholeCamera.cpp:53-86 ; ReconstructionFilter::sample (ReconstructionFilter.hpp:86-103,152-169)
+    const tgpu_camera &cam = sc.camera;
+    float uvx, uvy;
+    if (cam.filter_type == TGPU_FILTER_DIRAC) {
+        uvx = uvy = 0.0f;
+    } else if (cam.filter_type == TGPU_FILTER_BOX) {
+        uvx = xi0 - 0.5f;
+        uvy = xi1 - 0.5f;
+    } else {
+        auto sample1 = [&](float xi) {
+            const int R = 31;
+            bool negative = xi < 0.5f;
+            xi = negative ? xi*2.0f : (xi - 0.5f)*2.0f;
+            int idx = R - 1;
+            for (int i = 0; i < R - 1; ++i) {
+                if (xi < cam.filter_cdf[i]) {
+                    idx = i;
+                    break;
+                }
+            }
+            float pdf = cam.filter_cdf[idx] - cam.filter_cdf[idx - 1];
+            float u = cam.filter_bin_size*(idx + (xi - cam.filter_cdf[idx - 1])/pdf);
+            if (negative) u = -u;
+            return u;
+        };
+        uvx = sample1(xi0);
+        uvy = sample1(xi1);
+    }
+    V3 localD = V3(-1.0f + (float(px) + 0.5f + uvx)*2.0f*cam.pixel_size_x,
+                   cam.ratio - (float(py) + 0.5f + uvy)*2.0f*cam.pixel_size_x,
+                   cam.plane_dist).normalized();
+    ray.pos = V3(cam.pos);
+    ray.dir = mulVector(cam.rot, localD);
+    ray.nearT = 1e-4f; // math/Ray.hpp:24
+    ray.farT = INF;
+}
+
+V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c) const
+{   // integrators/path_tracer/PathTracer.cpp:14-149 (no media, no AOV buffers)
+    c.samples++;
+    float xi0 = sampler.next1D(), xi1 = sampler.next1D();
+    Ray ray;
+    cameraRay(px, py, xi0, xi1, ray);
+    V3 throughput(1.0f); // point.weight*direction.weight
+    Temp data;
+    Info info;
+    V3 emission(0.0f);
+    const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
+    const bool nee = sc.settings.enable_light_sampling != 0;
+
+    int bounce = 0;
+    c.extend++;
+    bool didHit = intersect(ray, data, info, c);
+    bool wasSpecular = true;
+    while (didHit && bounce < maxBounces) {
+        Event surfaceEvent = makeLocalScatterEvent(data, info, ray, &sampler);
+        bool terminate = !handleSurface(surfaceEvent, data, info, bounce, nee, ray, throughput, emission, wasSpecular, c);
+        if (terminate) return emission;
+
+        if (throughput.max() == 0.0f) break;
+
+        float roulettePdf = vabs(throughput).max();
+        if (bounce > 2 && roulettePdf < 0.1f) {
+            if (sampler.nextBoolean(roulettePdf))
+                throughput /= roulettePdf;
+            else
+                return emission;
+        }
+        if (std::isnan(ray.dir.sum() + ray.pos.sum())) return V3(0.0f);
+        if (std::isnan(throughput.sum() + emission.sum())) return V3(0.0f);
+
+        bounce++;
+        if (bounce < maxBounces) {
+            c.extend++;
+            didHit = intersect(ray, data, info, c);
+        }
+    }
+    if (bounce >= minBounces && bounce < maxBounces) {
+        // TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) / TraceableScene::intersectInfinites (:194-209)
+        if (sc.env.present) {
+            Temp d2;
+            Info i2;
+            d2.kind = PRIM_ENV; d2.index = 0; d2.p = ray.pos; d2.w = ray.dir;
+            i2.w = ray.dir;
+            intersectionInfo(d2, i2);
+            if (!nee || wasSpecular || !sc.env.samplable)
+                emission += throughput*primEvalDirect(d2, i2);
+        }
+    }
+    if (std::isnan(throughput.sum() + emission.sum())) return V3(0.0f);
+    return emission;
+}
+
+// ========================================================================================
+// C API
+// ========================================================================================
+extern "C" {
+
+oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_mode, int rcp_mode)
+{
+    if (!scene || scene->abi_version != TGPU_ABI_VERSION) return nullptr;
+    oracle_ctx *ctx = new oracle_ctx();
+    ctx->sc = *scene; // shallow: caller keeps the buffers alive
+    ctx->rngMode = rng_mode;
+    ctx->mathMode = math_mode;
+    ctx->rcpMode = rcp_mode;
+    ctx->buildBvh();
+    return ctx;
+}
+
+void oracle_destroy(oracle_ctx *ctx) { delete ctx; }
+
+static void addSample(float *mean, uint32_t *count, const V3 &c) // cameras/OutputBuffer.hpp:104-132 (single buffer)
+{
+    if (isnanV(c) || isinfV(c)) return;
+    uint32_t sampleIdx = (*count)++;
+    V3 m(mean);
+    V3 r = m + (c - m)/float(sampleIdx + 1);
+    mean[0] = r.x; mean[1] = r.y; mean[2] = r.z;
+}
+
+static void flushCounters(oracle_ctx *ctx, const oracle_ctx::Counters &c)
+{
+    ctx->stSamples += c.samples; ctx->stExtend += c.extend; ctx->stShadow += c.shadow;
+    ctx->stSurface += c.surface; ctx->stNodes += c.nodes; ctx->stTris += c.tris;
+}
+
+void oracle_tile_seeds(uint32_t res_x, uint32_t res_y, uint32_t seed, uint32_t *out)
+{   // PathTraceIntegrator.cpp:27-42,187
+    Pcg32 s(hash32(seed));
+    uint32_t i = 0;
+    for (uint32_t y = 0; y < res_y; y += 16)
+        for (uint32_t x = 0; x < res_x; x += 16) out[i++] = hash32(s.nextI());
+}
+
+int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint32_t spp_count,
+                        float *rgb_mean, uint32_t *sample_count, int n_threads)
+{
+    const uint32_t W = ctx->sc.camera.res_x, H = ctx->sc.camera.res_y, T = 16;
+    uint32_t tilesX = (W + T - 1)/T, tilesY = (H + T - 1)/T, nTiles = tilesX*tilesY;
+    std::vector<uint32_t> seeds(nTiles);
+    oracle_tile_seeds(W, H, seed, seeds.data());
+    if (!ctx->tilesInit || ctx->tileSeedBase != seed || spp_begin == 0) {
+        ctx->tilePcg.assign(nTiles, Pcg32());
+        for (uint32_t i = 0; i < nTiles; ++i) ctx->tilePcg[i] = Pcg32(seeds[i]); // SobolPathSampler ctor :26-33
+        ctx->tilesInit = true;
+        ctx->tileSeedBase = seed;
+    }
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        oracle_ctx::Counters c;
+        while (true) {
+            uint32_t t = next.fetch_add(1);
+            if (t >= nTiles) break;
+            uint32_t tx = (t % tilesX)*T, ty = (t/tilesX)*T;
+            uint32_t tw = std::min(T, W - tx), th = std::min(T, H - ty);
+            Sampler s;
+            s.matrices = ctx->sc.sobol_matrices;
+            s.sobol = ctx->sc.settings.use_sobol != 0;
+            s.seed = seeds[t];
+            for (uint32_t y = 0; y < th; ++y) { // PathTraceIntegrator::renderTile :136-156
+                for (uint32_t x = 0; x < tw; ++x) {
+                    uint32_t px = tx + x, py = ty + y, pixelIndex = px + py*W;
+                    for (uint32_t i = 0; i < spp_count; ++i) {
+                        s.startPath(pixelIndex, spp_begin + i);
+                        if (ctx->rngMode == 0) {
+                            s.supplemental = &ctx->tilePcg[t];
+                        } else {
+                            s.local = pathLocalPcg(s.scramble, spp_begin + i);
+                            s.supplemental = &s.local;
+                        }
+                        V3 col = ctx->traceSample(px, py, s, c);
+                        addSample(rgb_mean + size_t(pixelIndex)*3, sample_count + pixelIndex, col);
+                    }
+                }
+            }
+        }
+        flushCounters(ctx, c);
+    };
+    int nt = std::max(1, n_threads);
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; ++i) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return 0;
+}
+
+int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t spp_begin, uint32_t spp_count,
+                        float *rgb_mean, uint32_t *sample_count, int n_threads)
+{
+    if (ctx->rngMode != 1) return -1; // the tile-sequential stream is only defined for whole tiles in image order
+    const uint32_t W = ctx->sc.camera.res_x;
+    std::atomic<uint32_t> next{0};
+    const uint32_t chunk = 64;
+    auto worker = [&]() {
+        oracle_ctx::Counters c;
+        Sampler s;
+        s.matrices = ctx->sc.sobol_matrices;
+        s.sobol = ctx->sc.settings.use_sobol != 0;
+        while (true) {
+            uint32_t b = next.fetch_add(chunk);
+            if (b >= shard->n_pixels) break;
+            for (uint32_t k = b; k < std::min(b + chunk, shard->n_pixels); ++k) {
+                uint32_t pixelIndex = shard->pixel_index[k];
+                s.seed = shard->tile_seed[k];
+                for (uint32_t i = 0; i < spp_count; ++i) {
+                    s.startPath(pixelIndex, spp_begin + i);
+                    s.local = pathLocalPcg(s.scramble, spp_begin + i);
+                    s.supplemental = &s.local;
+                    V3 col = ctx->traceSample(pixelIndex % W, pixelIndex/W, s, c);
+                    addSample(rgb_mean + size_t(k)*3, sample_count + k, col);
+                }
+            }
+        }
+        flushCounters(ctx, c);
+    };
+    int nt = std::max(1, n_threads);
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; ++i) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return 0;
+}
+
+int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *hits)
+{
+    oracle_ctx::Counters c;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *r = rays + size_t(i)*8;
+        Ray ray{V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7]};
+        Temp data;
+        Info info;
+        bool hit = ctx->intersect(ray, data, info, c);
+        uint32_t prim = 0xFFFFFFFFu;
+        float u = 0, v = 0;
+        if (hit) {
+            uint32_t kind = data.kind == PRIM_TRI ? 0u : data.kind == PRIM_QUAD ? 1u : 2u;
+            prim = (kind << 30) | data.index;
+            if (data.kind != PRIM_CUBE) { u = data.u; v = data.v; }
+        }
+        float *h = hits + size_t(i)*4;
+        h[0] = hit ? ray.farT : r[7];
+        h[1] = u;
+        h[2] = v;
+        std::memcpy(&h[3], &prim, 4);
+    }
+    flushCounters(ctx, c);
+    return 0;
+}
+
+int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_t *occluded)
+{
+    oracle_ctx::Counters c;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *r = rays + size_t(i)*8;
+        Ray ray{V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7]};
+        Temp data;
+        Info info;
+        occluded[i] = ctx->intersect(ray, data, info, c) ? 1 : 0;
+    }
+    flushCounters(ctx, c);
+    return 0;
+}
+
+uint32_t oracle_hash32(uint32_t x) { return hash32(x); }
+
+uint32_t oracle_sobol(const oracle_ctx *ctx, uint32_t index, uint32_t dim, uint32_t scramble)
+{
+    uint32_t result = scramble;
+    for (uint32_t i = dim*32u; index; index >>= 1, ++i)
+        if (index & 1) result ^= ctx->sc.sobol_matrices[i];
+    return result;
+}
+
+void oracle_pcg_stream(uint64_t state, uint64_t seq, uint32_t n, uint32_t *out)
+{
+    Pcg32 p(state, seq);
+    for (uint32_t i = 0; i < n; ++i) out[i] = p.nextI();
+}
+
+void oracle_camera_ray(const oracle_ctx *ctx, uint32_t px, uint32_t py, float xi0, float xi1, float *o)
+{
+    Ray r;
+    ctx->cameraRay(px, py, xi0, xi1, r);
+    o[0] = r.pos.x; o[1] = r.pos.y; o[2] = r.pos.z; o[3] = r.dir.x; o[4] = r.dir.y; o[5] = r.dir.z;
+}
+
+void oracle_get_stats(oracle_ctx *ctx, oracle_stats *out)
+{
+    out->samples = ctx->stSamples; out->extend_rays = ctx->stExtend; out->shadow_rays = ctx->stShadow;
+    out->surface_events = ctx->stSurface; out->node_visits = ctx->stNodes; out->tri_tests = ctx->stTris;
+}
+
+void oracle_reset_stats(oracle_ctx *ctx)
+{
+    ctx->stSamples = 0; ctx->stExtend = 0; ctx->stShadow = 0; ctx->stSurface = 0; ctx->stNodes = 0; ctx->stTris = 0;
+}
+
+} // extern "C"

@@ -1,0 +1,69 @@
+/*
+ * oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's unidirectional path-tracing hot path
+ * (PathTraceIntegrator::renderTile -> PathTracer::traceSample -> TraceBase::* ->
+ * primitives / BSDFs / sampler), consuming the same flattened scene description
+ * (tgpu_scene_desc) the HIP core takes.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; nothing under
+ * tungsten_amd/ links or calls it.
+ *
+ * Parity status: pinned against full-frame PFMs rendered by the unmodified,
+ * compiled reference (tests/golden/README.md) -- see DESIGN.md "Oracle".
+ *
+ * Modes (the reference behaviour is all zeros):
+ *   rng  0 = tile-sequential supplemental PCG stream, exactly as the reference
+ *            (SobolPathSampler.hpp:14,57-65; PathTraceIntegrator.cpp:36-38,136-156)
+ *        1 = path-local supplemental stream (what a parallel wavefront can do)
+ *   math 0 = glibc libm   1 = include/tgpu_math.h (bit-identical on gfx950)
+ *   rcp  0 = IEEE division for the triangle hit (t,u,v)
+ *        1 = Embree's rcp(): RCPPS + one Newton step (vfloat4_sse2.h:166-173)
+ */
+#ifndef TUNGSTEN_ORACLE_H_
+#define TUNGSTEN_ORACLE_H_
+
+#include "../include/tungsten_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_ctx oracle_ctx;
+
+typedef struct oracle_stats {
+    uint64_t samples, extend_rays, shadow_rays, surface_events;
+    uint64_t node_visits, tri_tests;
+} oracle_stats;
+
+oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_mode, int rcp_mode);
+void oracle_destroy(oracle_ctx *ctx);
+
+/* Reference order: dice the whole image into 16x16 tiles seeded from `seed`,
+ * trace samples [spp_begin, spp_begin+spp_count) of every pixel, accumulate into
+ * rgb_mean / sample_count (res_x*res_y, image order).  Per-tile sampler state is
+ * kept inside the context between calls (first call must use spp_begin == 0). */
+int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint32_t spp_count,
+                        float *rgb_mean, uint32_t *sample_count, int n_threads);
+
+/* Shard order (rng mode 1 only): same contract as tgpu_render_pass+tgpu_download. */
+int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t spp_begin, uint32_t spp_count,
+                        float *rgb_mean, uint32_t *sample_count, int n_threads);
+
+/* Ray-level queries, same layout as tgpu_trace_closest / tgpu_trace_occluded. */
+int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *hits);
+int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_t *occluded);
+
+/* Leaf functions exposed for known-answer tests. */
+uint32_t oracle_hash32(uint32_t x);
+uint32_t oracle_sobol(const oracle_ctx *ctx, uint32_t index, uint32_t dim, uint32_t scramble);
+void oracle_pcg_stream(uint64_t state, uint64_t seq, uint32_t n, uint32_t *out);
+void oracle_camera_ray(const oracle_ctx *ctx, uint32_t px, uint32_t py, float xi0, float xi1, float *origin_dir6);
+void oracle_tile_seeds(uint32_t res_x, uint32_t res_y, uint32_t seed, uint32_t *out);
+
+void oracle_get_stats(oracle_ctx *ctx, oracle_stats *out);
+void oracle_reset_stats(oracle_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""ctypes mirror of include/tungsten_amd.h (keep in sync; tests/test_abi.py checks sizes)."""
+import ctypes as C
+
+TGPU_ABI_VERSION = 1
+
+f32 = C.c_float
+i32 = C.c_int32
+u32 = C.c_uint32
+u64 = C.c_uint64
+pf32 = C.POINTER(C.c_float)
+pu32 = C.POINTER(C.c_uint32)
+pi32 = C.POINTER(C.c_int32)
+pu8 = C.POINTER(C.c_uint8)
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", i32), ("value", f32*3), ("on_color", f32*3), ("off_color", f32*3),
+                ("res_u", i32), ("res_v", i32), ("bitmap", i32)]
+
+
+class Bitmap(C.Structure):
+    _fields_ = [("w", i32), ("h", i32), ("clamp", i32), ("linear", i32), ("scale", f32), ("texels", pf32)]
+
+
+class Bsdf(C.Structure):
+    _fields_ = [("type", i32), ("albedo_tex", i32), ("roughness_tex", i32), ("distribution", i32),
+                ("eta", f32*3), ("k", f32*3), ("ior", f32), ("thickness", f32), ("sigma_a", f32*3),
+                ("substrate", i32), ("scaled_sigma_a", f32*3), ("avg_transmittance", f32)]
+
+
+class Quad(C.Structure):
+    _fields_ = [("base", f32*3), ("edge0", f32*3), ("edge1", f32*3), ("normal", f32*3), ("tangent", f32*3),
+                ("bitangent", f32*3), ("inv_uv_sq", f32*2), ("area", f32), ("bsdf", i32), ("emission_tex", i32)]
+
+
+class Cube(C.Structure):
+    _fields_ = [("rot", f32*9), ("inv_rot", f32*9), ("pos", f32*3), ("scale", f32*3), ("bsdf", i32),
+                ("emission_tex", i32)]
+
+
+class Env(C.Structure):
+    _fields_ = [("present", i32), ("samplable", i32), ("emission_tex", i32), ("rot", f32*9), ("inv_rot", f32*9),
+                ("dist_w", i32), ("dist_h", i32), ("pdf", pf32), ("cdf", pf32), ("marginal_pdf", pf32),
+                ("marginal_cdf", pf32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", f32*3), ("rot", f32*9), ("res_x", u32), ("res_y", u32), ("plane_dist", f32),
+                ("ratio", f32), ("pixel_size_x", f32), ("filter_type", i32), ("filter_bin_size", f32),
+                ("filter_cdf", f32*32)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("min_bounces", i32), ("max_bounces", i32), ("enable_light_sampling", i32),
+                ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("use_sobol", i32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("kind", i32), ("index", i32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("abi_version", u32), ("camera", Camera), ("settings", Settings),
+                ("n_tris", u32), ("tri_pos", pf32), ("tri_normal", pf32), ("tri_uv", pf32), ("tri_bsdf", pi32),
+                ("tri_smooth", pu8),
+                ("n_quads", u32), ("quads", C.POINTER(Quad)),
+                ("n_cubes", u32), ("cubes", C.POINTER(Cube)),
+                ("n_bsdfs", u32), ("bsdfs", C.POINTER(Bsdf)),
+                ("n_textures", u32), ("textures", C.POINTER(Texture)),
+                ("n_bitmaps", u32), ("bitmaps", C.POINTER(Bitmap)),
+                ("n_lights", u32), ("lights", C.POINTER(Light)),
+                ("env", Env),
+                ("sobol_matrices", pu32)]
+
+
+class ShardDesc(C.Structure):
+    _fields_ = [("n_pixels", u32), ("pixel_index", pu32), ("tile_seed", pu32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", u64), ("extend_rays", u64), ("shadow_rays", u64),
+                ("extend_node_visits", u64), ("extend_tri_tests", u64),
+                ("shadow_node_visits", u64), ("shadow_tri_tests", u64),
+                ("surface_events", u64),
+                ("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
+                ("other_ms", C.c_double),
+                ("extend_launches", u64), ("shadow_launches", u64)]

@@ -1,0 +1,95 @@
+// C entry points of the host library (libtungsten_host.so) used by the Python
+// test/bench harness through ctypes.  Pure host code: scene loading and
+// flattening, shard construction, image I/O.  No GPU and no oracle here.
+#include "scene.hpp"
+
+#include <cstring>
+#include <memory>
+
+using namespace tungsten_amd;
+
+namespace {
+void setErr(char *err, int errLen, const std::string &msg)
+{
+    if (err && errLen > 0) {
+        std::strncpy(err, msg.c_str(), size_t(errLen) - 1);
+        err[errLen - 1] = 0;
+    }
+}
+} // namespace
+
+extern "C" {
+
+struct tgh_scene { Scene scene; };
+struct tgh_shard { Shard shard; tgpu_shard_desc desc; };
+
+tgh_scene *tgh_scene_load(const char *jsonPath, char *err, int errLen)
+{
+    try {
+        std::unique_ptr<tgh_scene> s(new tgh_scene{Scene::load(jsonPath)});
+        return s.release();
+    } catch (const std::exception &e) {
+        setErr(err, errLen, e.what());
+        return nullptr;
+    }
+}
+
+void tgh_scene_free(tgh_scene *s) { delete s; }
+
+void tgh_scene_set_resolution(tgh_scene *s, uint32_t w, uint32_t h) { s->scene.setResolution(w, h); }
+void tgh_scene_set_bounces(tgh_scene *s, int minBounces, int maxBounces)
+{
+    s->scene.settings.min_bounces = minBounces;
+    s->scene.settings.max_bounces = maxBounces;
+}
+void tgh_scene_set_light_sampling(tgh_scene *s, int enable) { s->scene.settings.enable_light_sampling = enable; }
+void tgh_scene_set_sobol(tgh_scene *s, int enable) { s->scene.renderer.useSobol = enable != 0; }
+
+int tgh_scene_flatten(tgh_scene *s, char *err, int errLen)
+{
+    try {
+        s->scene.flatten();
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errLen, e.what());
+        return -1;
+    }
+}
+
+const tgpu_scene_desc *tgh_scene_desc(const tgh_scene *s) { return &s->scene.desc(); }
+
+// out[0..7] = resX, resY, spp, sppStep, useSobol, adaptive, minBounces, maxBounces
+void tgh_scene_info(const tgh_scene *s, uint32_t *out)
+{
+    out[0] = s->scene.resX;
+    out[1] = s->scene.resY;
+    out[2] = s->scene.renderer.spp;
+    out[3] = s->scene.renderer.sppStep;
+    out[4] = s->scene.renderer.useSobol;
+    out[5] = s->scene.renderer.useAdaptiveSampling;
+    out[6] = uint32_t(s->scene.settings.min_bounces);
+    out[7] = uint32_t(s->scene.settings.max_bounces);
+}
+
+const char *tgh_scene_tonemap(const tgh_scene *s) { return s->scene.tonemap.c_str(); }
+
+tgh_shard *tgh_shard_create(uint32_t resX, uint32_t resY, uint32_t seed, uint32_t rank, uint32_t world)
+{
+    tgh_shard *s = new tgh_shard{makeShard(resX, resY, seed, rank, world), {}};
+    s->desc = s->shard.desc();
+    return s;
+}
+void tgh_shard_free(tgh_shard *s) { delete s; }
+const tgpu_shard_desc *tgh_shard_desc(const tgh_shard *s) { return &s->desc; }
+uint32_t tgh_shard_size(const tgh_shard *s) { return s->desc.n_pixels; }
+const uint32_t *tgh_shard_pixels(const tgh_shard *s) { return s->desc.pixel_index; }
+
+int tgh_save_pfm(const char *path, const float *rgb, int w, int h) { return savePfm(path, rgb, w, h) ? 0 : -1; }
+int tgh_save_png_tonemapped(const char *path, const char *tonemap, const float *rgb, int w, int h)
+{
+    std::vector<uint8_t> ldr;
+    tonemapToLdr(tonemap, rgb, w, h, ldr);
+    return savePng(path, ldr.data(), w, h) ? 0 : -1;
+}
+
+} // extern "C"

@@ -1,0 +1,999 @@
+#include "scene.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace tungsten_amd {
+
+static const float PI = 3.1415926536f; // Angle.hpp:8
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+static std::string readFile(const std::string &path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("Unable to open file '" + path + "'");
+    std::stringstream ss;
+    ss << in.rdbuf();
+    return ss.str();
+}
+
+static std::string dirName(const std::string &path)
+{
+    size_t p = path.find_last_of('/');
+    return p == std::string::npos ? std::string(".") : path.substr(0, p);
+}
+
+static bool endsWith(const std::string &s, const std::string &suffix)
+{
+    if (s.size() < suffix.size()) return false;
+    std::string tail = s.substr(s.size() - suffix.size());
+    std::transform(tail.begin(), tail.end(), tail.begin(), [](unsigned char c) { return char(std::tolower(c)); });
+    return tail == suffix;
+}
+
+uint32_t hash32(uint32_t x) // MathUtil.hpp:120-128
+{
+    x = ~x + (x << 15);
+    x = x ^ (x >> 12);
+    x = x + (x << 2);
+    x = x ^ (x >> 4);
+    x = x*2057;
+    x = x ^ (x >> 16);
+    return x;
+}
+
+std::string Scene::assetDir()
+{
+    if (const char *env = std::getenv("TUNGSTEN_AMD_ASSETS")) return env;
+#ifdef TUNGSTEN_AMD_DEFAULT_ASSETS
+    return TUNGSTEN_AMD_DEFAULT_ASSETS;
+#else
+    return "assets";
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// transform parsing (JsonPtr.cpp:91-186)
+// ---------------------------------------------------------------------------
+static Vec3 randomOrtho(const Vec3 &a)
+{
+    Vec3 res;
+    if (std::abs(a.x) > std::abs(a.y))
+        res = Vec3(0.0f, 1.0f, 0.0f);
+    else
+        res = Vec3(1.0f, 0.0f, 0.0f);
+    return a.cross(res).normalized();
+}
+
+static void gramSchmidt(Vec3 &a, Vec3 &b, Vec3 &c)
+{
+    a.normalize();
+    b -= a*a.dot(b);
+    if (b.lengthSq() < 1e-5)
+        b = randomOrtho(a);
+    else
+        b.normalize();
+
+    c -= a*a.dot(c);
+    c -= b*b.dot(c);
+    if (c.lengthSq() < 1e-5)
+        c = a.cross(b);
+    else
+        c.normalize();
+}
+
+static bool getVec3(const Json &v, const char *key, Vec3 &dst)
+{
+    float tmp[3];
+    if (!v.getVec(key, tmp, 3)) return false;
+    dst = Vec3(tmp[0], tmp[1], tmp[2]);
+    return true;
+}
+
+static Mat4 parseTransform(const Json &v)
+{
+    if (v.isArray()) {
+        if (v.size() != 16) throw JsonLoadException("Trying to parse a matrix, but this array has the wrong size");
+        Mat4 m;
+        for (int i = 0; i < 16; ++i) m.a[i] = v[i].asFloat();
+        return m;
+    }
+    if (!v.isObject()) throw JsonLoadException("Parameter has wrong type: Expecting a matrix value here");
+
+    Vec3 x(1.0f, 0.0f, 0.0f), y(0.0f, 1.0f, 0.0f), z(0.0f, 0.0f, 1.0f);
+    Vec3 pos(0.0f);
+    getVec3(v, "position", pos);
+
+    bool explicitX = false, explicitY = false, explicitZ = false;
+    Vec3 lookAt;
+    if (getVec3(v, "look_at", lookAt)) {
+        z = lookAt - pos;
+        explicitZ = true;
+    }
+    explicitY = getVec3(v, "up", y);
+    explicitX = getVec3(v, "x_axis", x) || explicitX;
+    explicitY = getVec3(v, "y_axis", y) || explicitY;
+    explicitZ = getVec3(v, "z_axis", z) || explicitZ;
+
+    int id = (explicitZ ? 4 : 0) + (explicitY ? 2 : 0) + (explicitX ? 1 : 0);
+    switch (id) {
+    case 0: gramSchmidt(z, y, x); break;
+    case 1: gramSchmidt(x, z, y); break;
+    case 2: gramSchmidt(y, z, x); break;
+    case 3: gramSchmidt(y, x, z); break;
+    case 4: gramSchmidt(z, y, x); break;
+    case 5: gramSchmidt(z, x, y); break;
+    case 6: gramSchmidt(z, y, x); break;
+    case 7: gramSchmidt(z, y, x); break;
+    }
+    if (x.cross(y).dot(z) < 0.0f) {
+        if (!explicitX)
+            x = -x;
+        else if (!explicitY)
+            y = -y;
+        else
+            z = -z;
+    }
+    Vec3 scale;
+    if (getVec3(v, "scale", scale)) {
+        x *= scale.x;
+        y *= scale.y;
+        z *= scale.z;
+    }
+    Vec3 rot;
+    if (getVec3(v, "rotation", rot)) {
+        Mat4 tform = Mat4::rotYXZ(rot);
+        x = tform*x;
+        y = tform*y;
+        z = tform*z;
+    }
+    return Mat4(x[0], y[0], z[0], pos[0], x[1], y[1], z[1], pos[1], x[2], y[2], z[2], pos[2], 0.0f, 0.0f, 0.0f, 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// resources
+// ---------------------------------------------------------------------------
+bool loadWo3(const std::string &path, std::vector<float> &verts, std::vector<uint32_t> &tris)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t nv = 0, nt = 0;
+    bool ok = std::fread(&nv, 8, 1, f) == 1;
+    if (ok && nv < (1ull << 32)) {
+        verts.resize(size_t(nv)*8);
+        ok = nv == 0 || std::fread(verts.data(), 32, size_t(nv), f) == size_t(nv);
+    } else {
+        ok = false;
+    }
+    ok = ok && std::fread(&nt, 8, 1, f) == 1;
+    if (ok && nt < (1ull << 32)) {
+        tris.resize(size_t(nt)*4);
+        ok = nt == 0 || std::fread(tris.data(), 16, size_t(nt), f) == size_t(nt);
+    } else {
+        ok = false;
+    }
+    std::fclose(f);
+    return ok;
+}
+
+// Radiance RGBE (.hdr) decode, same arithmetic as the reference's vendored
+// stb_image (thirdparty/stbi/stb_image.c:5588-5613): f = ldexp(1, e-136), c*f.
+static void rgbeToFloat(const uint8_t *rgbe, float *out)
+{
+    if (rgbe[3] != 0) {
+        float f1 = float(std::ldexp(1.0f, int(rgbe[3]) - (128 + 8)));
+        out[0] = rgbe[0]*f1;
+        out[1] = rgbe[1]*f1;
+        out[2] = rgbe[2]*f1;
+    } else {
+        out[0] = out[1] = out[2] = 0.0f;
+    }
+}
+
+bool loadRadianceHdr(const std::string &path, int &w, int &h, std::vector<float> &rgb)
+{
+    std::string data;
+    try {
+        data = readFile(path);
+    } catch (...) {
+        return false;
+    }
+    size_t pos = 0;
+    auto readLine = [&](std::string &line) {
+        line.clear();
+        while (pos < data.size() && data[pos] != '\n') line += data[pos++];
+        if (pos < data.size()) ++pos;
+    };
+    std::string line;
+    readLine(line);
+    if (line != "#?RADIANCE" && line != "#?RGBE") return false;
+    bool valid = false;
+    while (true) {
+        readLine(line);
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") valid = true;
+        if (pos >= data.size()) return false;
+    }
+    if (!valid) return false;
+    readLine(line);
+    if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) return false;
+    if (w <= 0 || h <= 0) return false;
+    rgb.resize(size_t(w)*h*3);
+
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(data.data());
+    size_t n = data.size();
+    if (w < 8 || w >= 32768) {
+        // flat data
+        for (int i = 0; i < w*h; ++i) {
+            if (pos + 4 > n) return false;
+            rgbeToFloat(p + pos, &rgb[size_t(i)*3]);
+            pos += 4;
+        }
+        return true;
+    }
+    std::vector<uint8_t> scan(size_t(w)*4);
+    for (int j = 0; j < h; ++j) {
+        if (pos + 4 > n) return false;
+        uint8_t c1 = p[pos], c2 = p[pos + 1], len = p[pos + 2];
+        if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+            // not RLE: the whole image is flat (stb falls back for the full image from this pixel on
+            // only when j == 0)
+            if (j != 0) return false;
+            for (int i = 0; i < w*h; ++i) {
+                if (pos + 4 > n) return false;
+                rgbeToFloat(p + pos, &rgb[size_t(i)*3]);
+                pos += 4;
+            }
+            return true;
+        }
+        int slen = (int(len) << 8) | p[pos + 3];
+        pos += 4;
+        if (slen != w) return false;
+        for (int k = 0; k < 4; ++k) {
+            int i = 0;
+            while (i < w) {
+                if (pos >= n) return false;
+                uint8_t count = p[pos++];
+                if (count > 128) {
+                    if (pos >= n) return false;
+                    uint8_t value = p[pos++];
+                    count -= 128;
+                    if (i + count > w) return false;
+                    for (int z = 0; z < count; ++z) scan[size_t(i++)*4 + k] = value;
+                } else {
+                    if (i + count > w || pos + count > n) return false;
+                    for (int z = 0; z < count; ++z) scan[size_t(i++)*4 + k] = p[pos++];
+                }
+            }
+        }
+        for (int i = 0; i < w; ++i) rgbeToFloat(&scan[size_t(i)*4], &rgb[(size_t(j)*w + i)*3]);
+    }
+    return true;
+}
+
+bool savePfm(const std::string &path, const float *rgb, int w, int h) // ImageIO.cpp:528-545
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "PF\n%d %d\n-1\n", w, h);
+    for (int y = h - 1; y >= 0; --y) std::fwrite(rgb + size_t(y)*w*3, sizeof(float), size_t(w)*3, f);
+    std::fclose(f);
+    return true;
+}
+
+bool loadPfm(const std::string &path, int &w, int &h, std::vector<float> &rgb)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    float scale = 0.0f;
+    if (std::fscanf(f, "%2s %d %d %f", magic, &w, &h, &scale) != 4 || std::strcmp(magic, "PF") != 0 || scale >= 0.0f) {
+        std::fclose(f);
+        return false;
+    }
+    std::fgetc(f);
+    rgb.resize(size_t(w)*h*3);
+    bool ok = true;
+    for (int y = h - 1; y >= 0 && ok; --y) ok = std::fread(&rgb[size_t(y)*w*3], sizeof(float), size_t(w)*3, f) == size_t(w)*3;
+    std::fclose(f);
+    return ok;
+}
+
+// PNG with stored (uncompressed) deflate blocks: enough for an output writer.
+bool savePng(const std::string &path, const uint8_t *rgb, int w, int h)
+{
+    static uint32_t crcTable[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crcTable[n] = c;
+        }
+        init = true;
+    }
+    auto crc = [&](const std::vector<uint8_t> &buf, size_t from) {
+        uint32_t c = 0xFFFFFFFFu;
+        for (size_t i = from; i < buf.size(); ++i) c = crcTable[(c ^ buf[i]) & 0xFF] ^ (c >> 8);
+        return c ^ 0xFFFFFFFFu;
+    };
+    auto put32 = [](std::vector<uint8_t> &b, uint32_t v) {
+        b.push_back(uint8_t(v >> 24)); b.push_back(uint8_t(v >> 16)); b.push_back(uint8_t(v >> 8)); b.push_back(uint8_t(v));
+    };
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    auto chunk = [&](const char *tag, const std::vector<uint8_t> &payload) {
+        put32(out, uint32_t(payload.size()));
+        size_t from = out.size();
+        out.insert(out.end(), tag, tag + 4);
+        out.insert(out.end(), payload.begin(), payload.end());
+        put32(out, crc(out, from));
+    };
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, uint32_t(w)); put32(ihdr, uint32_t(h));
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk("IHDR", ihdr);
+
+    std::vector<uint8_t> raw;
+    raw.reserve(size_t(h)*(size_t(w)*3 + 1));
+    for (int y = 0; y < h; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + size_t(y)*w*3, rgb + size_t(y + 1)*w*3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    size_t pos = 0;
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    while (pos < raw.size() || raw.empty()) {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back(uint8_t(n & 0xFF)); z.push_back(uint8_t(n >> 8));
+        z.push_back(uint8_t(~n & 0xFF)); z.push_back(uint8_t((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        pos += n;
+        if (raw.empty()) break;
+    }
+    put32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    return true;
+}
+
+void tonemapToLdr(const std::string &op, const float *rgb, int w, int h, std::vector<uint8_t> &ldr)
+{
+    ldr.resize(size_t(w)*h*3);
+    for (size_t i = 0; i < size_t(w)*h*3; ++i) {
+        float c = rgb[i] > 0.0f ? rgb[i] : 0.0f; // Camera::tonemap clamps below at 0 (Camera.hpp:158-161)
+        float t;
+        if (op == "linear") {
+            t = c;
+        } else if (op == "gamma") {
+            t = std::pow(c, 1.0f/2.2f);
+        } else if (op == "reinhard") {
+            t = std::pow(c/(c + 1.0f), 1.0f/2.2f);
+        } else if (op == "filmic") {
+            float x = std::max(0.0f, c - 0.004f);
+            t = (x*(6.2f*x + 0.5f))/(x*(6.2f*x + 1.7f) + 0.06f);
+        } else { // pbrt
+            t = c < 0.0031308f ? 12.92f*c : 1.055f*std::pow(c, 1.0f/2.4f) - 0.055f;
+        }
+        int v = int(t*255.0f);
+        ldr[i] = uint8_t(std::min(std::max(v, 0), 255));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// JSON -> scene objects
+// ---------------------------------------------------------------------------
+int Scene::fetchTexture(const Json &v, bool /*scalarAverage*/) // Scene.cpp:127-151
+{
+    tgpu_texture t{};
+    t.bitmap = -1;
+    if (v.isString()) {
+        // TextureCache.hpp:32-33: gammaCorrect = true, linear = true, clamp = false
+        std::string path = v.asString();
+        std::string full = path.size() && path[0] == '/' ? path : sceneDir + "/" + path;
+        for (size_t i = 0; i < _bitmapPaths.size(); ++i) {
+            if (_bitmapPaths[i] == full) {
+                t.type = TGPU_TEX_BITMAP;
+                t.bitmap = int(i);
+                _textures.push_back(t);
+                return int(_textures.size()) - 1;
+            }
+        }
+        int w = 0, h = 0;
+        std::vector<float> texels;
+        if (!(endsWith(full, ".hdr") && loadRadianceHdr(full, w, h, texels)))
+            throw std::runtime_error("Unable to load texture at '" + full + "' (only Radiance .hdr bitmaps are in scope)");
+        tgpu_bitmap bm{};
+        bm.w = w; bm.h = h; bm.clamp = 0; bm.linear = 1; bm.scale = 1.0f; bm.texels = nullptr;
+        _bitmaps.push_back(bm);
+        _bitmapTexels.push_back(std::move(texels));
+        _bitmapPaths.push_back(full);
+        t.type = TGPU_TEX_BITMAP;
+        t.bitmap = int(_bitmaps.size()) - 1;
+    } else if (v.isNumber()) {
+        t.type = TGPU_TEX_CONSTANT;
+        t.value[0] = t.value[1] = t.value[2] = v.asFloat();
+    } else if (v.isArray()) {
+        t.type = TGPU_TEX_CONSTANT;
+        v.toVec(t.value, 3);
+    } else if (v.isObject()) {
+        std::string type = v["type"].asString();
+        if (type == "checker") { // CheckerTexture.cpp:15-45
+            t.type = TGPU_TEX_CHECKER;
+            t.on_color[0] = t.on_color[1] = t.on_color[2] = 0.8f;
+            t.off_color[0] = t.off_color[1] = t.off_color[2] = 0.2f;
+            t.res_u = t.res_v = 20;
+            v.getVec("on_color", t.on_color, 3);
+            v.getVec("off_color", t.off_color, 3);
+            v.getField("res_u", t.res_u);
+            v.getField("res_v", t.res_v);
+        } else if (type == "constant") {
+            t.type = TGPU_TEX_CONSTANT;
+            v.getVec("value", t.value, 3);
+        } else {
+            throw std::runtime_error("Texture type '" + type + "' is outside the hot-path scope");
+        }
+    } else {
+        throw JsonLoadException("Type mismatch: Expecting a texture here");
+    }
+    _textures.push_back(t);
+    return int(_textures.size()) - 1;
+}
+
+// Cu from ComplexIorData.hpp:26 is the only conductor the benchmark configs use;
+// a few more common ones are listed for convenience.
+static bool lookupComplexIor(const std::string &name, float *eta, float *k)
+{
+    struct Entry { const char *name; float eta[3]; float k[3]; };
+    static const Entry table[] = {
+        {"Cu", {0.2004376970f, 0.9240334304f, 1.1022119527f}, {3.9129485033f, 2.4528477015f, 2.1421879552f}},
+    };
+    for (const Entry &e : table) {
+        if (name == e.name) {
+            for (int i = 0; i < 3; ++i) { eta[i] = e.eta[i]; k[i] = e.k[i]; }
+            return true;
+        }
+    }
+    return false;
+}
+
+int Scene::parseBsdf(const Json &v)
+{
+    tgpu_bsdf b{};
+    std::string type = v["type"].asString();
+    // Bsdf::fromJson (Bsdf.cpp): albedo default = constant 1
+    if (v["albedo"])
+        b.albedo_tex = fetchTexture(v["albedo"], false);
+    else {
+        Json one; one.type = Json::Number; one.num = 1.0;
+        b.albedo_tex = fetchTexture(one, false);
+    }
+    if (v["bump"]) throw std::runtime_error("bump maps are outside the hot-path scope");
+    b.roughness_tex = -1;
+    b.substrate = -1;
+    if (type == "lambert") {
+        b.type = TGPU_BSDF_LAMBERT;
+    } else if (type == "null") {
+        b.type = TGPU_BSDF_NULL;
+    } else if (type == "rough_conductor") { // RoughConductorBsdf.cpp:14-45
+        b.type = TGPU_BSDF_ROUGH_CONDUCTOR;
+        std::string material;
+        std::string dist = "ggx";
+        const float defEta[3] = {0.200438f, 0.924033f, 1.10221f}, defK[3] = {3.91295f, 2.45285f, 2.14219f};
+        for (int i = 0; i < 3; ++i) { b.eta[i] = defEta[i]; b.k[i] = defK[i]; }
+        v.getVec("eta", b.eta, 3);
+        v.getVec("k", b.k, 3);
+        v.getField("distribution", dist);
+        if (v.getField("material", material) && !lookupComplexIor(material, b.eta, b.k))
+            throw JsonLoadException("Unable to find material with name '" + material + "'");
+        if (dist == "beckmann") b.distribution = TGPU_DIST_BECKMANN;
+        else if (dist == "phong") b.distribution = TGPU_DIST_PHONG;
+        else if (dist == "ggx") b.distribution = TGPU_DIST_GGX;
+        else throw JsonLoadException("Unknown microfacet distribution '" + dist + "'");
+        if (v["roughness"])
+            b.roughness_tex = fetchTexture(v["roughness"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 0.1;
+            b.roughness_tex = fetchTexture(r, true);
+        }
+    } else if (type == "smooth_coat") { // SmoothCoatBsdf.cpp:19-39
+        b.type = TGPU_BSDF_SMOOTH_COAT;
+        b.ior = 1.3f;
+        b.thickness = 1.0f;
+        b.sigma_a[0] = b.sigma_a[1] = b.sigma_a[2] = 0.0f;
+        v.getField("ior", b.ior);
+        v.getField("thickness", b.thickness);
+        v.getVec("sigma_a", b.sigma_a, 3);
+        if (!v["substrate"]) throw std::runtime_error("smooth_coat without substrate is outside the hot-path scope");
+        b.substrate = fetchBsdf(v["substrate"]);
+        if (_bsdfs[size_t(b.substrate)].type == TGPU_BSDF_SMOOTH_COAT || _bsdfs[size_t(b.substrate)].type == TGPU_BSDF_NULL)
+            throw std::runtime_error("smooth_coat substrate must be lambert or rough_conductor in this scope");
+        for (int i = 0; i < 3; ++i) b.scaled_sigma_a[i] = b.thickness*b.sigma_a[i]; // SmoothCoatBsdf::prepareForRender
+        {
+            float sum = b.scaled_sigma_a[0]; sum += b.scaled_sigma_a[1]; sum += b.scaled_sigma_a[2];
+            float avg = sum*(1.0f/3.0f);
+            b.avg_transmittance = std::exp(-2.0f*avg);
+        }
+    } else {
+        throw std::runtime_error("BSDF type '" + type + "' is outside the hot-path scope (SURVEY.md section 2 row 8)");
+    }
+    _bsdfs.push_back(b);
+    return int(_bsdfs.size()) - 1;
+}
+
+int Scene::fetchBsdf(const Json &v) // Scene.cpp:83-93,120-125
+{
+    if (v.isString()) {
+        for (auto &kv : _namedBsdfs)
+            if (kv.first == v.asString()) return kv.second;
+        throw JsonLoadException("Unable to find an object with name '" + v.asString() + "'");
+    } else if (v.isObject()) {
+        return parseBsdf(v);
+    }
+    throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
+}
+
+void Scene::parsePrimitive(const Json &v)
+{
+    std::string type = v["type"].asString();
+    Mat4 transform;
+    if (v["transform"]) transform = parseTransform(v["transform"]);
+    if (v["power"]) throw std::runtime_error("'power' emitters are outside the hot-path scope");
+    if (v["int_medium"] || v["ext_medium"]) throw std::runtime_error("participating media are outside the round-1 scope");
+    int emissionTex = -1;
+    if (v["emission"]) emissionTex = fetchTexture(v["emission"], false);
+
+    if (type == "mesh") {
+        if (emissionTex >= 0) throw std::runtime_error("emissive meshes are outside the hot-path scope");
+        MeshData m;
+        v.getField("name", m.name);
+        m.transform = transform;
+        v.getField("smooth", m.smooth);
+        bool recompute = false;
+        v.getField("recompute_normals", recompute);
+        if (recompute) throw std::runtime_error("recompute_normals is outside the hot-path scope");
+        const Json &bsdf = v["bsdf"];
+        if (bsdf.isArray())
+            for (size_t i = 0; i < bsdf.size(); ++i) m.bsdfs.push_back(fetchBsdf(bsdf[i]));
+        else if (bsdf)
+            m.bsdfs.push_back(fetchBsdf(bsdf));
+        else {
+            Json d = Json::parse("{\"type\":\"lambert\",\"albedo\":1}"); // Primitive::_defaultBsdf
+            m.bsdfs.push_back(parseBsdf(d));
+        }
+        std::string file;
+        if (v.getField("file", file)) {
+            std::string full = file.size() && file[0] == '/' ? file : sceneDir + "/" + file;
+            if (!endsWith(full, ".wo3") || !loadWo3(full, m.verts, m.tris))
+                throw std::runtime_error("Unable to load triangle mesh at " + full);
+        }
+        meshes.push_back(std::move(m));
+        _primOrder.push_back({PrimMesh, int(meshes.size()) - 1});
+    } else if (type == "quad") {
+        QuadSrc q{transform, fetchBsdf(v["bsdf"]), emissionTex};
+        _quadSrc.push_back(q);
+        _primOrder.push_back({PrimQuad, int(_quadSrc.size()) - 1});
+    } else if (type == "cube") {
+        CubeSrc c{transform, fetchBsdf(v["bsdf"]), emissionTex};
+        _cubeSrc.push_back(c);
+        _primOrder.push_back({PrimCube, int(_cubeSrc.size()) - 1});
+    } else if (type == "infinite_sphere") {
+        if (_envSrc.present) throw std::runtime_error("more than one infinite_sphere is outside the hot-path scope");
+        _envSrc.present = true;
+        _envSrc.transform = transform;
+        _envSrc.emissionTex = emissionTex;
+        _envSrc.sample = true;
+        v.getField("sample", _envSrc.sample);
+        _primOrder.push_back({PrimEnv, 0});
+    } else {
+        throw std::runtime_error("Primitive type '" + type + "' is outside the hot-path scope (SURVEY.md section 2 row 6)");
+    }
+}
+
+void Scene::parseCamera(const Json &v)
+{
+    std::string type = "pinhole";
+    v.getField("type", type);
+    if (type != "pinhole") throw std::runtime_error("Camera type '" + type + "' is outside the hot-path scope");
+    v.getField("tonemap", tonemap);
+    float res[2] = {float(resX), float(resY)};
+    if (v.getVec("resolution", res, 2)) {
+        resX = uint32_t(res[0]);
+        resY = uint32_t(res[1]);
+    }
+    if (v["medium"]) throw std::runtime_error("camera media are outside the round-1 scope");
+    v.getField("reconstruction_filter", filterName);
+    if (v["transform"]) camTransform = parseTransform(v["transform"]);
+    v.getField("fov", fovDeg);
+}
+
+Scene Scene::load(const std::string &jsonPath)
+{
+    Scene s;
+    s.sceneDir = dirName(jsonPath);
+    s.sceneJsonText = readFile(jsonPath);
+    Json root = Json::parse(s.sceneJsonText);
+
+    if (root["media"] && root["media"].size() > 0) throw std::runtime_error("participating media are outside the round-1 scope");
+    const Json &bsdfs = root["bsdfs"];
+    for (size_t i = 0; bsdfs && i < bsdfs.size(); ++i) {
+        int id = s.parseBsdf(bsdfs[i]);
+        std::string name;
+        if (bsdfs[i].getField("name", name)) s._namedBsdfs.emplace_back(name, id);
+    }
+    const Json &prims = root["primitives"];
+    for (size_t i = 0; prims && i < prims.size(); ++i) s.parsePrimitive(prims[i]);
+    if (root["camera"]) s.parseCamera(root["camera"]);
+
+    // PathTracerSettings / TraceSettings defaults
+    s.settings.min_bounces = 0;
+    s.settings.max_bounces = 64;
+    s.settings.enable_light_sampling = 1;
+    s.settings.enable_two_sided_shading = 1;
+    s.settings.enable_consistency_checks = 0;
+    if (const Json &it = root["integrator"]) {
+        std::string type = "path_tracer";
+        it.getField("type", type);
+        if (type != "path_tracer")
+            throw std::runtime_error("Integrator '" + type + "' is out of scope: this core implements path_tracer only");
+        bool b;
+        it.getField("min_bounces", s.settings.min_bounces);
+        it.getField("max_bounces", s.settings.max_bounces);
+        if (it.getField("enable_light_sampling", b)) s.settings.enable_light_sampling = b;
+        if (it.getField("enable_two_sided_shading", b)) s.settings.enable_two_sided_shading = b;
+        if (it.getField("enable_consistency_checks", b)) s.settings.enable_consistency_checks = b;
+        bool flag = true;
+        if (it.getField("include_surfaces", flag) && !flag) throw std::runtime_error("include_surfaces=false is outside the hot-path scope");
+    }
+    if (const Json &r = root["renderer"]) {
+        r.getField("output_file", s.renderer.outputFile);
+        r.getField("hdr_output_file", s.renderer.hdrOutputFile);
+        r.getField("resume_render_file", s.renderer.resumeRenderFile);
+        r.getField("overwrite_output_files", s.renderer.overwriteOutputFiles);
+        r.getField("adaptive_sampling", s.renderer.useAdaptiveSampling);
+        r.getField("enable_resume_render", s.renderer.enableResumeRender);
+        r.getField("stratified_sampler", s.renderer.useSobol);
+        r.getField("scene_bvh", s.renderer.useSceneBvh);
+        int v;
+        if (r.getField("spp", v)) s.renderer.spp = uint32_t(v);
+        if (r.getField("spp_step", v)) s.renderer.sppStep = uint32_t(v);
+        if (r["checkpoint_interval"].isString()) s.renderer.checkpointInterval = r["checkpoint_interval"].asString();
+        if (r["timeout"].isString()) s.renderer.timeout = r["timeout"].asString();
+    }
+    return s;
+}
+
+void Scene::setResolution(uint32_t w, uint32_t h)
+{
+    resX = w;
+    resY = h;
+}
+
+// ---------------------------------------------------------------------------
+// flatten: prepareForRender bakes
+// ---------------------------------------------------------------------------
+static void storeMat3(const Mat4 &m, float *dst)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) dst[i*3 + j] = m(i, j);
+}
+
+static float filterEval(const std::string &name, float x) // ReconstructionFilter.hpp:187-209
+{
+    if (name == "tent") return 1.0f - std::abs(x);
+    if (name == "gaussian") {
+        const float Alpha = 2.0f;
+        return std::max(std::exp(-Alpha*x*x) - std::exp(-Alpha*4.0f), 0.0f);
+    }
+    x = std::abs(x);
+    if (name == "mitchell_netravali") {
+        const float B = 1.0f/3.0f, C = 1.0f/3.0f;
+        if (x < 1.0f)
+            return 1.0f/6.0f*((12.0f - 9.0f*B - 6.0f*C)*x*x*x + (-18.0f + 12.0f*B + 6.0f*C)*x*x + (6.0f - 2.0f*B));
+        else if (x < 2.0f)
+            return 1.0f/6.0f*((-B - 6.0f*C)*x*x*x + (6.0f*B + 30.0f*C)*x*x + (-12.0f*B - 48.0f*C)*x + (8.0f*B + 24.0f*C));
+        return 0.0f;
+    }
+    if (name == "catmull_rom") {
+        if (x < 1.0f) return 1.0f/6.0f*((12.0f - 3.0f)*x*x*x + (-18.0f + 3.0f)*x*x + 6.0f);
+        else if (x < 2.0f) return 1.0f/6.0f*(-3.0f*x*x*x + 15.0f*x*x - 24.0f*x + 12.0f);
+        return 0.0f;
+    }
+    if (name == "lanczos") {
+        if (x == 0.0f) return 1.0f;
+        else if (x < 2.0f) return std::sin(PI*x)*std::sin(PI*x/2.0f)/(PI*PI*x*x/2.0f);
+        return 0.0f;
+    }
+    throw JsonLoadException("Unknown reconstruction filter '" + name + "'");
+}
+
+void Scene::flatten()
+{
+    const int RFILTER_RESOLUTION = 31;
+    _desc = tgpu_scene_desc{};
+    _desc.abi_version = TGPU_ABI_VERSION;
+
+    // ---- camera: Camera::fromJson flips the right axis (Camera.cpp:64), then precompute ----
+    tgpu_camera &cam = _desc.camera;
+    Mat4 t = camTransform;
+    Vec3 pos = t.translation();
+    t.setRight(-t.right());
+    cam.pos[0] = pos.x; cam.pos[1] = pos.y; cam.pos[2] = pos.z;
+    storeMat3(t, cam.rot);
+    cam.res_x = resX;
+    cam.res_y = resY;
+    cam.ratio = resY/float(resX);
+    cam.pixel_size_x = 1.0f/resX;
+    float fovRad = fovDeg*(PI/180.0f);
+    cam.plane_dist = 1.0f/std::tan(fovRad*0.5f);
+    if (filterName == "dirac") {
+        cam.filter_type = TGPU_FILTER_DIRAC;
+    } else if (filterName == "box") {
+        cam.filter_type = TGPU_FILTER_BOX;
+    } else { // ReconstructionFilter.cpp:34-58
+        cam.filter_type = TGPU_FILTER_TABULATED;
+        float width = filterName == "tent" ? 1.0f : 2.0f;
+        cam.filter_bin_size = width/RFILTER_RESOLUTION;
+        float filter[RFILTER_RESOLUTION + 1];
+        float filterSum = 0.0f;
+        for (int i = 0; i < RFILTER_RESOLUTION; ++i) {
+            filter[i] = filterEval(filterName, (i*width)/RFILTER_RESOLUTION);
+            filterSum += filter[i];
+        }
+        cam.filter_cdf[0] = 0.0f;
+        for (int i = 1; i < RFILTER_RESOLUTION; ++i) cam.filter_cdf[i] = cam.filter_cdf[i - 1] + filter[i - 1]/filterSum;
+        cam.filter_cdf[RFILTER_RESOLUTION] = 1.0f;
+    }
+
+    _desc.settings = settings;
+    _desc.settings.use_sobol = renderer.useSobol ? 1 : 0;
+
+    // ---- meshes: world-space bake (TriangleMesh.cpp:524-552) ----
+    _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear();
+    for (const MeshData &m : meshes) {
+        size_t nv = m.verts.size()/8, nt = m.tris.size()/4;
+        Mat4 normalTform = m.transform.toNormalMatrix();
+        std::vector<Vec3> p(nv), n(nv);
+        for (size_t i = 0; i < nv; ++i) {
+            const float *v = &m.verts[i*8];
+            p[i] = m.transform*Vec3(v[0], v[1], v[2]);
+            n[i] = normalTform.transformVector(Vec3(v[3], v[4], v[5]));
+        }
+        for (size_t i = 0; i < nt; ++i) {
+            const uint32_t *tri = &m.tris[i*4];
+            int material = int(int32_t(tri[3]));
+            material = std::min(std::max(material, 0), int(m.bsdfs.size()) - 1);
+            for (int k = 0; k < 3; ++k) {
+                uint32_t vi = tri[k];
+                if (vi >= nv) throw std::runtime_error("mesh '" + m.name + "' has an out-of-range vertex index");
+                _triPos.push_back(p[vi].x); _triPos.push_back(p[vi].y); _triPos.push_back(p[vi].z);
+                _triNormal.push_back(n[vi].x); _triNormal.push_back(n[vi].y); _triNormal.push_back(n[vi].z);
+                _triUv.push_back(m.verts[size_t(vi)*8 + 6]); _triUv.push_back(m.verts[size_t(vi)*8 + 7]);
+            }
+            _triBsdf.push_back(m.bsdfs[size_t(material)]);
+            _triSmooth.push_back(m.smooth ? 1 : 0);
+        }
+    }
+    _desc.n_tris = uint32_t(_triBsdf.size());
+    _desc.tri_pos = _triPos.data();
+    _desc.tri_normal = _triNormal.data();
+    _desc.tri_uv = _triUv.data();
+    _desc.tri_bsdf = _triBsdf.data();
+    _desc.tri_smooth = _triSmooth.data();
+
+    // ---- quads (Quad.cpp:298-316) ----
+    _quads.clear();
+    for (const QuadSrc &q : _quadSrc) {
+        tgpu_quad o{};
+        Vec3 base = q.transform*Vec3(0.0f);
+        Vec3 edge0 = q.transform.transformVector(Vec3(1.0f, 0.0f, 0.0f));
+        Vec3 edge1 = q.transform.transformVector(Vec3(0.0f, 0.0f, 1.0f));
+        base -= edge0*0.5f;
+        base -= edge1*0.5f;
+        Vec3 n = edge1.cross(edge0);
+        float area = n.length();
+        n /= area;
+        Vec3 tg = edge0.normalized(), bt = edge1.normalized();
+        for (int i = 0; i < 3; ++i) {
+            o.base[i] = base[i]; o.edge0[i] = edge0[i]; o.edge1[i] = edge1[i];
+            o.normal[i] = n[i]; o.tangent[i] = tg[i]; o.bitangent[i] = bt[i];
+        }
+        o.area = area;
+        o.inv_uv_sq[0] = 1.0f/edge0.lengthSq();
+        o.inv_uv_sq[1] = 1.0f/edge1.lengthSq();
+        o.bsdf = q.bsdf;
+        o.emission_tex = q.emissionTex;
+        _quads.push_back(o);
+    }
+    _desc.n_quads = uint32_t(_quads.size());
+    _desc.quads = _quads.data();
+
+    // ---- cubes (Cube.cpp:353-370) ----
+    _cubes.clear();
+    for (const CubeSrc &c : _cubeSrc) {
+        tgpu_cube o{};
+        Vec3 p = c.transform*Vec3(0.0f);
+        Vec3 sc = c.transform.extractScale()*Vec3(0.5f);
+        Mat4 rot = c.transform.extractRotation();
+        Mat4 inv = rot.transpose();
+        storeMat3(rot, o.rot);
+        storeMat3(inv, o.inv_rot);
+        for (int i = 0; i < 3; ++i) { o.pos[i] = p[i]; o.scale[i] = sc[i]; }
+        o.bsdf = c.bsdf;
+        o.emission_tex = c.emissionTex;
+        _cubes.push_back(o);
+    }
+    _desc.n_cubes = uint32_t(_cubes.size());
+    _desc.cubes = _cubes.data();
+
+    // ---- lights in primitive order (TraceableScene.hpp:86-102) ----
+    _lights.clear();
+    int lightCount = 0;
+    for (const PrimRef &pr : _primOrder) {
+        if (pr.kind == PrimQuad && _quadSrc[size_t(pr.index)].emissionTex >= 0) {
+            _lights.push_back({TGPU_LIGHT_QUAD, pr.index});
+            ++lightCount;
+        } else if (pr.kind == PrimCube && _cubeSrc[size_t(pr.index)].emissionTex >= 0) {
+            throw std::runtime_error("emissive cubes are outside the hot-path scope");
+        } else if (pr.kind == PrimEnv && _envSrc.emissionTex >= 0) {
+            ++lightCount;
+            if (_envSrc.sample) _lights.push_back({TGPU_LIGHT_ENV, 0});
+        }
+    }
+    EnvSrc env = _envSrc;
+    if (env.present && env.emissionTex < 0) env.present = false; // non-emissive sphere never contributes
+    if (lightCount == 0) { // default white environment (TraceableScene.hpp:97-102)
+        Json one; one.type = Json::Number; one.num = 1.0;
+        env = EnvSrc{};
+        env.present = true;
+        env.sample = true;
+        env.emissionTex = fetchTexture(one, false);
+        _lights.push_back({TGPU_LIGHT_ENV, 0});
+    }
+    _desc.n_lights = uint32_t(_lights.size());
+    _desc.lights = _lights.data();
+
+    // ---- environment (InfiniteSphere.cpp:280-286, BitmapTexture.cpp:400-431, Distribution2D.hpp:18-64) ----
+    tgpu_env &e = _desc.env;
+    e = tgpu_env{};
+    e.present = env.present ? 1 : 0;
+    if (env.present) {
+        e.samplable = env.sample ? 1 : 0;
+        e.emission_tex = env.emissionTex;
+        Mat4 rot = env.transform.extractRotation();
+        Mat4 inv = rot.transpose();
+        storeMat3(rot, e.rot);
+        storeMat3(inv, e.inv_rot);
+        const tgpu_texture &tex = _textures[size_t(env.emissionTex)];
+        if (tex.type == TGPU_TEX_CHECKER) throw std::runtime_error("checker emission on infinite_sphere is outside the hot-path scope");
+        if (tex.type == TGPU_TEX_BITMAP && env.sample) {
+            const tgpu_bitmap &bm = _bitmaps[size_t(tex.bitmap)];
+            const std::vector<float> &px = _bitmapTexels[size_t(tex.bitmap)];
+            int w = bm.w, h = bm.h;
+            std::vector<float> weights(size_t(w)*h);
+            for (int y = 0, idx = 0; y < h; ++y) {
+                float rowWeight = 1.0f;
+                rowWeight *= std::sin((y*PI)/h);
+                for (int x = 0; x < w; ++x, ++idx) {
+                    const float *c = &px[size_t(idx)*3];
+                    float m = c[0]; if (c[1] > m) m = c[1]; if (c[2] > m) m = c[2];
+                    weights[size_t(idx)] = m*rowWeight;
+                }
+            }
+            auto W = [&](int x, int y) -> float & { return weights[size_t(x) + size_t(y)*w]; };
+            for (int y = 0; y < h; ++y) {
+                for (int x = 0; x < w - 1; ++x) W(x, y) = std::max(W(x, y), W(x + 1, y));
+                if (!bm.clamp) W(0, y) = W(w - 1, y) = std::max(W(w - 1, y), W(0, y));
+                for (int x = w - 1; x > 0; --x) W(x, y) = std::max(W(x, y), W(x - 1, y));
+            }
+            for (int x = 0; x < w; ++x) {
+                for (int y = 0; y < h - 1; ++y) W(x, y) = std::max(W(x, y), W(x, y + 1));
+                if (!bm.clamp) W(x, 0) = W(x, h - 1) = std::max(W(x, 0), W(x, h - 1));
+                for (int y = h - 1; y > 0; --y) W(x, y) = std::max(W(x, y), W(x, y - 1));
+            }
+            // Distribution2D ctor
+            _envPdf = std::move(weights);
+            _envCdf.assign(_envPdf.size() + size_t(h), 0.0f);
+            _envMarginalPdf.assign(size_t(h), 0.0f);
+            _envMarginalCdf.assign(size_t(h) + 1, 0.0f);
+            _envMarginalCdf[0] = 0.0f;
+            for (int y = 0; y < h; ++y) {
+                size_t idxP = size_t(y)*w, idxC = size_t(y)*(w + 1);
+                _envCdf[idxC] = 0.0f;
+                for (int x = 0; x < w; ++x, ++idxP, ++idxC) {
+                    _envMarginalPdf[size_t(y)] += _envPdf[idxP];
+                    _envCdf[idxC + 1] = _envCdf[idxC] + _envPdf[idxP];
+                }
+                _envMarginalCdf[size_t(y) + 1] = _envMarginalCdf[size_t(y)] + _envMarginalPdf[size_t(y)];
+            }
+            for (int y = 0; y < h; ++y) {
+                size_t idxP = size_t(y)*w, idxC = size_t(y)*(w + 1);
+                size_t idxTail = idxC + size_t(w);
+                float rowWeight = _envCdf[idxTail];
+                if (rowWeight < 1e-4f) {
+                    for (int x = 0; x < w; ++x, ++idxP, ++idxC) {
+                        _envPdf[idxP] = 1.0f/w;
+                        _envCdf[idxC] = x/float(w);
+                    }
+                } else {
+                    for (int x = 0; x < w; ++x, ++idxP, ++idxC) {
+                        _envPdf[idxP] /= rowWeight;
+                        _envCdf[idxC] /= rowWeight;
+                    }
+                }
+                _envCdf[idxTail] = 1.0f;
+            }
+            float totalWeight = _envMarginalCdf.back();
+            for (float &p : _envMarginalPdf) p /= totalWeight;
+            for (float &c : _envMarginalCdf) c /= totalWeight;
+            _envMarginalCdf.back() = 1.0f;
+            e.dist_w = w;
+            e.dist_h = h;
+            e.pdf = _envPdf.data();
+            e.cdf = _envCdf.data();
+            e.marginal_pdf = _envMarginalPdf.data();
+            e.marginal_cdf = _envMarginalCdf.data();
+        }
+    }
+
+    for (size_t i = 0; i < _bitmaps.size(); ++i) _bitmaps[i].texels = _bitmapTexels[i].data();
+    _desc.n_bsdfs = uint32_t(_bsdfs.size());
+    _desc.bsdfs = _bsdfs.data();
+    _desc.n_textures = uint32_t(_textures.size());
+    _desc.textures = _textures.data();
+    _desc.n_bitmaps = uint32_t(_bitmaps.size());
+    _desc.bitmaps = _bitmaps.data();
+
+    // ---- Sobol' matrices asset ----
+    if (_sobol.empty()) {
+        std::string path = assetDir() + "/sobol_matrices_1024x32.bin";
+        FILE *f = std::fopen(path.c_str(), "rb");
+        if (!f) throw std::runtime_error("Unable to open Sobol' matrix asset '" + path + "' (set TUNGSTEN_AMD_ASSETS)");
+        _sobol.resize(1024*32);
+        size_t got = std::fread(_sobol.data(), 4, _sobol.size(), f);
+        std::fclose(f);
+        if (got != _sobol.size()) throw std::runtime_error("Sobol' matrix asset '" + path + "' is truncated");
+    }
+    _desc.sobol_matrices = _sobol.data();
+}
+
+// ---------------------------------------------------------------------------
+// shard
+// ---------------------------------------------------------------------------
+Shard makeShard(uint32_t resX, uint32_t resY, uint32_t seed, uint32_t rank, uint32_t world)
+{
+    const uint32_t TileSize = 16;
+    Shard s;
+    Pcg32 sampler(hash32(seed)); // PathTraceIntegrator.cpp:187
+    uint32_t tileId = 0;
+    for (uint32_t y = 0; y < resY; y += TileSize) {
+        for (uint32_t x = 0; x < resX; x += TileSize, ++tileId) {
+            uint32_t tileSeed = hash32(sampler.nextI()); // :36-38, drawn for every tile in row-major order
+            if (world > 1 && tileId % world != rank) continue;
+            uint32_t tw = std::min(TileSize, resX - x), th = std::min(TileSize, resY - y);
+            // 8x8 blocks inside the tile keep one wavefront's 64 primary rays spatially compact
+            for (uint32_t by = 0; by < th; by += 8)
+                for (uint32_t bx = 0; bx < tw; bx += 8)
+                    for (uint32_t py = by; py < std::min(by + 8, th); ++py)
+                        for (uint32_t px = bx; px < std::min(bx + 8, tw); ++px) {
+                            s.pixelIndex.push_back((x + px) + (y + py)*resX);
+                            s.tileSeed.push_back(tileSeed);
+                        }
+        }
+    }
+    return s;
+}
+
+} // namespace tungsten_amd

@@ -250,6 +250,11 @@ int tgpu_set_profiling(tgpu_ctx *ctx, uint32_t flags);
 int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out);
 int tgpu_reset_stats(tgpu_ctx *ctx);
 
+/* Test hook: evaluates include/tgpu_math.h on the device so that the "bit-identical to the
+ * host" claim can be checked.  kind: 0 sin, 1 cos, 2 exp, 3 log, 4 atan2(a,b), 5 acos,
+ * 6 a/b, 7 sqrt(a).  a, b, out: n floats in host memory.                      */
+int tgpu_eval_math(tgpu_ctx *ctx, int kind, const float *a, const float *b, uint32_t n, float *out);
+
 #ifdef __cplusplus
 }
 #endif

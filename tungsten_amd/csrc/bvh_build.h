@@ -1,0 +1,218 @@
+// Host-side SAH builder for the GPU BVH2 (replaces Embree's BVH4 builder; design model:
+// the reference's own binned SAH, src/core/bvh/BvhBuilder.cpp:99-157 and
+// BinnedSahSplitter.hpp:37-65 -- 32 bins, object splits, full bounds).
+//
+// GPU node layout (64 B = 4 x float4, one node holds BOTH children's boxes so a traversal
+// step needs a single 64-byte fetch):
+//   q0 = (c0.lo.x, c0.lo.y, c0.lo.z, c0.hi.x)
+//   q1 = (c0.hi.y, c0.hi.z, c1.lo.x, c1.lo.y)
+//   q2 = (c1.lo.z, c1.hi.x, c1.hi.y, c1.hi.z)
+//   q3 = (bits child0, bits child1, 0, 0)
+// child >= 0: inner node index; child < 0: leaf, payload = child & 0x7FFFFFFF =
+// (firstTri << 2) | (count - 1), count in 1..4, triangles stored in BVH order.
+// Triangle layout (48 B = 3 x float4), Embree's precomputed form
+// (thirdparty/embree/kernels/geometry/triangle.h:53-54): v0, e1 = v0-v1, e2 = v2-v0, Ng = e1 x e2
+//   t0 = (v0.x, v0.y, v0.z, e1.x)  t1 = (e1.y, e1.z, e2.x, e2.y)  t2 = (e2.z, Ng.x, Ng.y, Ng.z)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace tgpu_bvh {
+
+struct Float4 { float x, y, z, w; };
+
+struct Bvh {
+    std::vector<Float4> nodes;     // 4 per node; node 0 is the root
+    std::vector<Float4> tris;      // 3 per triangle, BVH order
+    std::vector<uint32_t> triId;   // BVH order -> index into the scene's triangle soup
+    uint32_t rootChild = 0;        // encoded root (a leaf when the scene has <= 4 triangles)
+    int maxDepth = 0;
+    uint32_t nodeCount = 0;
+};
+
+struct Box {
+    float lo[3], hi[3];
+    void reset()
+    {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; }
+    }
+    void grow(const Box &b)
+    {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+    }
+    float halfArea() const
+    {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx*dy + dy*dz + dz*dx;
+    }
+};
+
+class Builder {
+public:
+    Builder(const float *triPos, uint32_t nTris) : _pos(triPos), _n(nTris) {}
+
+    Bvh build()
+    {
+        Bvh out;
+        _out = &out;
+        _boxes.resize(_n);
+        _cent.resize(size_t(_n)*3);
+        _order.resize(_n);
+        for (uint32_t i = 0; i < _n; ++i) {
+            const float *p = _pos + size_t(i)*9;
+            Box b;
+            for (int k = 0; k < 3; ++k) {
+                b.lo[k] = std::min(p[k], std::min(p[3 + k], p[6 + k]));
+                b.hi[k] = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+                _cent[size_t(i)*3 + k] = 0.5f*(b.lo[k] + b.hi[k]);
+            }
+            _boxes[i] = b;
+            _order[i] = i;
+        }
+        out.triId.reserve(_n);
+        out.tris.reserve(size_t(_n)*3);
+        if (_n == 0) {
+            out.rootChild = 0x80000000u; // never dereferenced: kernels test n_tris first
+            return out;
+        }
+        Box rootBox;
+        out.rootChild = uint32_t(recurse(0, _n, 1, rootBox));
+        out.nodeCount = uint32_t(out.nodes.size()/4);
+        return out;
+    }
+
+private:
+    static constexpr int Bins = 32;
+    static constexpr uint32_t MaxLeaf = 4;
+
+    int32_t makeLeaf(uint32_t first, uint32_t count, Box &box)
+    {
+        uint32_t start = uint32_t(_out->triId.size());
+        box.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            uint32_t id = _order[i];
+            box.grow(_boxes[id]);
+            const float *p = _pos + size_t(id)*9;
+            float v0[3] = {p[0], p[1], p[2]};
+            float e1[3] = {p[0] - p[3], p[1] - p[4], p[2] - p[5]};
+            float e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+            float ng[3] = {e1[1]*e2[2] - e1[2]*e2[1], e1[2]*e2[0] - e1[0]*e2[2], e1[0]*e2[1] - e1[1]*e2[0]};
+            _out->tris.push_back({v0[0], v0[1], v0[2], e1[0]});
+            _out->tris.push_back({e1[1], e1[2], e2[0], e2[1]});
+            _out->tris.push_back({e2[2], ng[0], ng[1], ng[2]});
+            _out->triId.push_back(id);
+        }
+        return int32_t(0x80000000u | (start << 2) | (count - 1));
+    }
+
+    int32_t recurse(uint32_t first, uint32_t count, int depth, Box &box)
+    {
+        _out->maxDepth = std::max(_out->maxDepth, depth);
+        if (count <= MaxLeaf) return makeLeaf(first, count, box);
+
+        Box cb;
+        cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            const float *c = &_cent[size_t(_order[i])*3];
+            for (int k = 0; k < 3; ++k) { cb.lo[k] = std::min(cb.lo[k], c[k]); cb.hi[k] = std::max(cb.hi[k], c[k]); }
+        }
+        float bestCost = std::numeric_limits<float>::infinity();
+        int bestAxis = -1, bestSplit = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            float ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0.0f)) continue;
+            float scale = float(Bins)/ext;
+            uint32_t cnt[Bins] = {0};
+            Box bb[Bins];
+            for (int b = 0; b < Bins; ++b) bb[b].reset();
+            for (uint32_t i = first; i < first + count; ++i) {
+                uint32_t id = _order[i];
+                int b = std::min(Bins - 1, int((_cent[size_t(id)*3 + ax] - cb.lo[ax])*scale));
+                cnt[b]++;
+                bb[b].grow(_boxes[id]);
+            }
+            float rightArea[Bins];
+            uint32_t rightCnt[Bins];
+            Box acc;
+            acc.reset();
+            uint32_t c = 0;
+            for (int b = Bins - 1; b >= 1; --b) {
+                acc.grow(bb[b]);
+                c += cnt[b];
+                rightArea[b] = c ? acc.halfArea() : 0.0f;
+                rightCnt[b] = c;
+            }
+            acc.reset();
+            c = 0;
+            for (int b = 0; b < Bins - 1; ++b) {
+                acc.grow(bb[b]);
+                c += cnt[b];
+                if (c == 0 || rightCnt[b + 1] == 0) continue;
+                float cost = acc.halfArea()*float(c) + rightArea[b + 1]*float(rightCnt[b + 1]);
+                if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestSplit = b; }
+            }
+        }
+        uint32_t mid;
+        if (bestAxis >= 0) {
+            float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+            float scale = float(Bins)/ext;
+            auto it = std::partition(_order.begin() + first, _order.begin() + first + count, [&](uint32_t id) {
+                int b = std::min(Bins - 1, int((_cent[size_t(id)*3 + bestAxis] - cb.lo[bestAxis])*scale));
+                return b <= bestSplit;
+            });
+            mid = uint32_t(it - _order.begin());
+            if (mid == first || mid == first + count) mid = first + count/2;
+        } else {
+            mid = first + count/2; // all centroids coincide
+        }
+        // depth guard: the traversal stack is sized from maxDepth, keep it bounded for pathological input
+        if (depth >= 60) {
+            std::nth_element(_order.begin() + first, _order.begin() + first + count/2, _order.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return _cent[size_t(a)*3] < _cent[size_t(b)*3]; });
+            mid = first + count/2;
+        }
+
+        uint32_t nodeIdx = uint32_t(_out->nodes.size()/4);
+        _out->nodes.resize(_out->nodes.size() + 4);
+        Box b0, b1;
+        int32_t c0 = recurse(first, mid - first, depth + 1, b0);
+        int32_t c1 = recurse(mid, first + count - mid, depth + 1, b1);
+        // pad the boxes by a few ulps so that the fma-based slab test stays conservative
+        pad(b0);
+        pad(b1);
+        Float4 *q = &_out->nodes[size_t(nodeIdx)*4];
+        q[0] = {b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]};
+        q[1] = {b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]};
+        q[2] = {b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]};
+        float f0, f1;
+        std::memcpy(&f0, &c0, 4);
+        std::memcpy(&f1, &c1, 4);
+        q[3] = {f0, f1, 0.0f, 0.0f};
+        box = b0;
+        box.grow(b1);
+        return int32_t(nodeIdx);
+    }
+
+    static void pad(Box &b)
+    {
+        for (int k = 0; k < 3; ++k) {
+            float m = std::max(std::abs(b.lo[k]), std::abs(b.hi[k]));
+            float eps = m*4.8e-7f + 1e-30f;
+            b.lo[k] -= eps;
+            b.hi[k] += eps;
+        }
+    }
+
+    const float *_pos;
+    uint32_t _n;
+    Bvh *_out = nullptr;
+    std::vector<Box> _boxes;
+    std::vector<float> _cent;
+    std::vector<uint32_t> _order;
+};
+
+} // namespace tgpu_bvh

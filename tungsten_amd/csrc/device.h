@@ -1,0 +1,680 @@
+// Device-side building blocks of the wavefront path tracer: vector math, sampler,
+// textures, lights, BSDFs.  Every function states the reference code it
+// replaces (paths relative to /root/reference/src/core).  Compiled with
+// -ffp-contract=off; the only fused multiply-adds are the explicit ones in
+// include/tgpu_math.h and in the BVH slab test, so the arithmetic is bit-for-bit
+// what the CPU oracle computes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tungsten_amd.h"
+#include "../../include/tgpu_math.h"
+
+#define TG_DEV __device__ __forceinline__
+
+namespace tg {
+
+constexpr float PI = 3.1415926536f; // math/Angle.hpp:8-16
+constexpr float TWO_PI = PI*2.0f;
+constexpr float INV_PI = 1.0f/PI;
+constexpr float INV_TWO_PI = 0.5f*INV_PI;
+constexpr float INV_FOUR_PI = 0.25f*INV_PI;
+#define TG_INF __builtin_huge_valf()
+
+// ---- Vec3f (math/Vec.hpp:127-193): same operation order as the reference ---------------
+struct V3 {
+    float x, y, z;
+    TG_DEV V3() : x(0), y(0), z(0) {}
+    TG_DEV explicit V3(float a) : x(a), y(a), z(a) {}
+    TG_DEV V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    TG_DEV explicit V3(const float *p) : x(p[0]), y(p[1]), z(p[2]) {}
+    TG_DEV V3 operator+(const V3 &o) const { return V3(x + o.x, y + o.y, z + o.z); }
+    TG_DEV V3 operator-(const V3 &o) const { return V3(x - o.x, y - o.y, z - o.z); }
+    TG_DEV V3 operator*(const V3 &o) const { return V3(x*o.x, y*o.y, z*o.z); }
+    TG_DEV V3 operator/(const V3 &o) const { return V3(x/o.x, y/o.y, z/o.z); }
+    TG_DEV V3 operator*(float s) const { return V3(x*s, y*s, z*s); }
+    TG_DEV V3 operator/(float s) const { return V3(x/s, y/s, z/s); }
+    TG_DEV V3 operator+(float s) const { return V3(x + s, y + s, z + s); }
+    TG_DEV V3 operator-(float s) const { return V3(x - s, y - s, z - s); }
+    TG_DEV V3 operator-() const { return V3(-x, -y, -z); }
+    TG_DEV V3 &operator+=(const V3 &o) { x += o.x; y += o.y; z += o.z; return *this; }
+    TG_DEV V3 &operator*=(const V3 &o) { x *= o.x; y *= o.y; z *= o.z; return *this; }
+    TG_DEV V3 &operator*=(float s) { x *= s; y *= s; z *= s; return *this; }
+    TG_DEV V3 &operator/=(float s) { x /= s; y /= s; z /= s; return *this; }
+    TG_DEV bool isZero() const { return x == 0.0f && y == 0.0f && z == 0.0f; }
+    TG_DEV float dot(const V3 &o) const { float s = x*o.x; s += y*o.y; s += z*o.z; return s; }
+    TG_DEV float lengthSq() const { float r = 0.0f; r += x*x; r += y*y; r += z*z; return r; }
+    TG_DEV float length() const { return __builtin_sqrtf(lengthSq()); }
+    TG_DEV V3 normalized() const { float inv = 1.0f/length(); return V3(x*inv, y*inv, z*inv); }
+    TG_DEV V3 cross(const V3 &o) const { return V3(y*o.z - z*o.y, z*o.x - x*o.z, x*o.y - y*o.x); }
+    TG_DEV float sum() const { float r = x; r += y; r += z; return r; }
+    TG_DEV float avg() const { return sum()*(1.0f/3.0f); }
+    TG_DEV float max() const { float m = x; if (y > m) m = y; if (z > m) m = z; return m; }
+    TG_DEV float comp(int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+TG_DEV V3 operator*(float s, const V3 &v) { return V3(v.x*s, v.y*s, v.z*s); }
+TG_DEV V3 vabs(const V3 &v) { return V3(__builtin_fabsf(v.x), __builtin_fabsf(v.y), __builtin_fabsf(v.z)); }
+TG_DEV float fmin2(float a, float b) { return a < b ? a : b; } // Tungsten::min/max/clamp (math/MathUtil.hpp)
+TG_DEV float fmax2(float a, float b) { return a > b ? a : b; }
+TG_DEV float clampf(float v, float lo, float hi) { return fmin2(fmax2(v, lo), hi); }
+TG_DEV bool isnanf_(float v) { return v != v; }
+TG_DEV bool isinff_(float v) { return __builtin_fabsf(v) == TG_INF; }
+
+TG_DEV V3 mulPoint0(const float *m, const V3 &b) // Mat4f*Vec3f, zero translation (math/Mat4f.hpp:320-327)
+{
+    return V3(m[0]*b.x + m[1]*b.y + m[2]*b.z + 0.0f, m[3]*b.x + m[4]*b.y + m[5]*b.z + 0.0f, m[6]*b.x + m[7]*b.y + m[8]*b.z + 0.0f);
+}
+TG_DEV V3 mulVector(const float *m, const V3 &b) // Mat4f::transformVector (math/Mat4f.hpp:159-166)
+{
+    return V3(m[0]*b.x + m[1]*b.y + m[2]*b.z, m[3]*b.x + m[4]*b.y + m[5]*b.z, m[6]*b.x + m[7]*b.y + m[8]*b.z);
+}
+
+// ---- BsdfLobes (bsdfs/BsdfLobes.hpp) ------------------------------------------------------
+enum : uint32_t {
+    GlossyReflectionLobe = 1u << 0, GlossyTransmissionLobe = 1u << 1, DiffuseReflectionLobe = 1u << 2,
+    DiffuseTransmissionLobe = 1u << 3, SpecularReflectionLobe = 1u << 4, SpecularTransmissionLobe = 1u << 5,
+    AnisotropicLobe = 1u << 6, ForwardLobe = 1u << 7,
+    SpecularLobe = SpecularReflectionLobe | SpecularTransmissionLobe,
+    TransmissiveLobe = GlossyTransmissionLobe | DiffuseTransmissionLobe | SpecularTransmissionLobe,
+    ReflectiveLobe = GlossyReflectionLobe | DiffuseReflectionLobe | SpecularReflectionLobe,
+    AllLobes = TransmissiveLobe | ReflectiveLobe | AnisotropicLobe,
+    AllButSpecular = ~(SpecularLobe | ForwardLobe),
+};
+
+// ---- device scene -----------------------------------------------------------------------------
+struct DBitmap { int32_t w, h, clamp, linear; float scale; const float *texels; };
+
+struct DScene {
+    tgpu_camera cam;
+    tgpu_settings settings;
+    // BVH (bvh_build.h layout)
+    const float4 *nodes;
+    const float4 *tris;
+    const uint32_t *triId;
+    uint32_t rootChild;
+    uint32_t nTris;
+    int32_t stackEntries;
+    // per-triangle shading records, soup order: 5 x float4
+    //   s0 = (n0.xyz, n1.x) s1 = (n1.yz, n2.xy) s2 = (n2.z, uv0.xy, uv1.x) s3 = (uv1.y, uv2.xy, bits(bsdf | smooth<<31))
+    //   s4 = (unnormalised Ng = (p1-p0)x(p2-p0), 0)
+    const float4 *triShade;
+    const uint8_t *triClass; // BSDF class of each triangle (queue selection in the extend kernel)
+    const tgpu_quad *quads; uint32_t nQuads;
+    const tgpu_cube *cubes; uint32_t nCubes;
+    const tgpu_bsdf *bsdfs;
+    const tgpu_texture *textures;
+    const DBitmap *bitmaps;
+    const tgpu_light *lights; uint32_t nLights;
+    tgpu_env env;          // pointers are device pointers
+    int32_t envConstant;   // emission texture is constant
+    const uint32_t *sobol; // 1024 x 32
+};
+
+// prim id encoding shared with the C ABI: kind << 30 | index; 0xFFFFFFFF = miss
+constexpr uint32_t PRIM_MISS = 0xFFFFFFFFu;
+constexpr uint32_t KIND_TRI = 0u, KIND_QUAD = 1u, KIND_CUBE = 2u, KIND_ENV = 3u;
+TG_DEV uint32_t primKind(uint32_t p) { return p >> 30; }
+TG_DEV uint32_t primIndex(uint32_t p) { return p & 0x3FFFFFFFu; }
+
+// ---- sampler (sampling/SobolPathSampler.hpp:20-84, UniformSampler.hpp:40-52) --------------------
+TG_DEV uint32_t hash32(uint32_t x) // math/MathUtil.hpp:120-128
+{
+    x = ~x + (x << 15);
+    x = x ^ (x >> 12);
+    x = x + (x << 2);
+    x = x ^ (x >> 4);
+    x = x*2057;
+    x = x ^ (x >> 16);
+    return x;
+}
+TG_DEV float normalizedUint(uint32_t i) { return tgpu_bits_to_float((i >> 9u) | 0x3F800000u) - 1.0f; } // BitManip.hpp:47-50
+
+struct Sampler {
+    const uint32_t *matrices;
+    uint64_t pcg;       // path-local supplemental stream (sequence 0 -> increment 1)
+    uint32_t scramble, index, dimension;
+    int32_t sobol;
+
+    TG_DEV uint32_t pcgNext()
+    {
+        uint64_t oldState = pcg;
+        pcg = oldState*6364136223846793005ULL + 1ULL;
+        uint32_t xorShifted = uint32_t(((oldState >> 18u) ^ oldState) >> 27u);
+        uint32_t rot = uint32_t(oldState >> 59u);
+        return (xorShifted >> rot) | (xorShifted << ((0u - rot) & 31u));
+    }
+    TG_DEV float pcg1D() { return normalizedUint(pcgNext()); }
+    // pcg32_srandom(seed = scramble:sampleIndex, inc = 1): the path-local replacement of the
+    // reference's tile-sequential stream (hard part 1)
+    TG_DEV void seedPathLocal(uint32_t scr, uint32_t sampleIndex)
+    {
+        pcg = 0;
+        pcgNext();
+        pcg += (uint64_t(scr) << 32) | uint64_t(sampleIndex);
+        pcgNext();
+    }
+    TG_DEV bool nextBoolean(float pTrue) { return pcg1D() < pTrue; }
+    TG_DEV float next1D()
+    {
+        if (!sobol || dimension >= 1024u) return pcg1D();
+        uint32_t result = scramble; // thirdparty/sobol/sobol.h:40-53
+        uint32_t idx = (index & ~0xFFu) | ((index + scramble) & 0xFFu);
+        const uint32_t *m = matrices + dimension*32u;
+        while (idx) {
+            int b = __builtin_ctz(idx);
+            result ^= m[b];
+            idx &= idx - 1u;
+        }
+        dimension++;
+        return normalizedUint(result);
+    }
+};
+
+// ---- textures ---------------------------------------------------------------------------------
+TG_DEV V3 loadRgb(const float *p) { return V3(p[0], p[1], p[2]); }
+
+TG_DEV V3 bitmapEval(const DBitmap &bm, float ux, float uy) // textures/BitmapTexture.cpp:298-352
+{
+    int w = bm.w, h = bm.h;
+    float u = ux*w;
+    float v = (1.0f - uy)*h;
+    bool linear = bm.linear != 0;
+    if (linear) {
+        u -= 0.5f;
+        v -= 0.5f;
+    }
+    int iu0 = u < 0.0f ? -int(-u) - 1 : int(u);
+    int iv0 = v < 0.0f ? -int(-v) - 1 : int(v);
+    int iu1 = iu0 + 1;
+    int iv1 = iv0 + 1;
+    u -= iu0;
+    v -= iv0;
+    if (!bm.clamp) {
+        iu0 = ((iu0 % w) + w) % w;
+        iu1 = ((iu1 % w) + w) % w;
+        iv0 = ((iv0 % h) + h) % h;
+        iv1 = ((iv1 % h) + h) % h;
+    } else {
+        iu0 = min(max(iu0, 0), w - 1);
+        iu1 = min(max(iu1, 0), w - 1);
+        iv0 = min(max(iv0, 0), h - 1);
+        iv1 = min(max(iv1, 0), h - 1);
+    }
+    const float *t = bm.texels;
+    if (!linear) return loadRgb(t + (size_t(iu0) + size_t(iv0)*w)*3);
+    V3 x00 = loadRgb(t + (size_t(iu0) + size_t(iv0)*w)*3), x01 = loadRgb(t + (size_t(iu1) + size_t(iv0)*w)*3);
+    V3 x10 = loadRgb(t + (size_t(iu0) + size_t(iv1)*w)*3), x11 = loadRgb(t + (size_t(iu1) + size_t(iv1)*w)*3);
+    V3 l = (x00*(1.0f - u) + x01*u)*(1.0f - v) + (x10*(1.0f - u) + x11*u)*v;
+    return bm.scale*l;
+}
+
+TG_DEV V3 texEval(const DScene &sc, int tex, float ux, float uy)
+{
+    const tgpu_texture &t = sc.textures[tex];
+    if (t.type == TGPU_TEX_CONSTANT) return V3(t.value);
+    if (t.type == TGPU_TEX_CHECKER) { // textures/CheckerTexture.cpp:64-69
+        int ui = int(ux*float(t.res_u)), vi = int(uy*float(t.res_v));
+        bool on = (ui ^ vi) & 1;
+        return on ? V3(t.on_color) : V3(t.off_color);
+    }
+    return bitmapEval(sc.bitmaps[t.bitmap], ux, uy);
+}
+
+// ---- environment light (primitives/InfiniteSphere.cpp) ---------------------------------------------
+TG_DEV void directionToUV(const DScene &sc, const V3 &wi, float &ux, float &uy, float *sinTheta) // :27-38
+{
+    V3 wLocal = mulPoint0(sc.env.inv_rot, wi);
+    if (sinTheta) *sinTheta = __builtin_sqrtf(fmax2(1.0f - wLocal.y*wLocal.y, 0.0f));
+    ux = tgpu_atan2f(wLocal.z, wLocal.x)*INV_TWO_PI + 0.5f;
+    uy = tgpu_acosf(-wLocal.y)*INV_PI;
+}
+
+TG_DEV V3 uvToDirection(const DScene &sc, float ux, float uy, float &sinTheta) // :40-50
+{
+    float phi = (ux - 0.5f)*TWO_PI;
+    float theta = uy*PI;
+    float sp, cp, st, ct;
+    tgpu_sincosf(phi, &sp, &cp);
+    tgpu_sincosf(theta, &st, &ct);
+    sinTheta = st;
+    return mulPoint0(sc.env.rot, V3(cp*sinTheta, -ct, sp*sinTheta));
+}
+
+TG_DEV float envPdf(const DScene &sc, float ux, float uy) // BitmapTexture.cpp:452-455, Distribution2D.hpp:66-71
+{
+    int w = sc.env.dist_w, h = sc.env.dist_h;
+    int row = int((1.0f - uy)*h), column = int(ux*w);
+    row = min(max(row, 0), h - 1);
+    column = min(max(column, 0), w - 1);
+    return sc.env.pdf[size_t(row)*w + column]*sc.env.marginal_pdf[row]*w*h;
+}
+
+// std::upper_bound(first, first + n, value) - first
+TG_DEV int upperBound(const float *a, int n, float value)
+{
+    int lo = 0, len = n;
+    while (len > 0) {
+        int half = len >> 1;
+        if (!(value < a[lo + half])) {
+            lo += half + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    return lo;
+}
+
+struct LightSample { V3 d; float dist, pdf; };
+
+TG_DEV bool envSampleDirect(const DScene &sc, Sampler &s, LightSample &out) // InfiniteSphere.cpp:161-176
+{
+    if (sc.envConstant) {
+        float xi0 = s.next1D(), xi1 = s.next1D();
+        float phi = xi0*TWO_PI; // SampleWarp::uniformSphere (sampling/SampleWarp.hpp:96-107)
+        float z = xi1*2.0f - 1.0f;
+        float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
+        float sp, cp;
+        tgpu_sincosf(phi, &sp, &cp);
+        out.d = V3(cp*r, sp*r, z);
+        out.dist = TG_INF;
+        out.pdf = INV_FOUR_PI;
+        return true;
+    }
+    float uvx = s.next1D(), uvy = s.next1D();
+    int w = sc.env.dist_w, h = sc.env.dist_h; // Distribution2D::warp (sampling/Distribution2D.hpp:66-76)
+    const float *mc = sc.env.marginal_cdf;
+    int row = upperBound(mc, h + 1, uvy) - 1;
+    uvy = clampf((uvy - mc[row])/sc.env.marginal_pdf[row], 0.0f, 1.0f);
+    const float *rs = sc.env.cdf + size_t(row)*(w + 1);
+    int column = upperBound(rs, w + 1, uvx) - 1;
+    uvx = clampf((uvx - rs[column])/sc.env.pdf[size_t(row)*w + column], 0.0f, 1.0f);
+    float ux = (uvx + column)/w; // BitmapTexture::sample (:433-439)
+    float uy = 1.0f - (uvy + row)/h;
+    float sinTheta;
+    out.d = uvToDirection(sc, ux, uy, sinTheta);
+    out.pdf = INV_PI*INV_TWO_PI*envPdf(sc, ux, uy)/sinTheta;
+    out.dist = TG_INF;
+    return out.pdf != 0.0f;
+}
+
+// ---- quads (primitives/Quad.cpp) ----------------------------------------------------------------
+struct QuadHit { float t, u, v; V3 p; bool backSide; };
+
+TG_DEV bool quadIntersect(const tgpu_quad &q, const V3 &pos, const V3 &dir, float nearT, float farT, QuadHit &h) // :71-98
+{
+    V3 normal(q.normal), base(q.base);
+    float nDotW = dir.dot(normal);
+    if (__builtin_fabsf(nDotW) < 1e-6f) return false;
+    float t = normal.dot(base - pos)/nDotW;
+    if (t < nearT || t > farT) return false;
+    V3 qp = pos + t*dir;
+    V3 v = qp - base;
+    float l0 = v.dot(V3(q.edge0))*q.inv_uv_sq[0];
+    float l1 = v.dot(V3(q.edge1))*q.inv_uv_sq[1];
+    if (l0 < 0.0f || l0 > 1.0f || l1 < 0.0f || l1 > 1.0f) return false;
+    h.t = t; h.u = l0; h.v = l1; h.p = qp; h.backSide = nDotW >= 0.0f;
+    return true;
+}
+
+TG_DEV bool quadSampleDirect(const tgpu_quad &q, const V3 &p, Sampler &s, LightSample &out) // :172-187
+{
+    V3 normal(q.normal), base(q.base);
+    if (normal.dot(p - base) <= 0.0f) return false;
+    float xi0 = s.next1D(), xi1 = s.next1D();
+    V3 qp = base + xi0*V3(q.edge0) + xi1*V3(q.edge1);
+    out.d = qp - p;
+    float rSq = out.d.lengthSq();
+    out.dist = __builtin_sqrtf(rSq);
+    out.d /= out.dist;
+    float cosTheta = -normal.dot(out.d);
+    out.pdf = rSq/(cosTheta*q.area);
+    return true;
+}
+
+// ---- cubes (primitives/Cube.cpp:94-127) ------------------------------------------------------------
+TG_DEV bool cubeIntersect(const tgpu_cube &cb, const V3 &pos, const V3 &dir, float nearT, float farT, float &tHit, bool &backSide)
+{
+    V3 p = mulPoint0(cb.inv_rot, pos - V3(cb.pos));
+    V3 d = mulPoint0(cb.inv_rot, dir);
+    float ttMin = nearT, ttMax = farT;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float di = d.comp(i), pi = p.comp(i), sc = cb.scale[i];
+        float invD = 1.0f/di;
+        float relMin = -sc - pi, relMax = sc - pi;
+        if (invD >= 0.0f) {
+            ttMin = fmax2(ttMin, relMin*invD);
+            ttMax = fmin2(ttMax, relMax*invD);
+        } else {
+            ttMax = fmin2(ttMax, relMin*invD);
+            ttMin = fmax2(ttMin, relMax*invD);
+        }
+    }
+    if (ttMin <= ttMax) {
+        if (ttMin > nearT && ttMin < farT) { tHit = ttMin; backSide = false; return true; }
+        if (ttMax > nearT && ttMax < farT) { tHit = ttMax; backSide = true; return true; }
+    }
+    return false;
+}
+
+// ---- tangent frame (math/TangentFrame.hpp:22-45) ---------------------------------------------------
+struct Frame {
+    V3 normal, tangent, bitangent;
+    TG_DEV V3 toLocal(const V3 &p) const { return V3(tangent.dot(p), bitangent.dot(p), normal.dot(p)); }
+    TG_DEV V3 toGlobal(const V3 &p) const { return tangent*p.x + bitangent*p.y + normal*p.z; }
+};
+TG_DEV Frame duffFrame(const V3 &n)
+{
+    Frame f;
+    f.normal = n;
+    float sign = __builtin_copysignf(1.0f, n.z);
+    const float a = -1.0f/(sign + n.z);
+    const float b = n.x*n.y*a;
+    f.tangent = V3(1.0f + sign*n.x*n.x*a, sign*b, -sign*n.x);
+    f.bitangent = V3(b, sign + n.y*n.y*a, -n.y);
+    return f;
+}
+
+// ---- BSDFs ---------------------------------------------------------------------------------------------
+struct Event { // samplerecords/SurfaceScatterEvent.hpp:14-66 (info fields folded in)
+    Frame frame;
+    V3 wi, wo, weight;
+    float pdf;
+    float uvx, uvy;
+    uint32_t requestedLobe, sampledLobe;
+    bool flippedFrame;
+};
+
+TG_DEV float roughnessToAlpha(float roughness) { return fmax2(roughness, 1e-3f); } // bsdfs/Microfacet.hpp:27-36
+
+// bsdfs/Microfacet.hpp:38-130 (Beckmann, GGX)
+TG_DEV float mfD(int dist, float alpha, const V3 &m)
+{
+    if (m.z <= 0.0f) return 0.0f;
+    float alphaSq = alpha*alpha;
+    float cosThetaSq = m.z*m.z;
+    float tanThetaSq = fmax2(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+    float cosThetaQu = cosThetaSq*cosThetaSq;
+    if (dist == TGPU_DIST_BECKMANN) return INV_PI*tgpu_expf(-tanThetaSq/alphaSq)/(alphaSq*cosThetaQu);
+    float s = alphaSq + tanThetaSq;
+    return alphaSq*INV_PI/(cosThetaQu*(s*s));
+}
+TG_DEV float mfG1(int dist, float alpha, const V3 &v, const V3 &m)
+{
+    if (v.dot(m)*v.z <= 0.0f) return 0.0f;
+    if (dist == TGPU_DIST_BECKMANN) {
+        float cosThetaSq = v.z*v.z;
+        float tanTheta = __builtin_fabsf(__builtin_sqrtf(fmax2(1.0f - cosThetaSq, 0.0f))/v.z);
+        float a = 1.0f/(alpha*tanTheta);
+        if (a < 1.6f)
+            return (3.535f*a + 2.181f*a*a)/(1.0f + 2.276f*a + 2.577f*a*a);
+        else
+            return 1.0f;
+    }
+    float alphaSq = alpha*alpha;
+    float cosThetaSq = v.z*v.z;
+    float tanThetaSq = fmax2(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+    return 2.0f/(1.0f + __builtin_sqrtf(1.0f + alphaSq*tanThetaSq));
+}
+TG_DEV float mfG(int dist, float alpha, const V3 &i, const V3 &o, const V3 &m) { return mfG1(dist, alpha, i, m)*mfG1(dist, alpha, o, m); }
+TG_DEV float mfPdf(int dist, float alpha, const V3 &m) { return mfD(dist, alpha, m)*m.z; }
+TG_DEV V3 mfSample(int dist, float alpha, float xix, float xiy)
+{
+    float phi = xiy*TWO_PI;
+    float cosTheta;
+    if (dist == TGPU_DIST_BECKMANN) {
+        float tanThetaSq = -alpha*alpha*tgpu_logf(1.0f - xix);
+        cosTheta = 1.0f/__builtin_sqrtf(1.0f + tanThetaSq);
+    } else {
+        float tanThetaSq = alpha*alpha*xix/(1.0f - xix);
+        cosTheta = 1.0f/__builtin_sqrtf(1.0f + tanThetaSq);
+    }
+    float r = __builtin_sqrtf(fmax2(1.0f - cosTheta*cosTheta, 0.0f));
+    float sp, cp;
+    tgpu_sincosf(phi, &sp, &cp);
+    return V3(cp*r, sp*r, cosTheta);
+}
+
+TG_DEV float conductorReflectance(float eta, float k, float cosThetaI) // bsdfs/Fresnel.hpp:102-125
+{
+    float cosThetaISq = cosThetaI*cosThetaI;
+    float sinThetaISq = fmax2(1.0f - cosThetaISq, 0.0f);
+    float sinThetaIQu = sinThetaISq*sinThetaISq;
+    float innerTerm = eta*eta - k*k - sinThetaISq;
+    float aSqPlusBSq = __builtin_sqrtf(fmax2(innerTerm*innerTerm + 4.0f*eta*eta*k*k, 0.0f));
+    float a = __builtin_sqrtf(fmax2((aSqPlusBSq + innerTerm)*0.5f, 0.0f));
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f*a*cosThetaI))/((aSqPlusBSq + cosThetaISq) + (2.0f*a*cosThetaI));
+    float Rp = ((cosThetaISq*aSqPlusBSq + sinThetaIQu) - (2.0f*a*cosThetaI*sinThetaISq))/
+               ((cosThetaISq*aSqPlusBSq + sinThetaIQu) + (2.0f*a*cosThetaI*sinThetaISq));
+    return 0.5f*(Rs + Rs*Rp);
+}
+TG_DEV V3 conductorReflectance3(const float *eta, const float *k, float c)
+{
+    return V3(conductorReflectance(eta[0], k[0], c), conductorReflectance(eta[1], k[1], c), conductorReflectance(eta[2], k[2], c));
+}
+TG_DEV float dielectricReflectance(float eta, float cosThetaI, float &cosThetaT) // bsdfs/Fresnel.hpp:75-92
+{
+    if (cosThetaI < 0.0f) {
+        eta = 1.0f/eta;
+        cosThetaI = -cosThetaI;
+    }
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    cosThetaT = __builtin_sqrtf(fmax2(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT);
+    float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
+    return (Rs*Rs + Rp*Rp)*0.5f;
+}
+TG_DEV bool checkReflectionConstraint(const V3 &wi, const V3 &wo) // bsdfs/Bsdf.hpp:44-47
+{
+    return __builtin_fabsf(wi.z*wo.z - wi.x*wo.x - wi.y*wo.y - 1.0f) < 1e-3f;
+}
+
+TG_DEV uint32_t baseLobes(int type)
+{
+    return type == TGPU_BSDF_LAMBERT ? uint32_t(DiffuseReflectionLobe) : (type == TGPU_BSDF_ROUGH_CONDUCTOR ? uint32_t(GlossyReflectionLobe) : 0u);
+}
+TG_DEV uint32_t bsdfLobes(const DScene &sc, const tgpu_bsdf &d)
+{
+    if (d.type == TGPU_BSDF_SMOOTH_COAT) return SpecularReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);
+    return baseLobes(d.type);
+}
+
+// Lambert (bsdfs/LambertBsdf.cpp:27-68) and RoughConductor (bsdfs/RoughConductorBsdf.cpp:60-143):
+// the two leaf BSDFs; SmoothCoat layers on top of one of them.
+TG_DEV V3 baseEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    if (d.type == TGPU_BSDF_LAMBERT) {
+        if (!(requested & DiffuseReflectionLobe)) return V3(0.0f);
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return V3(0.0f);
+        return texEval(sc, d.albedo_tex, uvx, uvy)*INV_PI*wo.z;
+    }
+    if (d.type == TGPU_BSDF_ROUGH_CONDUCTOR) {
+        if (!(requested & GlossyReflectionLobe)) return V3(0.0f);
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return V3(0.0f);
+        float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+        float alpha = roughnessToAlpha(roughness);
+        V3 hr = (wi + wo).normalized();
+        float cosThetaM = wi.dot(hr);
+        V3 F = conductorReflectance3(d.eta, d.k, cosThetaM);
+        float G = mfG(d.distribution, alpha, wi, wo, hr);
+        float D = mfD(d.distribution, alpha, hr);
+        float fr = (G*D*0.25f)/wi.z;
+        return texEval(sc, d.albedo_tex, uvx, uvy)*(F*fr);
+    }
+    return V3(0.0f);
+}
+
+TG_DEV float basePdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    if (d.type == TGPU_BSDF_LAMBERT) {
+        if (!(requested & DiffuseReflectionLobe)) return 0.0f;
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+        return __builtin_fabsf(wo.z)*INV_PI;
+    }
+    if (d.type == TGPU_BSDF_ROUGH_CONDUCTOR) {
+        if (!(requested & GlossyReflectionLobe)) return 0.0f;
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+        float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+        float sampleAlpha = roughnessToAlpha(roughness);
+        V3 hr = (wi + wo).normalized();
+        return mfPdf(d.distribution, sampleAlpha, hr)*0.25f/wi.dot(hr);
+    }
+    return 0.0f;
+}
+
+// samples with incident direction e.wi; fills e.wo, e.pdf, e.weight, e.sampledLobe
+TG_DEV bool baseSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{
+    if (d.type == TGPU_BSDF_LAMBERT) {
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return false;
+        if (e.wi.z <= 0.0f) return false;
+        float xix = s.next1D(), xiy = s.next1D();
+        float phi = xix*TWO_PI; // SampleWarp::cosineHemisphere (sampling/SampleWarp.hpp:42-52)
+        float r = __builtin_sqrtf(xiy);
+        float sp, cp;
+        tgpu_sincosf(phi, &sp, &cp);
+        e.wo = V3(cp*r, sp*r, __builtin_sqrtf(fmax2(1.0f - xiy, 0.0f)));
+        e.pdf = __builtin_fabsf(e.wo.z)*INV_PI;
+        e.weight = texEval(sc, d.albedo_tex, e.uvx, e.uvy);
+        e.sampledLobe = DiffuseReflectionLobe;
+        return true;
+    }
+    if (d.type == TGPU_BSDF_ROUGH_CONDUCTOR) {
+        if (!(e.requestedLobe & GlossyReflectionLobe)) return false;
+        if (e.wi.z <= 0.0f) return false;
+        float roughness = texEval(sc, d.roughness_tex, e.uvx, e.uvy).x;
+        float alpha = roughnessToAlpha(roughness);
+        float sampleAlpha = alpha;
+        float xix = s.next1D(), xiy = s.next1D();
+        V3 m = mfSample(d.distribution, sampleAlpha, xix, xiy);
+        float wiDotM = e.wi.dot(m);
+        e.wo = 2.0f*wiDotM*m - e.wi;
+        if (wiDotM <= 0.0f || e.wo.z <= 0.0f) return false;
+        float G = mfG(d.distribution, alpha, e.wi, e.wo, m);
+        float D = mfD(d.distribution, alpha, m);
+        float mPdf = mfPdf(d.distribution, sampleAlpha, m);
+        float pdf = mPdf*0.25f/wiDotM;
+        float weight = wiDotM*G*D/(e.wi.z*mPdf);
+        V3 F = conductorReflectance3(d.eta, d.k, wiDotM);
+        e.pdf = pdf;
+        e.weight = texEval(sc, d.albedo_tex, e.uvx, e.uvy)*(F*weight);
+        e.sampledLobe = GlossyReflectionLobe;
+        return true;
+    }
+    return false;
+}
+
+TG_DEV V3 expV3(const V3 &a) { return V3(tgpu_expf(a.x), tgpu_expf(a.y), tgpu_expf(a.z)); }
+
+TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
+{
+    if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    // bsdfs/SmoothCoatBsdf.cpp:146-178
+    if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+    const tgpu_bsdf &sub = sc.bsdfs[d.substrate];
+    bool evalR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+    bool evalT = (e.requestedLobe & baseLobes(sub.type)) != 0;
+    const V3 &wi = e.wi, &wo = e.wo;
+    float eta = 1.0f/d.ior;
+    float cosThetaTi, cosThetaTo;
+    float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+    float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+    if (evalR && checkReflectionConstraint(wi, wo)) {
+        return V3(Fi);
+    } else if (evalT) {
+        V3 wiSubstrate(wi.x*eta, wi.y*eta, __builtin_copysignf(cosThetaTi, wi.z));
+        V3 woSubstrate(wo.x*eta, wo.y*eta, __builtin_copysignf(cosThetaTo, wo.z));
+        float laplacian = eta*eta*wo.z/cosThetaTo;
+        V3 substrateF = baseEval(sc, sub, wiSubstrate, woSubstrate, e.requestedLobe, e.uvx, e.uvy);
+        V3 ss(d.scaled_sigma_a);
+        if (ss.max() > 0.0f) substrateF *= expV3(ss*(-1.0f/cosThetaTo - 1.0f/cosThetaTi));
+        return laplacian*(1.0f - Fi)*(1.0f - Fo)*substrateF;
+    }
+    return V3(0.0f);
+}
+
+TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
+{
+    if (d.type != TGPU_BSDF_SMOOTH_COAT) return basePdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    // bsdfs/SmoothCoatBsdf.cpp:180-215
+    if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+    const tgpu_bsdf &sub = sc.bsdfs[d.substrate];
+    bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+    bool sampleT = (e.requestedLobe & baseLobes(sub.type)) != 0;
+    const V3 &wi = e.wi, &wo = e.wo;
+    float eta = 1.0f/d.ior;
+    float cosThetaTi, cosThetaTo;
+    float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+    dielectricReflectance(eta, wo.z, cosThetaTo);
+    V3 wiSubstrate(wi.x*eta, wi.y*eta, __builtin_copysignf(cosThetaTi, wi.z));
+    V3 woSubstrate(wo.x*eta, wo.y*eta, __builtin_copysignf(cosThetaTo, wo.z));
+    if (sampleR && sampleT) {
+        float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability = specularWeight/(specularWeight + substrateWeight);
+        if (checkReflectionConstraint(wi, wo))
+            return specularProbability;
+        else
+            return basePdf(sc, sub, wiSubstrate, woSubstrate, e.requestedLobe, e.uvx, e.uvy)*(1.0f - specularProbability)*eta*eta*__builtin_fabsf(wo.z/cosThetaTo);
+    } else if (sampleT) {
+        return basePdf(sc, sub, wiSubstrate, woSubstrate, e.requestedLobe, e.uvx, e.uvy)*eta*eta*__builtin_fabsf(wo.z/cosThetaTo);
+    } else if (sampleR) {
+        return checkReflectionConstraint(wi, wo) ? 1.0f : 0.0f;
+    }
+    return 0.0f;
+}
+
+TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{
+    if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseSample(sc, d, e, s);
+    // bsdfs/SmoothCoatBsdf.cpp:41-100
+    if (e.wi.z <= 0.0f) return false;
+    const tgpu_bsdf &sub = sc.bsdfs[d.substrate];
+    bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+    bool sampleT = (e.requestedLobe & baseLobes(sub.type)) != 0;
+    if (!sampleR && !sampleT) return false;
+    const V3 wi = e.wi;
+    float eta = 1.0f/d.ior;
+    float cosThetaTi;
+    float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+    float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+    float specularWeight = Fi;
+    float specularProbability;
+    if (sampleR && sampleT)
+        specularProbability = specularWeight/(specularWeight + substrateWeight);
+    else if (sampleR)
+        specularProbability = 1.0f;
+    else
+        specularProbability = 0.0f;
+    if (sampleR && s.nextBoolean(specularProbability)) {
+        e.wo = V3(-wi.x, -wi.y, wi.z);
+        e.pdf = specularProbability;
+        e.weight = V3(Fi/specularProbability);
+        e.sampledLobe = SpecularReflectionLobe;
+    } else {
+        e.wi = V3(wi.x*eta, wi.y*eta, cosThetaTi);
+        bool success = baseSample(sc, sub, e, s);
+        e.wi = wi;
+        if (!success) return false;
+        float cosThetaTo;
+        float Fo = dielectricReflectance(d.ior, e.wo.z, cosThetaTo);
+        if (Fo == 1.0f) return false;
+        float cosThetaSubstrate = e.wo.z;
+        e.wo = V3(e.wo.x*d.ior, e.wo.y*d.ior, cosThetaTo);
+        e.weight *= (1.0f - Fi)*(1.0f - Fo);
+        V3 ss(d.scaled_sigma_a);
+        if (ss.max() > 0.0f) e.weight *= expV3(ss*(-1.0f/cosThetaSubstrate - 1.0f/cosThetaTi));
+        e.weight /= 1.0f - specularProbability;
+        e.pdf *= 1.0f - specularProbability;
+        e.pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+    }
+    return true;
+}
+
+} // namespace tg

@@ -1,0 +1,607 @@
+// C ABI of the MI355X path-tracing core (include/tungsten_amd.h): context, scene upload,
+// wavefront pass driver, downloads.  Host code only orchestrates; all path work runs in the
+// kernels of kernels.h.  No CPU fallback exists: every entry point fails loudly without a GPU.
+#include "kernels.h"
+#include "bvh_build.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tg;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct tgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    bool uploaded = false;
+    std::atomic<bool> abortFlag{false};
+
+    DScene sc{};
+    DState st{};
+    std::vector<void *> allocs;     // scene allocations
+    std::vector<void *> stateAllocs;
+
+    uint32_t nPixels = 0;
+    uint64_t capacity = 0; // paths in flight
+    uint32_t *hostCounters = nullptr; // pinned
+    int numCUs = 256;
+    int maxGrid = 2048;
+    size_t ldsBytes = 0;
+
+    uint32_t profFlags = 0;
+    tgpu_stats stats{};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<tgpu_quad> hostQuads; // for host-side checks only
+};
+
+namespace {
+
+bool fail(tgpu_ctx *ctx, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    return false;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);       \
+            return TGPU_ERR_HIP;                                                                        \
+        }                                                                                               \
+    } while (0)
+
+template <typename T>
+int upload(tgpu_ctx *ctx, std::vector<void *> &pool, const T *src, size_t count, T **dst)
+{
+    *dst = nullptr;
+    if (count == 0) count = 1; // keep pointers valid
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, count*sizeof(T)));
+    pool.push_back(p);
+    if (src) HIP_TRY(ctx, hipMemcpy(p, src, count*sizeof(T), hipMemcpyHostToDevice));
+    else HIP_TRY(ctx, hipMemset(p, 0, count*sizeof(T)));
+    *dst = static_cast<T *>(p);
+    return TGPU_OK;
+}
+
+void freePool(std::vector<void *> &pool)
+{
+    for (void *p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+int gridFor(const tgpu_ctx *ctx, uint64_t items)
+{
+    uint64_t blocks = (items + 255)/256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > uint64_t(ctx->maxGrid)) blocks = uint64_t(ctx->maxGrid);
+    return int(blocks);
+}
+
+struct Timer {
+    tgpu_ctx *ctx;
+    double *acc;
+    bool on;
+    Timer(tgpu_ctx *c, double *a) : ctx(c), acc(a), on((c->profFlags & 2u) != 0)
+    {
+        if (on) (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    }
+    ~Timer()
+    {
+        if (on) {
+            (void)hipEventRecord(ctx->ev[1], ctx->stream);
+            (void)hipEventSynchronize(ctx->ev[1]);
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+            *acc += ms;
+        }
+    }
+};
+
+int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
+{
+    if (!s || s->abi_version != TGPU_ABI_VERSION) { fail(ctx, "scene description has ABI version %u, expected %u", s ? s->abi_version : 0u, TGPU_ABI_VERSION); return TGPU_ERR_INVALID; }
+    if (s->camera.res_x == 0 || s->camera.res_y == 0) { fail(ctx, "camera resolution is zero"); return TGPU_ERR_INVALID; }
+    if (s->n_tris && (!s->tri_pos || !s->tri_normal || !s->tri_uv || !s->tri_bsdf || !s->tri_smooth)) { fail(ctx, "triangle arrays missing"); return TGPU_ERR_INVALID; }
+    if (s->n_tris >= (1u << 29)) { fail(ctx, "too many triangles (%u)", s->n_tris); return TGPU_ERR_UNSUPPORTED; }
+    if (!s->sobol_matrices) { fail(ctx, "Sobol matrices missing"); return TGPU_ERR_INVALID; }
+    if (s->n_lights > TG_MAX_LIGHTS) { fail(ctx, "more than %d samplable lights are not supported", TG_MAX_LIGHTS); return TGPU_ERR_UNSUPPORTED; }
+    if (s->settings.max_bounces < 0 || s->settings.max_bounces > 0xFFFF) { fail(ctx, "max_bounces out of range"); return TGPU_ERR_INVALID; }
+    auto texOk = [&](int t) { return t >= 0 && uint32_t(t) < s->n_textures; };
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const tgpu_texture &t = s->textures[i];
+        if (t.type == TGPU_TEX_BITMAP && (t.bitmap < 0 || uint32_t(t.bitmap) >= s->n_bitmaps)) { fail(ctx, "texture %u references bitmap %d", i, t.bitmap); return TGPU_ERR_INVALID; }
+        if (t.type < 0 || t.type > TGPU_TEX_BITMAP) { fail(ctx, "texture %u has unknown type", i); return TGPU_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < s->n_bitmaps; ++i)
+        if (s->bitmaps[i].w <= 0 || s->bitmaps[i].h <= 0 || !s->bitmaps[i].texels) { fail(ctx, "bitmap %u is empty", i); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) {
+        const tgpu_bsdf &b = s->bsdfs[i];
+        if (b.type < 0 || b.type >= TGPU_BSDF_NUM_CLASSES) { fail(ctx, "bsdf %u has type %d outside the hot-path scope", i, b.type); return TGPU_ERR_UNSUPPORTED; }
+        if (!texOk(b.albedo_tex)) { fail(ctx, "bsdf %u: bad albedo texture", i); return TGPU_ERR_INVALID; }
+        if (b.type == TGPU_BSDF_ROUGH_CONDUCTOR && !texOk(b.roughness_tex)) { fail(ctx, "bsdf %u: bad roughness texture", i); return TGPU_ERR_INVALID; }
+        if (b.type == TGPU_BSDF_ROUGH_CONDUCTOR && b.distribution == TGPU_DIST_PHONG) { fail(ctx, "bsdf %u: phong microfacet distribution is outside the hot-path scope", i); return TGPU_ERR_UNSUPPORTED; }
+        if (b.type == TGPU_BSDF_SMOOTH_COAT) {
+            if (b.substrate < 0 || uint32_t(b.substrate) >= s->n_bsdfs) { fail(ctx, "bsdf %u: bad substrate", i); return TGPU_ERR_INVALID; }
+            int st = s->bsdfs[b.substrate].type;
+            if (st != TGPU_BSDF_LAMBERT && st != TGPU_BSDF_ROUGH_CONDUCTOR) { fail(ctx, "bsdf %u: smooth_coat substrate must be lambert or rough_conductor", i); return TGPU_ERR_UNSUPPORTED; }
+        }
+    }
+    auto bsdfOk = [&](int b) { return b >= 0 && uint32_t(b) < s->n_bsdfs; };
+    for (uint32_t i = 0; i < s->n_tris; ++i)
+        if (!bsdfOk(s->tri_bsdf[i])) { fail(ctx, "triangle %u references bsdf %d", i, s->tri_bsdf[i]); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_quads; ++i) {
+        if (!bsdfOk(s->quads[i].bsdf)) { fail(ctx, "quad %u references bsdf %d", i, s->quads[i].bsdf); return TGPU_ERR_INVALID; }
+        if (s->quads[i].emission_tex >= 0 && !texOk(s->quads[i].emission_tex)) { fail(ctx, "quad %u: bad emission texture", i); return TGPU_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < s->n_cubes; ++i) {
+        if (!bsdfOk(s->cubes[i].bsdf)) { fail(ctx, "cube %u references bsdf %d", i, s->cubes[i].bsdf); return TGPU_ERR_INVALID; }
+        if (s->cubes[i].emission_tex >= 0) { fail(ctx, "emissive cubes are outside the hot-path scope"); return TGPU_ERR_UNSUPPORTED; }
+    }
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const tgpu_light &l = s->lights[i];
+        if (l.kind == TGPU_LIGHT_ENV) {
+            if (!s->env.present) { fail(ctx, "light %u is the environment but env.present is 0", i); return TGPU_ERR_INVALID; }
+        } else if (l.kind == TGPU_LIGHT_QUAD) {
+            if (l.index < 0 || uint32_t(l.index) >= s->n_quads || s->quads[l.index].emission_tex < 0) { fail(ctx, "light %u: bad quad", i); return TGPU_ERR_INVALID; }
+        } else { fail(ctx, "light %u has unknown kind", i); return TGPU_ERR_INVALID; }
+    }
+    if (s->env.present) {
+        if (!texOk(s->env.emission_tex)) { fail(ctx, "environment: bad emission texture"); return TGPU_ERR_INVALID; }
+        const tgpu_texture &t = s->textures[s->env.emission_tex];
+        if (t.type == TGPU_TEX_CHECKER) { fail(ctx, "checker environment emission is outside the hot-path scope"); return TGPU_ERR_UNSUPPORTED; }
+        if (t.type == TGPU_TEX_BITMAP && s->env.samplable) {
+            if (!s->env.pdf || !s->env.cdf || !s->env.marginal_pdf || !s->env.marginal_cdf || s->env.dist_w <= 0 || s->env.dist_h <= 0) { fail(ctx, "environment: sampling tables missing"); return TGPU_ERR_INVALID; }
+        }
+    }
+    return TGPU_OK;
+}
+
+void resetDequeueHeads(tgpu_ctx *ctx)
+{
+    (void)hipMemsetAsync(ctx->st.counters, 0, CNT_TOTAL*sizeof(uint32_t), ctx->stream);
+}
+
+} // namespace
+
+extern "C" {
+
+int tgpu_init(int device, tgpu_ctx **out)
+{
+    if (!out) return TGPU_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TGPU_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TGPU_ERR_NO_DEVICE;
+    tgpu_ctx *ctx = new tgpu_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->numCUs = prop.multiProcessorCount;
+    ctx->maxGrid = ctx->numCUs*8;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev[0]) != hipSuccess ||
+        hipEventCreate(&ctx->ev[1]) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCounters), CNT_TOTAL*sizeof(uint32_t)) != hipSuccess) {
+        delete ctx;
+        return TGPU_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return TGPU_OK;
+}
+
+void tgpu_destroy(tgpu_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    freePool(ctx->allocs);
+    freePool(ctx->stateAllocs);
+    if (ctx->hostCounters) (void)hipHostFree(ctx->hostCounters);
+    if (ctx->ev[0]) (void)hipEventDestroy(ctx->ev[0]);
+    if (ctx->ev[1]) (void)hipEventDestroy(ctx->ev[1]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *tgpu_last_error(const tgpu_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_desc *shard, uint64_t maxPaths)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = validate(ctx, s);
+    if (rc != TGPU_OK) return rc;
+    if (!shard || shard->n_pixels == 0 || !shard->pixel_index || !shard->tile_seed) { fail(ctx, "empty shard"); return TGPU_ERR_INVALID; }
+    const uint32_t nImagePixels = s->camera.res_x*s->camera.res_y;
+    for (uint32_t i = 0; i < shard->n_pixels; ++i)
+        if (shard->pixel_index[i] >= nImagePixels) { fail(ctx, "shard pixel %u out of range", i); return TGPU_ERR_INVALID; }
+
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    freePool(ctx->allocs);
+    freePool(ctx->stateAllocs);
+    ctx->uploaded = false;
+    ctx->sc = DScene{};
+    ctx->st = DState{};
+    DScene &sc = ctx->sc;
+    sc.cam = s->camera;
+    sc.settings = s->settings;
+
+    // ---- BVH ----
+    tgpu_bvh::Builder builder(s->tri_pos, s->n_tris);
+    tgpu_bvh::Bvh bvh = builder.build();
+    sc.nTris = s->n_tris;
+    sc.rootChild = bvh.rootChild;
+    sc.stackEntries = bvh.maxDepth + 2;
+    float4 *dNodes, *dTris;
+    uint32_t *dTriId;
+    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh.nodes.data()), bvh.nodes.size(), &dNodes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh.tris.data()), bvh.tris.size(), &dTris))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, bvh.triId.data(), bvh.triId.size(), &dTriId))) return rc;
+    sc.nodes = dNodes;
+    sc.tris = dTris;
+    sc.triId = dTriId;
+    ctx->ldsBytes = size_t(sc.stackEntries)*256*sizeof(uint32_t);
+    if (ctx->ldsBytes > 160*1024) { fail(ctx, "BVH depth %d needs more LDS than a CU has", bvh.maxDepth); return TGPU_ERR_UNSUPPORTED; }
+
+    // ---- shading records ----
+    std::vector<tgpu_bvh::Float4> shade(size_t(s->n_tris)*5);
+    std::vector<uint8_t> triClass(s->n_tris);
+    for (uint32_t i = 0; i < s->n_tris; ++i) {
+        const float *n = s->tri_normal + size_t(i)*9, *uv = s->tri_uv + size_t(i)*6, *p = s->tri_pos + size_t(i)*9;
+        uint32_t bits = uint32_t(s->tri_bsdf[i]) | (s->tri_smooth[i] ? 0x80000000u : 0u);
+        float fb;
+        std::memcpy(&fb, &bits, 4);
+        // unnormalizedGeometricNormalAt: (p1 - p0) x (p2 - p0)  (TriangleMesh.cpp:81-88)
+        float a[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, b[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+        float ng[3] = {a[1]*b[2] - a[2]*b[1], a[2]*b[0] - a[0]*b[2], a[0]*b[1] - a[1]*b[0]};
+        tgpu_bvh::Float4 *q = &shade[size_t(i)*5];
+        q[0] = {n[0], n[1], n[2], n[3]};
+        q[1] = {n[4], n[5], n[6], n[7]};
+        q[2] = {n[8], uv[0], uv[1], uv[2]};
+        q[3] = {uv[3], uv[4], uv[5], fb};
+        q[4] = {ng[0], ng[1], ng[2], 0.0f};
+        triClass[i] = uint8_t(s->bsdfs[s->tri_bsdf[i]].type);
+    }
+    float4 *dShade;
+    uint8_t *dClass;
+    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(shade.data()), shade.size(), &dShade))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, triClass.data(), triClass.size(), &dClass))) return rc;
+    sc.triShade = dShade;
+    sc.triClass = dClass;
+
+    // ---- analytic primitives, materials, textures ----
+    tgpu_quad *dQuads; tgpu_cube *dCubes; tgpu_bsdf *dBsdfs; tgpu_texture *dTex; tgpu_light *dLights;
+    if ((rc = upload(ctx, ctx->allocs, s->quads, s->n_quads, &dQuads))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, s->cubes, s->n_cubes, &dCubes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, s->bsdfs, s->n_bsdfs, &dBsdfs))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, s->textures, s->n_textures, &dTex))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, s->lights, s->n_lights, &dLights))) return rc;
+    sc.quads = dQuads; sc.nQuads = s->n_quads;
+    sc.cubes = dCubes; sc.nCubes = s->n_cubes;
+    sc.bsdfs = dBsdfs;
+    sc.textures = dTex;
+    sc.lights = dLights; sc.nLights = s->n_lights;
+    std::vector<DBitmap> bitmaps(s->n_bitmaps);
+    for (uint32_t i = 0; i < s->n_bitmaps; ++i) {
+        const tgpu_bitmap &b = s->bitmaps[i];
+        float *dTexels;
+        if ((rc = upload(ctx, ctx->allocs, b.texels, size_t(b.w)*b.h*3, &dTexels))) return rc;
+        bitmaps[i] = DBitmap{b.w, b.h, b.clamp, b.linear, b.scale, dTexels};
+    }
+    DBitmap *dBitmaps;
+    if ((rc = upload(ctx, ctx->allocs, bitmaps.data(), bitmaps.size(), &dBitmaps))) return rc;
+    sc.bitmaps = dBitmaps;
+
+    // ---- environment ----
+    sc.env = s->env;
+    sc.env.pdf = sc.env.cdf = sc.env.marginal_pdf = sc.env.marginal_cdf = nullptr;
+    sc.envConstant = 1;
+    if (s->env.present) {
+        sc.envConstant = s->textures[s->env.emission_tex].type == TGPU_TEX_CONSTANT;
+        if (!sc.envConstant && s->env.samplable) {
+            size_t w = size_t(s->env.dist_w), h = size_t(s->env.dist_h);
+            float *a, *b, *c, *d;
+            if ((rc = upload(ctx, ctx->allocs, s->env.pdf, w*h, &a))) return rc;
+            if ((rc = upload(ctx, ctx->allocs, s->env.cdf, (w + 1)*h, &b))) return rc;
+            if ((rc = upload(ctx, ctx->allocs, s->env.marginal_pdf, h, &c))) return rc;
+            if ((rc = upload(ctx, ctx->allocs, s->env.marginal_cdf, h + 1, &d))) return rc;
+            sc.env.pdf = a; sc.env.cdf = b; sc.env.marginal_pdf = c; sc.env.marginal_cdf = d;
+        }
+    }
+    uint32_t *dSobol;
+    if ((rc = upload(ctx, ctx->allocs, s->sobol_matrices, size_t(1024)*32, &dSobol))) return rc;
+    sc.sobol = dSobol;
+
+    // ---- shard + framebuffer ----
+    DState &st = ctx->st;
+    ctx->nPixels = shard->n_pixels;
+    std::vector<uint32_t> scramble(shard->n_pixels);
+    auto h32 = [](uint32_t x) { x = ~x + (x << 15); x = x ^ (x >> 12); x = x + (x << 2); x = x ^ (x >> 4); x = x*2057; x = x ^ (x >> 16); return x; };
+    for (uint32_t i = 0; i < shard->n_pixels; ++i) scramble[i] = shard->tile_seed[i] ^ h32(shard->pixel_index[i]); // SobolPathSampler.hpp:47-52
+    uint32_t *dPix, *dScr, *dCnt;
+    float *dMean;
+    if ((rc = upload(ctx, ctx->stateAllocs, shard->pixel_index, shard->n_pixels, &dPix))) return rc;
+    if ((rc = upload(ctx, ctx->stateAllocs, scramble.data(), scramble.size(), &dScr))) return rc;
+    if ((rc = upload<float>(ctx, ctx->stateAllocs, nullptr, size_t(shard->n_pixels)*3, &dMean))) return rc;
+    if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, shard->n_pixels, &dCnt))) return rc;
+    st.pixelIndex = dPix; st.scramble = dScr; st.fbMean = dMean; st.fbCount = dCnt;
+
+    // ---- wavefront state ----
+    uint64_t cap = maxPaths ? maxPaths : std::min<uint64_t>(uint64_t(shard->n_pixels)*16, 16ull << 20);
+    if (cap < 64) cap = 64;
+    ctx->capacity = cap;
+    float4 **f4[] = {&st.rayO, &st.rayD, &st.hit, &st.tp, &st.em, &st.shA, &st.shB, &st.shC, &st.shD, &st.shE, &st.shF};
+    for (float4 **pp : f4)
+        if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
+    if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
+    uint32_t **qs[] = {&st.extQ[0], &st.extQ[1], &st.missQ, &st.shadowQ};
+    for (uint32_t **pp : qs)
+        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
+    for (int c = 0; c < TGPU_BSDF_NUM_CLASSES; ++c)
+        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.classQ[c]))) return rc;
+    if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL, &st.counters))) return rc;
+    if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8, &st.stats))) return rc;
+
+    ctx->stats = tgpu_stats{};
+    ctx->uploaded = true;
+    ctx->abortFlag = false;
+    return TGPU_OK;
+}
+
+// One wavefront batch: pixels [pixBegin, pixBegin+pixCount) x samples [sppBegin, sppBegin+sppCount)
+static int renderBatch(tgpu_ctx *ctx, hipStream_t stream, uint32_t pixBegin, uint32_t pixCount, uint32_t sppBegin, uint32_t sppCount)
+{
+    DScene &sc = ctx->sc;
+    DState &st = ctx->st;
+    const uint32_t total = pixCount*sppCount;
+    const bool count = (ctx->profFlags & 1u) != 0;
+    hipStream_t saved = ctx->stream;
+    ctx->stream = stream;
+    {
+        Timer t(ctx, &ctx->stats.other_ms);
+        hipLaunchKernelGGL(k_generate, dim3(gridFor(ctx, total)), dim3(256), 0, stream, sc, st, pixBegin, pixCount, sppBegin, sppCount);
+    }
+    uint32_t nCur = total;
+    const uint32_t *queue = nullptr;
+    int cur = 0;
+    int rc = TGPU_OK;
+    for (int iter = 0; nCur > 0; ++iter) {
+        if (ctx->abortFlag.load()) { rc = TGPU_ERR_ABORTED; break; }
+        (void)hipMemsetAsync(st.counters, 0, CNT_TOTAL*sizeof(uint32_t), stream);
+        int grid = gridFor(ctx, nCur);
+        {
+            Timer t(ctx, &ctx->stats.extend_ms);
+            if (count) hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, queue, nCur);
+            else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, queue, nCur);
+        }
+        ctx->stats.extend_rays += nCur;
+        ctx->stats.extend_launches++;
+        uint32_t *next = st.extQ[cur ^ 1];
+        {
+            Timer t(ctx, &ctx->stats.shade_ms);
+            hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st);
+            hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(256), 0, stream, sc, st, next);
+            hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(256), 0, stream, sc, st, next);
+            hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(256), 0, stream, sc, st, next);
+            hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(256), 0, stream, sc, st, next);
+        }
+        {
+            Timer t(ctx, &ctx->stats.shadow_ms);
+            if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st);
+        }
+        ctx->stats.shadow_launches++;
+        hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {
+            fail(ctx, "wavefront iteration %d failed: %s", iter, hipGetErrorString(e));
+            rc = TGPU_ERR_HIP;
+            break;
+        }
+        nCur = ctx->hostCounters[CNT_EXT_NEXT];
+        if (nCur > total) { fail(ctx, "internal error: queue overflow (%u > %u)", nCur, total); rc = TGPU_ERR_HIP; break; }
+        queue = next;
+        cur ^= 1;
+    }
+    if (rc == TGPU_OK) {
+        Timer t(ctx, &ctx->stats.other_ms);
+        hipLaunchKernelGGL(k_accumulate, dim3(gridFor(ctx, pixCount)), dim3(256), 0, stream, sc, st, pixBegin, pixCount, sppCount);
+        ctx->stats.samples += total;
+    }
+    ctx->stream = saved;
+    return rc;
+}
+
+int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *streamPtr)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "tgpu_render_pass before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    if (sppCount == 0) return TGPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = streamPtr ? static_cast<hipStream_t>(streamPtr) : ctx->stream;
+    if (uint64_t(sppCount) > ctx->capacity) { fail(ctx, "spp_count %u exceeds the paths-in-flight capacity %llu", sppCount, (unsigned long long)ctx->capacity); return TGPU_ERR_INVALID; }
+    ctx->abortFlag = false;
+    uint32_t pixPerBatch = uint32_t(std::min<uint64_t>(ctx->capacity/sppCount, ctx->nPixels));
+    for (uint32_t p = 0; p < ctx->nPixels; p += pixPerBatch) {
+        uint32_t n = std::min(pixPerBatch, ctx->nPixels - p);
+        int rc = renderBatch(ctx, stream, p, n, sppBegin, sppCount);
+        if (rc != TGPU_OK) return rc;
+    }
+    return TGPU_OK;
+}
+
+int tgpu_wait(tgpu_ctx *ctx)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGPU_OK;
+}
+
+int tgpu_abort(tgpu_ctx *ctx)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    ctx->abortFlag = true;
+    return TGPU_OK;
+}
+
+int tgpu_download(tgpu_ctx *ctx, float *rgb, uint32_t *cnt)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "tgpu_download before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (rgb) HIP_TRY(ctx, hipMemcpy(rgb, ctx->st.fbMean, size_t(ctx->nPixels)*3*sizeof(float), hipMemcpyDeviceToHost));
+    if (cnt) HIP_TRY(ctx, hipMemcpy(cnt, ctx->st.fbCount, size_t(ctx->nPixels)*sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TGPU_OK;
+}
+
+int tgpu_resolve_to_device(tgpu_ctx *ctx, void *deviceRgb, void *streamPtr)
+{
+    if (!ctx || !deviceRgb) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "tgpu_resolve_to_device before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = streamPtr ? static_cast<hipStream_t>(streamPtr) : ctx->stream;
+    if (stream != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(deviceRgb, ctx->st.fbMean, size_t(ctx->nPixels)*3*sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return TGPU_OK;
+}
+
+int tgpu_upload_framebuffer(tgpu_ctx *ctx, const float *rgb, const uint32_t *cnt)
+{
+    if (!ctx || !rgb || !cnt) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "tgpu_upload_framebuffer before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->st.fbMean, rgb, size_t(ctx->nPixels)*3*sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->st.fbCount, cnt, size_t(ctx->nPixels)*sizeof(uint32_t), hipMemcpyHostToDevice));
+    return TGPU_OK;
+}
+
+static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, uint8_t *occ)
+{
+    if (!ctx || !rays || (!hits && !occ)) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "ray query before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DState &st = ctx->st;
+    std::vector<float> o, d;
+    uint8_t *dOcc = nullptr;
+    if (occ) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dOcc), size_t(std::min<uint64_t>(n, ctx->capacity)) + 1));
+    int rc = TGPU_OK;
+    for (uint64_t base = 0; base < n && rc == TGPU_OK; base += ctx->capacity) {
+        uint32_t m = uint32_t(std::min<uint64_t>(ctx->capacity, n - base));
+        o.resize(size_t(m)*4);
+        d.resize(size_t(m)*4);
+        for (uint32_t i = 0; i < m; ++i) {
+            const float *r = rays + (base + i)*8;
+            o[size_t(i)*4 + 0] = r[0]; o[size_t(i)*4 + 1] = r[1]; o[size_t(i)*4 + 2] = r[2]; o[size_t(i)*4 + 3] = r[3];
+            d[size_t(i)*4 + 0] = r[4]; d[size_t(i)*4 + 1] = r[5]; d[size_t(i)*4 + 2] = r[6]; d[size_t(i)*4 + 3] = r[7];
+        }
+        hipError_t e = hipMemcpyAsync(st.rayO, o.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(st.rayD, d.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(st.counters, 0, CNT_TOTAL*sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) {
+            if (hits) {
+                hipLaunchKernelGGL((k_extend<false, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, (const uint32_t *)nullptr, m);
+                e = hipMemcpyAsync(hits + base*4, st.hit, size_t(m)*16, hipMemcpyDeviceToHost, ctx->stream);
+            } else {
+                hipLaunchKernelGGL(k_occluded_raw, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
+                e = hipMemcpyAsync(occ + base, dOcc, m, hipMemcpyDeviceToHost, ctx->stream);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { fail(ctx, "ray query failed: %s", hipGetErrorString(e)); rc = TGPU_ERR_HIP; }
+    }
+    if (dOcc) (void)hipFree(dOcc);
+    if (rc == TGPU_OK && hits) {
+        // a miss reports the ray's own tfar
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t prim;
+            std::memcpy(&prim, &hits[size_t(i)*4 + 3], 4);
+            if (prim == 0xFFFFFFFFu) hits[size_t(i)*4] = rays[size_t(i)*8 + 7];
+        }
+    }
+    return rc;
+}
+
+int tgpu_trace_closest(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits) { return traceRaw(ctx, rays, n, hits, nullptr); }
+int tgpu_trace_occluded(tgpu_ctx *ctx, const float *rays, uint32_t n, uint8_t *occ) { return traceRaw(ctx, rays, n, nullptr, occ); }
+
+int tgpu_set_profiling(tgpu_ctx *ctx, uint32_t flags)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    ctx->profFlags = flags;
+    return TGPU_OK;
+}
+
+int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out)
+{
+    if (!ctx || !out) return TGPU_ERR_INVALID;
+    if (ctx->uploaded) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long d[8];
+        HIP_TRY(ctx, hipMemcpy(d, ctx->st.stats, sizeof(d), hipMemcpyDeviceToHost));
+        ctx->stats.extend_node_visits = d[0];
+        ctx->stats.extend_tri_tests = d[1];
+        ctx->stats.shadow_node_visits = d[2];
+        ctx->stats.shadow_tri_tests = d[3];
+        ctx->stats.shadow_rays = d[4];
+        ctx->stats.surface_events = d[5];
+    }
+    *out = ctx->stats;
+    return TGPU_OK;
+}
+
+int tgpu_reset_stats(tgpu_ctx *ctx)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    ctx->stats = tgpu_stats{};
+    if (ctx->uploaded) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemset(ctx->st.stats, 0, 8*sizeof(unsigned long long)));
+    }
+    return TGPU_OK;
+}
+
+int tgpu_eval_math(tgpu_ctx *ctx, int kind, const float *a, const float *b, uint32_t n, float *out)
+{
+    if (!ctx || !a || !b || !out) return TGPU_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    size_t bytes = size_t(n ? n : 1)*sizeof(float);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&da), bytes));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&db), bytes));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dout), bytes));
+    hipError_t e = hipMemcpy(da, a, size_t(n)*4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, b, size_t(n)*4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_eval_math, dim3(gridFor(ctx, n)), dim3(256), 0, ctx->stream, kind, da, db, n, dout);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, size_t(n)*4, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    if (e != hipSuccess) { fail(ctx, "tgpu_eval_math: %s", hipGetErrorString(e)); return TGPU_ERR_HIP; }
+    return TGPU_OK;
+}
+
+} // extern "C"

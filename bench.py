@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the MI355X wavefront path tracer on BASELINE.json's headline config.
+
+Workload (config.workload): configs[1] = materialtest 1280x720, Lambert + RoughConductor, Sobol,
+adaptive sampling off, spp_step 16.  One "step" = one pass of the hot path (16 spp over the whole
+image); the default K = 16 steps is the 256-spp render the metric's wall-clock is quoted on.
+
+    python bench.py --gpus 1 --steps 16 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: 16x16 image tiles are dealt round-robin to ranks (weak scaling is NOT what happens
+here: total work is fixed -> "scaling": "strong"); each rank renders its shard with no data-path
+collective and one RCCL gather of the framebuffers to rank 0 closes the timed region.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = k_extend (closest-hit BVH traversal), HBM bound.  achieved =
+               algorithmic bytes per launch / average launch duration, both measured live after
+               the timed region: bytes from the kernel's own visit counters (64 B per BVH node
+               fetch, 48 B per triangle fetch, 56 B of queue traffic per ray), duration from HIP
+               events recorded on the stream the kernel runs on.
+  cpu_baseline the CPU oracle (oracle/, a port -- test infrastructure) timed on this box's host
+               cores on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+SCENE = os.path.join(REPO, "assets", "materialtest", "c2.json")
+NODE_BYTES, TRI_BYTES, RAY_QUEUE_BYTES = 64, 48, 56  # DESIGN.md "algorithmic bytes"
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-step", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--save-image", default=None, help="write the gathered image as PFM (rank 0)")
+    args = ap.parse_args()
+
+    import torch  # device memory, streams and torch.distributed: plumbing only
+    import numpy as np
+    import tungsten_amd as ta
+    from tungsten_amd.dist import gather_framebuffer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    scene = ta.HostScene(SCENE)
+    shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank, world)
+    ctx = ta.Context(local_rank)
+    ctx.upload(scene, shard)
+    out = torch.zeros((shard.n_pixels, 3), dtype=torch.float32, device=device)
+    spp_step = args.spp_step
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    done = 0
+    for _ in range(args.warmup):
+        ctx.render_pass(done, spp_step)
+        done += spp_step
+    ctx.wait()
+    if dist is not None:  # warm the communicator outside the timed region
+        gather_framebuffer(out, shard, world, rank, dist)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render_pass(done, spp_step)
+        done += spp_step
+    ctx.wait()
+    ctx.resolve_to_device(out.data_ptr())
+    ctx.wait()
+    image = gather_framebuffer(out, shard, world, rank, dist)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples = scene.res_x*scene.res_y*spp_step*args.steps
+    value = samples/elapsed/1e6
+    result = {
+        "metric": "Msamples/sec (whole node), materialtest 1280x720",
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed/args.steps*1e3, 3),
+        "wall_clock_s": round(elapsed, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic camera paths on the vendored materialtest scene (assets/materialtest/c2.json)",
+        "config": {"workload": "materialtest 1280x720, Lambert+RoughConductor only, 1xMI355X wavefront (BASELINE configs[1])",
+                   "spp": spp_step*args.steps, "spp_step": spp_step, "sampler": "sobol", "adaptive": False,
+                   "max_bounces": scene.max_bounces, "parallelism": f"tile-shard x{world}"},
+    }
+
+    if rank == 0 and args.save_image and image is not None:
+        ta.save_pfm(args.save_image, image)
+
+    # ---- roofline of the dominant kernel (rank 0's shard) -------------------------------------
+    if not args.no_roofline and rank == 0:
+        ctx.set_profiling(1)  # visit counters (k_extend<true,..>)
+        ctx.reset_stats()
+        ctx.render_pass(done, spp_step)
+        ctx.wait()
+        c = ctx.stats()
+        ctx.set_profiling(2)  # HIP-event timing of the production kernels
+        ctx.reset_stats()
+        for i in range(2):
+            ctx.render_pass(done + spp_step*(1 + i), spp_step)
+        ctx.wait()
+        t = ctx.stats()
+        ctx.set_profiling(0)
+        launches = max(1, c["extend_launches"])
+        bytes_per_launch = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES +
+                            c["extend_rays"]*RAY_QUEUE_BYTES)/launches
+        avg_ms = t["extend_ms"]/max(1, t["extend_launches"])
+        achieved = bytes_per_launch/(avg_ms*1e-3)/1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(REPO, "profiles", "pmc_extend.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "avg_launch_ms": round(avg_ms, 5),
+            "launches_per_step": launches,
+            "per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
+                        "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)},
+            "per_sample": {"extend_rays": round(c["extend_rays"]/max(1, c["samples"]), 3),
+                           "shadow_rays": round(c["shadow_rays"]/max(1, c["samples"]), 3),
+                           "surface_events": round(c["surface_events"]/max(1, c["samples"]), 3)},
+            "kernel_ms_per_step": {k: round(t[k]/2, 3) for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms")},
+        }
+
+    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) ----------------------
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle.oracle_py import Oracle
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        orc = Oracle(scene, rng=1, math=1, rcp=0)
+        full = ta.Shard(scene.res_x, scene.res_y)
+        tc = time.perf_counter()
+        orc.render_shard(full, spp_step, spp_step=spp_step, threads=cores)
+        dt = time.perf_counter() - tc
+        n = scene.res_x*scene.res_y*spp_step
+        result["cpu_baseline"] = {"value": round(n/dt/1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                  "sample": f"1 step (16 spp) of the same 1280x720 workload = {n} samples in {dt:.1f} s"}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

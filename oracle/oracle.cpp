@@ -1641,3 +1641,91 @@ void oracle_reset_stats(oracle_ctx *ctx)
 }
 
 } // extern "C"
+
+// ---- leaf functions for the known-answer tests (tests/test_oracle_kat.py) ----------------------------
+extern "C" {
+
+static oracle_ctx *leafCtx(int math_mode)
+{
+    static oracle_ctx c0, c1;
+    oracle_ctx *c = math_mode ? &c1 : &c0;
+    c->mathMode = math_mode;
+    return c;
+}
+
+float oracle_normalized_uint(uint32_t i) { return normalizedUint(i); }
+
+void oracle_cosine_hemisphere(int math_mode, float xix, float xiy, float *out3)
+{   // sampling/SampleWarp.hpp:42-52
+    const oracle_ctx *o = leafCtx(math_mode);
+    float phi = xix*TWO_PI;
+    float r = std::sqrt(xiy);
+    out3[0] = o->mcos(phi)*r;
+    out3[1] = o->msin(phi)*r;
+    out3[2] = std::sqrt(fmax2(1.0f - xiy, 0.0f));
+}
+
+// out: m.xyz, D(m), pdf(m), G1(v, m)
+void oracle_microfacet(int math_mode, int dist, float alpha, float xix, float xiy, const float *v3, float *out6)
+{
+    MF mf{leafCtx(math_mode), dist};
+    V3 m = mf.sample(alpha, xix, xiy);
+    out6[0] = m.x; out6[1] = m.y; out6[2] = m.z;
+    out6[3] = mf.D(alpha, m);
+    out6[4] = mf.pdf(alpha, m);
+    out6[5] = mf.G1(alpha, V3(v3), m);
+}
+
+void oracle_conductor_reflectance(const float *eta3, const float *k3, float cosThetaI, float *out3)
+{
+    V3 f = conductorReflectance3(eta3, k3, cosThetaI);
+    out3[0] = f.x; out3[1] = f.y; out3[2] = f.z;
+}
+
+void oracle_dielectric_reflectance(float eta, float cosThetaI, float *out2)
+{
+    float ct;
+    out2[0] = dielectricReflectance(eta, cosThetaI, ct);
+    out2[1] = ct;
+}
+
+void oracle_tangent_frame(const float *n3, float *out6)
+{
+    Frame f = duffFrame(V3(n3));
+    out6[0] = f.tangent.x; out6[1] = f.tangent.y; out6[2] = f.tangent.z;
+    out6[3] = f.bitangent.x; out6[4] = f.bitangent.y; out6[5] = f.bitangent.z;
+}
+
+// include/tgpu_math.h evaluated on the host: kind as tgpu_eval_math
+void oracle_eval_math(int kind, const float *a, const float *b, uint32_t n, float *out)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        float x = a[i], y = b[i], r;
+        switch (kind) {
+        case 0: r = tgpu_sinf(x); break;
+        case 1: r = tgpu_cosf(x); break;
+        case 2: r = tgpu_expf(x); break;
+        case 3: r = tgpu_logf(x); break;
+        case 4: r = tgpu_atan2f(x, y); break;
+        case 5: r = tgpu_acosf(x); break;
+        case 6: r = x/y; break;
+        case 7: r = std::sqrt(x); break;
+        default: r = 0.0f; break;
+        }
+        out[i] = r;
+    }
+}
+
+// Embree's rcp() on this CPU (RCPPS is implementation defined): lets a test decide whether the
+// bit-exact reference fixtures (generated on an Intel Xeon) apply to this host.
+float oracle_embree_rcp(float a)
+{
+#if defined(__SSE__)
+    float r = _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(a)));
+    return r*(2.0f - r*a);
+#else
+    return 1.0f/a;
+#endif
+}
+
+} // extern "C"

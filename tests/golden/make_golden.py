@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Regenerates the golden PFMs in this directory by running the COMPILED, UNMODIFIED REFERENCE.
+
+Provenance (recorded in DESIGN.md "Oracle"): the renderer binary used here is the survey-phase
+build of /root/reference (SURVEY.md section 8c recipe: cmake + ninja in /tmp, Embree 2.11 vendored,
+g++ 11.4 -O3, no FMA) that was left at /tmp/tungsten-build/tungsten.  This repository does not and
+cannot rebuild it (its Embree needs cmake-generated headers); the fixtures are data: float
+framebuffers written by the reference's own ImageIO::saveHdr (.pfm).
+
+Each fixture = (scene under assets/, resolution, spp).  Scenes are written next to the assets with
+the resolution/spp/output names patched in, rendered with `tungsten -t 8`, and removed again.
+The default seed 0xBA5EBA11 applies (Shared.hpp:246-248).
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF_BIN = os.environ.get("TUNGSTEN_REF_BIN", "/tmp/tungsten-build/tungsten")
+
+FIXTURES = [
+    # name, scene (relative to assets/), resolution, spp
+    ("c2_128x72_1spp", "materialtest/c2.json", (128, 72), 1),
+    ("c2_128x72_16spp", "materialtest/c2.json", (128, 72), 16),
+    ("c2_128x72_48spp", "materialtest/c2.json", (128, 72), 48),
+    ("c2_100x57_4spp", "materialtest/c2.json", (100, 57), 4),
+    ("c1_128x72_4spp", "materialtest/c1_noadapt.json", (128, 72), 4),
+    ("c1_128x72_32spp", "materialtest/c1_noadapt.json", (128, 72), 32),
+    ("cornell_96x54_8spp", "cornell-box/scene_sobol.json", (96, 54), 8),
+]
+
+
+def main():
+    if not os.path.exists(REF_BIN):
+        sys.exit(f"reference binary {REF_BIN} not found; fixtures cannot be regenerated here")
+    only = set(sys.argv[1:])
+    for name, scene, res, spp in FIXTURES:
+        if only and name not in only:
+            continue
+        src = os.path.join(REPO, "assets", scene)
+        if not os.path.exists(src):
+            print("skip (scene missing):", name)
+            continue
+        d = json.load(open(src))
+        d["camera"]["resolution"] = list(res)
+        d["renderer"].update({"spp": spp, "output_file": name + ".png", "hdr_output_file": name + ".pfm",
+                              "overwrite_output_files": True, "adaptive_sampling": False})
+        tmp = os.path.join(os.path.dirname(src), f"_tmp_{name}.json")
+        json.dump(d, open(tmp, "w"))
+        try:
+            r = subprocess.run([REF_BIN, "-t", "8", "-d", HERE, tmp], capture_output=True, text=True)
+        finally:
+            os.remove(tmp)
+        if r.returncode != 0:
+            sys.exit(r.stdout + r.stderr)
+        png = os.path.join(HERE, name + ".png")
+        if os.path.exists(png):
+            os.remove(png)
+        print("wrote", name + ".pfm")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo processes each render their tile shard (the oracle
+stands in for the GPU on this GPU-less box: the shard/gather plumbing under test is the same code
+bench.py uses) and rank 0's gathered image must equal the single-rank image bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, scene_path
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import tungsten_amd as ta
+    from tungsten_amd.dist import gather_framebuffer
+    from oracle.oracle_py import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(72, 40))
+    shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank, world)
+    rgb, _ = Oracle(scene, rng=1, math=1).render_shard(shard, 4, spp_step=4, threads=2)
+    img = gather_framebuffer(torch.from_numpy(rgb), shard, world, rank, dist)
+    if rank == 0:
+        np.save(out_path, img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_shard_gather_equals_single_rank(ta, oracle_py, tmp_path, world):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    scene = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(72, 40))
+    full = ta.Shard(scene.res_x, scene.res_y)
+    rgb, _ = oracle_py.Oracle(scene, rng=1, math=1).render_shard(full, 4, spp_step=4, threads=2)
+    assert np.array_equal(got, full.scatter(rgb))
+
+
+def test_shard_sizes_are_balanced(ta):
+    from tungsten_amd.dist import shard_sizes
+    for world in (2, 4, 8):
+        sizes = shard_sizes(1280, 720, world)
+        assert sum(sizes) == 1280*720
+        assert max(sizes) - min(sizes) <= 256  # at most one 16x16 tile

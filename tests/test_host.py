@@ -1,0 +1,129 @@
+"""Host logic: scene loading, shards, ABI layout, library exports (no GPU)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import REPO, scene_path
+
+
+def test_load_materialtest(ta):
+    s = ta.HostScene(scene_path("materialtest/materialtest.json"))
+    assert (s.res_x, s.res_y) == (1000, 563)
+    assert s.spp == 32 and s.spp_step == 16 and s.use_sobol and s.adaptive
+    d = s.desc.contents
+    assert d.n_tris == 80768  # Ring 17536 + T-Ball 49920 + Stand 13312
+    assert d.n_quads == 1 and d.n_lights == 1 and d.env.present == 1 and d.env.samplable == 1
+    assert (d.env.dist_w, d.env.dist_h) == (1024, 512)
+    mc = np.ctypeslib.as_array(d.env.marginal_cdf, shape=(513,))
+    assert mc[0] == 0.0 and mc[-1] == 1.0 and (np.diff(mc) >= 0).all()
+    assert abs(d.camera.plane_dist - 1.0/np.tan(np.radians(35.0)/2)) < 1e-5
+    cdf = np.array(d.camera.filter_cdf[:32])
+    assert cdf[0] == 0 and cdf[31] == 1 and (np.diff(cdf) >= 0).all()
+
+
+def test_resolution_override_and_errors(ta):
+    s = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(64, 32))
+    assert (s.res_x, s.res_y) == (64, 32) and not s.adaptive
+    with pytest.raises(RuntimeError):
+        ta.HostScene(scene_path("materialtest/does_not_exist.json"))
+    with tempfile.TemporaryDirectory() as td:
+        bad = os.path.join(td, "bad.json")
+        open(bad, "w").write('{"bsdfs": [{"name": "x", "type": "hair"}]}')
+        with pytest.raises(RuntimeError, match="outside the hot-path scope"):
+            ta.HostScene(bad)
+        open(bad, "w").write('{"primitives": [')
+        with pytest.raises(RuntimeError, match="JSON"):
+            ta.HostScene(bad)
+        open(bad, "w").write('{"integrator": {"type": "bidirectional_path_tracer"}}')
+        with pytest.raises(RuntimeError, match="path_tracer only"):
+            ta.HostScene(bad)
+
+
+def test_empty_scene_gets_default_light(ta):
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "empty.json")
+        open(p, "w").write('{"camera": {"resolution": [8, 8]}}')
+        s = ta.HostScene(p)
+        d = s.desc.contents
+        assert d.n_tris == 0 and d.n_lights == 1 and d.env.present == 1  # TraceableScene.hpp:97-102
+
+
+@pytest.mark.parametrize("res", [(128, 72), (100, 57), (16, 16), (17, 1), (1, 1)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shards_partition_the_image(ta, oracle_py, res, world):
+    w, h = res
+    seeds = oracle_py.tile_seeds(w, h)
+    seen = np.zeros(w*h, np.int32)
+    for r in range(world):
+        sh = ta.Shard(w, h, 0xBA5EBA11, r, world)
+        px = sh.pixel_index
+        seen[px] += 1
+        d = sh.desc.contents
+        ts = np.ctypeslib.as_array(d.tile_seed, shape=(sh.n_pixels,)) if sh.n_pixels else np.zeros(0, np.uint32)
+        tile = (px % w)//16 + (px//w)//16*((w + 15)//16)
+        assert (tile % world == r).all()          # tile t -> rank t % world
+        assert (ts == seeds[tile]).all()          # seeds as PathTraceIntegrator::diceTiles draws them
+    assert (seen == 1).all()                      # every pixel exactly once
+
+
+def _header_functions():
+    text = open(os.path.join(REPO, "include", "tungsten_amd.h")).read()
+    return sorted(set(re.findall(r"\b(tgpu_[a-z_]+)\s*\(", text)))
+
+
+def test_core_library_exports_every_declared_symbol(ta):
+    lib = ta.core_lib()  # loads without a GPU; compute entry points are not called here
+    names = _header_functions()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/tungsten_amd.h but not exported"
+
+
+def test_abi_struct_sizes_match_the_c_header(ta):
+    from tungsten_amd import _abi
+    src = r'''
+#include "tungsten_amd.h"
+#include <stdio.h>
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tgpu_texture), sizeof(tgpu_bitmap),
+ sizeof(tgpu_bsdf), sizeof(tgpu_quad), sizeof(tgpu_cube), sizeof(tgpu_env), sizeof(tgpu_camera), sizeof(tgpu_settings),
+ sizeof(tgpu_light), sizeof(tgpu_scene_desc), sizeof(tgpu_shard_desc), sizeof(tgpu_stats));return 0;}'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)  # header is plain C
+        sizes = [int(t) for t in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    mirrors = [_abi.Texture, _abi.Bitmap, _abi.Bsdf, _abi.Quad, _abi.Cube, _abi.Env, _abi.Camera, _abi.Settings,
+               _abi.Light, _abi.SceneDesc, _abi.ShardDesc, _abi.Stats]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_no_gpu_means_loud_failure(ta):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ta.CoreError, match="no CPU fallback"):
+        ta.Context(0)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under tungsten_amd/ may reference it."""
+    for root, _, files in os.walk(os.path.join(REPO, "tungsten_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                for needle in ("oracle_", "liboracle", "import oracle", "from oracle", "oracle/"):
+                    assert needle not in text, f"{f} links, imports or calls the oracle ({needle})"
+
+
+def test_pfm_roundtrip(ta, tmp_path):
+    img = np.random.default_rng(0).random((5, 7, 3), dtype=np.float32)
+    p = tmp_path / "x.pfm"
+    ta.save_pfm(p, img)
+    assert np.array_equal(ta.load_pfm(p), img)

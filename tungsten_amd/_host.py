@@ -105,6 +105,8 @@ class Shard:
 
     @property
     def pixel_index(self):
+        if self.n_pixels == 0:
+            return np.zeros(0, np.uint32)
         d = self.desc.contents
         return np.ctypeslib.as_array(d.pixel_index, shape=(self.n_pixels,)).copy()
 

@@ -1,0 +1,41 @@
+"""Image-plane sharding across ranks + the final gather.
+
+Tile t (row-major 16x16 tiles, PathTraceIntegrator.cpp:27-42) goes to rank t % world.  Every rank
+renders its own shard with no data-path collective; one gather of the per-rank framebuffers to
+rank 0 ends the render (RCCL over xGMI when the tensors live on the GPU, gloo on CPU tensors).
+Shards differ in size by at most one tile, so they are padded to the common maximum for the
+collective.
+"""
+import numpy as np
+
+from ._host import Shard
+
+
+def shard_sizes(res_x, res_y, world, seed=0xBA5EBA11):
+    return [Shard(res_x, res_y, seed, r, world).n_pixels for r in range(world)]
+
+
+def gather_framebuffer(local_rgb, shard, world, rank, dist=None, device=None):
+    """Gather shard-ordered rgb tensors (torch, on `device`) to rank 0 and assemble the image.
+
+    local_rgb: torch tensor (n_local, 3) float32.  Returns an (H, W, 3) numpy image on rank 0,
+    None elsewhere.  With world == 1 no collective is issued.
+    """
+    import torch
+
+    res_x, res_y = shard.res_x, shard.res_y
+    if world == 1:
+        return shard.scatter(local_rgb.detach().cpu().numpy())
+    sizes = shard_sizes(res_x, res_y, world)
+    n_max = max(sizes)
+    padded = torch.zeros((n_max, 3), dtype=torch.float32, device=local_rgb.device)
+    padded[: local_rgb.shape[0]] = local_rgb
+    gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, gather_list=gathered, dst=0)
+    if rank != 0:
+        return None
+    image = np.zeros((res_y*res_x, 3), np.float32)
+    for r in range(world):
+        sh = Shard(res_x, res_y, 0xBA5EBA11, r, world)
+        image[sh.pixel_index] = gathered[r][: sizes[r]].cpu().numpy()
+    return image.reshape(res_y, res_x, 3)

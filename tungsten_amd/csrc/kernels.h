@@ -7,9 +7,12 @@
 //   K5 miss       environment lookup                     (TraceBase.cpp:570-578)
 //   K7 accumulate per-pixel running mean                 (OutputBuffer.hpp:104-132)
 //
-// Path state lives in HBM as SoA float4/uint4 streams indexed by path slot; queues are
-// compact arrays of slot indices with device-side counters.  All kernels are launched with
-// a fixed, chip-filling grid and stride/pull over their queue ("persistent threads").
+// Path state lives in HBM as SoA float4/uint4 streams indexed by path SLOT of a fixed pool; queues
+// are compact arrays of slot indices with device-side counters.  A slot whose path ended is
+// retired (its radiance goes to the per-sample result ring) and immediately re-used for the next
+// camera sample (path regeneration, K1), so every wavefront iteration runs on a full pool and the
+// long low-occupancy tail of a pass is paid once per render instead of once per pass.  All kernels
+// are launched with a fixed, chip-filling grid and stride/pull over their queue.
 #pragma once
 #include "device.h"
 
@@ -17,7 +20,21 @@ namespace tg {
 
 // ---- path-state streams ---------------------------------------------------------------------
 enum { CNT_EXT_NEXT = 0, CNT_MISS = 1, CNT_CLASS0 = 2, CNT_SHADOW = 2 + TGPU_BSDF_NUM_CLASSES,
-       CNT_HEAD_EXT = 3 + TGPU_BSDF_NUM_CLASSES, CNT_HEAD_SHADOW = 4 + TGPU_BSDF_NUM_CLASSES, CNT_TOTAL = 16 };
+       CNT_HEAD_EXT = 3 + TGPU_BSDF_NUM_CLASSES, CNT_HEAD_SHADOW = 4 + TGPU_BSDF_NUM_CLASSES,
+       CNT_END = 5 + TGPU_BSDF_NUM_CLASSES, CNT_REGEN = 6 + TGPU_BSDF_NUM_CLASSES,
+       CNT_JOB_DONE0 = 7 + TGPU_BSDF_NUM_CLASSES /* TG_RING entries, persistent across iterations */,
+       CNT_PER_ITER = CNT_JOB_DONE0 /* everything below is zeroed every iteration */, CNT_TOTAL = 16 };
+#define TG_RING 4
+
+// Samples are handed out in global order: job by job, inside a job sample-major then shard pixel
+// (coalesced accumulate).  A job = one spp range over all shard pixels (one tgpu_render_pass chunk).
+struct JobRing {
+    unsigned long long start[TG_RING]; // global index of the job's first sample
+    uint32_t sppBegin[TG_RING];
+    uint32_t sppCount[TG_RING];
+    uint32_t ringSlot[TG_RING];        // which slice of the result ring the job writes
+    uint32_t n;
+};
 
 enum { END_ALIVE = 0, END_RAW = 1, END_ZERO = 2, END_CHECKED = 3 };
 // flags word (bits of tp.w): [15:0] bounce, [16] wasSpecular, [27:24] end state
@@ -40,11 +57,16 @@ struct DState {
     float4 *shD;    // B.xyz (unoccluded bsdf-sample term), bits(end cap prim | postAdd flag << 31 hmm)
     float4 *shE;    // throughput at the vertex.xyz, bits(has post-add)
     float4 *shF;    // emitter term to add after the NEE term.xyz
+    uint32_t *sampleRef; // per slot: index into `results` of the sample the slot is tracing
+    float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w unused)
     uint32_t *extQ[2];
     uint32_t *classQ[TGPU_BSDF_NUM_CLASSES];
     uint32_t *missQ;
     uint32_t *shadowQ;
+    uint32_t *endQ;      // slots whose path ended this iteration
     uint32_t *counters;
+    uint32_t nPixels;
+    uint32_t resultSlice; // samples per ring slot = nPixels * resultSpp
     unsigned long long *stats; // [0] ext nodes [1] ext tris [2] shadow nodes [3] shadow tris [4] shadow rays [5] surface events
     // shard
     const uint32_t *pixelIndex;
@@ -112,28 +134,78 @@ TG_DEV void cameraRay(const tgpu_camera &cam, uint32_t px, uint32_t py, float xi
     dir = mulVector(cam.rot, localD);
 }
 
-__global__ void __launch_bounds__(256) k_generate(DScene sc, DState st, uint32_t pixBegin, uint32_t pixCount, uint32_t sppBegin, uint32_t sppCount)
+// Retire + regenerate.  For every slot in the end queue (INITIAL: every slot of the pool):
+//  1. retire: the finished path's radiance, with traceSample's exit rules applied (PathTracer.cpp:119-131),
+//     goes to the result ring; the job's completion counter is bumped;
+//  2. regenerate: the slot takes the next sample in global order, if any is admitted (< limit), sets up
+//     sampler + camera ray (PathTraceIntegrator.cpp:143-147, PathTracer.cpp:23-31) and joins the next extend queue.
+template <bool INITIAL>
+__global__ void __launch_bounds__(256) k_regenerate(DScene sc, DState st, JobRing jobs, uint32_t poolSize, unsigned long long sampleBase,
+                                                    unsigned long long limit, uint32_t *extNext)
 {
-    uint32_t total = pixCount*sppCount;
-    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < total; i += gridDim.x*blockDim.x) {
-        uint32_t kk = i % pixCount, s = i/pixCount;
-        uint32_t k = pixBegin + kk;
-        uint32_t pixel = st.pixelIndex[k];
-        Sampler smp;
-        smp.matrices = sc.sobol;
-        smp.sobol = sc.settings.use_sobol;
-        smp.scramble = st.scramble[k];
-        smp.index = sppBegin + s;
-        smp.dimension = 0;
-        smp.seedPathLocal(smp.scramble, smp.index);
-        float xi0 = smp.next1D(), xi1 = smp.next1D();
-        V3 pos, dir;
-        cameraRay(sc.cam, pixel % sc.cam.res_x, pixel/sc.cam.res_x, xi0, xi1, pos, dir);
-        st.rayO[i] = mk4(pos, 1e-4f); // math/Ray.hpp:24
-        st.rayD[i] = mk4(dir, TG_INF);
-        st.tp[i] = mk4u(V3(1.0f), packFlags(0, true, END_ALIVE));
-        st.em[i] = mk4u(V3(0.0f), smp.scramble);
-        st.samp[i] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
+    const uint32_t count = INITIAL ? poolSize : st.counters[CNT_END];
+    const uint32_t stride = gridDim.x*blockDim.x;
+    const uint32_t rounded = (count + 63u) & ~63u;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
+        const bool active = q < count;
+        uint32_t slot = 0;
+        if (active) slot = INITIAL ? q : st.endQ[q];
+        if (!INITIAL) {
+            uint32_t ring = 0xFFFFFFFFu;
+            if (active) {
+                float4 tpw = st.tp[slot], emw = st.em[slot];
+                V3 c = xyz(emw);
+                int end = flagsEnd(__float_as_uint(tpw.w));
+                if (end == END_ZERO) c = V3(0.0f);
+                else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
+                uint32_t ref = st.sampleRef[slot];
+                st.results[ref] = mk4(c, 0.0f);
+                ring = ref/st.resultSlice;
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < TG_RING; ++r) {
+                unsigned long long m = __ballot(ring == r);
+                if (m && lane == __builtin_ctzll(m)) atomicAdd(&st.counters[CNT_JOB_DONE0 + r], uint32_t(__builtin_popcountll(m)));
+            }
+        }
+        // claim the next samples for the active lanes of this wave
+        unsigned long long mask = __ballot(active);
+        unsigned long long g = 0;
+        if (mask) {
+            int leader = __builtin_ctzll(mask);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&st.counters[CNT_REGEN], uint32_t(__builtin_popcountll(mask)));
+            base = __shfl(base, leader);
+            g = sampleBase + base + uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+        }
+        bool started = active && g < limit;
+        if (started) {
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t t = 1; t < TG_RING; ++t)
+                if (t < jobs.n && g >= jobs.start[t]) j = t;
+            uint32_t e = uint32_t(g - jobs.start[j]);
+            uint32_t s = e/st.nPixels, k = e - s*st.nPixels;
+            uint32_t pixel = st.pixelIndex[k];
+            Sampler smp;
+            smp.matrices = sc.sobol;
+            smp.sobol = sc.settings.use_sobol;
+            smp.scramble = st.scramble[k];
+            smp.index = jobs.sppBegin[j] + s;
+            smp.dimension = 0;
+            smp.seedPathLocal(smp.scramble, smp.index);
+            float xi0 = smp.next1D(), xi1 = smp.next1D();
+            V3 pos, dir;
+            cameraRay(sc.cam, pixel % sc.cam.res_x, pixel/sc.cam.res_x, xi0, xi1, pos, dir);
+            st.rayO[slot] = mk4(pos, 1e-4f); // math/Ray.hpp:24
+            st.rayD[slot] = mk4(dir, TG_INF);
+            st.tp[slot] = mk4u(V3(1.0f), packFlags(0, true, END_ALIVE));
+            st.em[slot] = mk4u(V3(0.0f), smp.scramble);
+            st.samp[slot] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
+            st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
+        }
+        queueAppend(started, extNext, &st.counters[CNT_EXT_NEXT], slot);
     }
 }
 
@@ -363,35 +435,42 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, const uint
 // =================================================================================================
 __global__ void __launch_bounds__(256) k_miss(DScene sc, DState st)
 {
-    uint32_t count = st.counters[CNT_MISS];
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) {
-        uint32_t path = st.missQ[q];
-        float4 tpw = st.tp[path], emw = st.em[path];
-        V3 tp = xyz(tpw), em = xyz(emw);
-        uint32_t flags = __float_as_uint(tpw.w);
-        int bounce = flagsBounce(flags);
-        bool wasSpecular = flagsSpecular(flags);
-        int end = END_CHECKED;
-        // per-bounce NaN guard of the previous vertex (PathTracer.cpp:121-122), evaluated once its NEE is in
-        if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
-            end = END_ZERO;
-        } else if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
-            bool nee = sc.settings.enable_light_sampling != 0;
-            if (!nee || wasSpecular || !sc.env.samplable) {
-                V3 D = xyz(st.rayD[path]);
-                V3 E;
-                if (sc.envConstant) {
-                    E = V3(sc.textures[sc.env.emission_tex].value);
-                } else {
-                    float ux, uy;
-                    directionToUV(sc, D, ux, uy, nullptr);
-                    E = texEval(sc, sc.env.emission_tex, ux, uy);
+    const uint32_t count = st.counters[CNT_MISS];
+    const uint32_t stride = gridDim.x*blockDim.x;
+    const uint32_t rounded = (count + 63u) & ~63u;
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
+        const bool active = q < count;
+        uint32_t path = 0;
+        if (active) {
+            path = st.missQ[q];
+            float4 tpw = st.tp[path], emw = st.em[path];
+            V3 tp = xyz(tpw), em = xyz(emw);
+            uint32_t flags = __float_as_uint(tpw.w);
+            int bounce = flagsBounce(flags);
+            bool wasSpecular = flagsSpecular(flags);
+            int end = END_CHECKED;
+            // per-bounce NaN guard of the previous vertex (PathTracer.cpp:121-122), evaluated once its NEE is in
+            if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
+                end = END_ZERO;
+            } else if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
+                bool nee = sc.settings.enable_light_sampling != 0;
+                if (!nee || wasSpecular || !sc.env.samplable) {
+                    V3 D = xyz(st.rayD[path]);
+                    V3 E;
+                    if (sc.envConstant) {
+                        E = V3(sc.textures[sc.env.emission_tex].value);
+                    } else {
+                        float ux, uy;
+                        directionToUV(sc, D, ux, uy, nullptr);
+                        E = texEval(sc, sc.env.emission_tex, ux, uy);
+                    }
+                    em += tp*E;
+                    st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
                 }
-                em += tp*E;
-                st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
             }
+            st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
         }
-        st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
+        queueAppend(active, st.endQ, &st.counters[CNT_END], path);
     }
 }
 
@@ -547,7 +626,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, uint32_t *e
     const uint32_t rounded = (count + 63u) & ~63u;
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
         bool active = q < count;
-        bool pushShadow = false, pushExt = false;
+        bool pushShadow = false, pushExt = false, ended = false;
         uint32_t path = 0;
         if (active) {
             path = st.classQ[CLASS][q];
@@ -773,9 +852,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, uint32_t *e
                 st.em[path] = mk4u(em, smp.scramble);
             }
             st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
+            ended = end != END_ALIVE;
         }
         queueAppend(pushShadow, st.shadowQ, &st.counters[CNT_SHADOW], path);
         queueAppend(pushExt, extNext, &st.counters[CNT_EXT_NEXT], path);
+        queueAppend(ended, st.endQ, &st.counters[CNT_END], path);
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&st.stats[5], (unsigned long long)count);
 }
@@ -840,20 +921,14 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
 // =================================================================================================
 // K7 accumulate: OutputBuffer::addSample in sample order (cameras/OutputBuffer.hpp:104-132)
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_accumulate(DScene sc, DState st, uint32_t pixBegin, uint32_t pixCount, uint32_t sppCount)
+__global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot, uint32_t sppCount)
 {
-    (void)sc;
-    for (uint32_t kk = blockIdx.x*blockDim.x + threadIdx.x; kk < pixCount; kk += gridDim.x*blockDim.x) {
-        uint32_t k = pixBegin + kk;
+    const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
+    for (uint32_t k = blockIdx.x*blockDim.x + threadIdx.x; k < st.nPixels; k += gridDim.x*blockDim.x) {
         V3 mean(st.fbMean + size_t(k)*3);
         uint32_t n = st.fbCount[k];
         for (uint32_t s = 0; s < sppCount; ++s) {
-            uint32_t i = s*pixCount + kk;
-            float4 tpw = st.tp[i], emw = st.em[i];
-            V3 c = xyz(emw);
-            int end = flagsEnd(__float_as_uint(tpw.w));
-            if (end == END_ZERO) c = V3(0.0f);
-            else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
+            V3 c = xyz(res[size_t(s)*st.nPixels + k]);
             if (isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) continue;
             mean = mean + (c - mean)/float(n + 1u);
             n++;

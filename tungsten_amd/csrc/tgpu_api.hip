@@ -6,6 +6,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -36,8 +40,22 @@ struct tgpu_ctx {
     std::vector<void *> stateAllocs;
 
     uint32_t nPixels = 0;
-    uint64_t capacity = 0; // paths in flight
+    uint64_t capacity = 0; // path slots in the pool
+    uint32_t resultSpp = 16; // samples per pixel one result-ring slot holds
     uint32_t *hostCounters = nullptr; // pinned
+
+    // job queue + worker thread: tgpu_render_pass enqueues, the worker drives the wavefront loop
+    struct Job { uint32_t sppBegin, sppCount; unsigned long long start, total; uint32_t ringSlot; };
+    std::mutex mtx;
+    std::condition_variable cvWork, cvIdle;
+    std::deque<Job> pending, active;
+    bool idle = true, shutdown = false;
+    int lastRc = TGPU_OK;
+    std::thread worker;
+    unsigned long long sampleBase = 0, globalCursor = 0;
+    uint32_t nCur = 0;
+    int curQ = 0;
+    uint32_t ringFree = (1u << TG_RING) - 1u;
     int numCUs = 256;
     int maxGrid = 2048;
     size_t ldsBytes = 0;
@@ -207,9 +225,28 @@ int tgpu_init(int device, tgpu_ctx **out)
     return TGPU_OK;
 }
 
+static void workerMain(tgpu_ctx *ctx);
+static int waitIdle(tgpu_ctx *ctx, bool consume = false)
+{
+    std::unique_lock<std::mutex> lk(ctx->mtx);
+    ctx->cvIdle.wait(lk, [&] { return ctx->idle; });
+    int rc = ctx->lastRc;
+    if (consume) ctx->lastRc = TGPU_OK;
+    return rc;
+}
+
 void tgpu_destroy(tgpu_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->worker.joinable()) {
+        ctx->abortFlag = true;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mtx);
+            ctx->shutdown = true;
+        }
+        ctx->cvWork.notify_all();
+        ctx->worker.join();
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     freePool(ctx->allocs);
@@ -234,10 +271,15 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (uint32_t i = 0; i < shard->n_pixels; ++i)
         if (shard->pixel_index[i] >= nImagePixels) { fail(ctx, "shard pixel %u out of range", i); return TGPU_ERR_INVALID; }
 
+    (void)waitIdle(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     freePool(ctx->allocs);
     freePool(ctx->stateAllocs);
     ctx->uploaded = false;
+    ctx->sampleBase = ctx->globalCursor = 0;
+    ctx->nCur = 0;
+    ctx->curQ = 0;
+    ctx->ringFree = (1u << TG_RING) - 1u;
     ctx->sc = DScene{};
     ctx->st = DState{};
     DScene &sc = ctx->sc;
@@ -344,48 +386,83 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, shard->n_pixels, &dCnt))) return rc;
     st.pixelIndex = dPix; st.scramble = dScr; st.fbMean = dMean; st.fbCount = dCnt;
 
-    // ---- wavefront state ----
-    uint64_t cap = maxPaths ? maxPaths : std::min<uint64_t>(uint64_t(shard->n_pixels)*16, 16ull << 20);
+    // ---- wavefront state: a pool of `cap` path slots + the per-sample result ring ----
+    uint64_t cap = maxPaths ? maxPaths : std::min<uint64_t>(std::max<uint64_t>(uint64_t(shard->n_pixels)*16, 4096), 8ull << 20);
     if (cap < 64) cap = 64;
+    if (cap > (1ull << 30)) { fail(ctx, "max_paths_in_flight too large"); return TGPU_ERR_INVALID; }
     ctx->capacity = cap;
     float4 **f4[] = {&st.rayO, &st.rayD, &st.hit, &st.tp, &st.em, &st.shA, &st.shB, &st.shC, &st.shD, &st.shE, &st.shF};
     for (float4 **pp : f4)
         if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
-    uint32_t **qs[] = {&st.extQ[0], &st.extQ[1], &st.missQ, &st.shadowQ};
+    uint32_t **qs[] = {&st.extQ[0], &st.extQ[1], &st.missQ, &st.shadowQ, &st.endQ, &st.sampleRef};
     for (uint32_t **pp : qs)
         if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     for (int c = 0; c < TGPU_BSDF_NUM_CLASSES; ++c)
         if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.classQ[c]))) return rc;
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL, &st.counters))) return rc;
     if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8, &st.stats))) return rc;
+    ctx->resultSpp = 16;
+    while (uint64_t(shard->n_pixels)*ctx->resultSpp*TG_RING > (1ull << 31) && ctx->resultSpp > 1) ctx->resultSpp /= 2;
+    st.nPixels = shard->n_pixels;
+    st.resultSlice = shard->n_pixels*ctx->resultSpp;
+    if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, size_t(st.resultSlice)*TG_RING, &st.results))) return rc;
 
     ctx->stats = tgpu_stats{};
     ctx->uploaded = true;
     ctx->abortFlag = false;
+    if (!ctx->worker.joinable()) ctx->worker = std::thread(workerMain, ctx);
     return TGPU_OK;
 }
 
-// One wavefront batch: pixels [pixBegin, pixBegin+pixCount) x samples [sppBegin, sppBegin+sppCount)
-static int renderBatch(tgpu_ctx *ctx, hipStream_t stream, uint32_t pixBegin, uint32_t pixCount, uint32_t sppBegin, uint32_t sppCount)
+// ---- the wavefront driver (runs on the context's worker thread) ---------------------------------------------
+// One iteration = extend -> miss/shade (per BSDF class) -> shadow -> retire+regenerate, followed by one readback
+// of the queue counters.  Jobs (spp ranges) are admitted while a slot of the result ring is free; a job's
+// samples are folded into the framebuffer (k_accumulate) once all of them have retired, in job order.
+static int driveIteration(tgpu_ctx *ctx)
 {
     DScene &sc = ctx->sc;
     DState &st = ctx->st;
-    const uint32_t total = pixCount*sppCount;
+    hipStream_t stream = ctx->stream;
     const bool count = (ctx->profFlags & 1u) != 0;
-    hipStream_t saved = ctx->stream;
-    ctx->stream = stream;
+
+    // admit pending jobs into free ring slots
     {
-        Timer t(ctx, &ctx->stats.other_ms);
-        hipLaunchKernelGGL(k_generate, dim3(gridFor(ctx, total)), dim3(256), 0, stream, sc, st, pixBegin, pixCount, sppBegin, sppCount);
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        while (!ctx->pending.empty() && ctx->active.size() < TG_RING && ctx->ringFree) {
+            tgpu_ctx::Job j = ctx->pending.front();
+            ctx->pending.pop_front();
+            j.ringSlot = uint32_t(__builtin_ctz(ctx->ringFree));
+            ctx->ringFree &= ~(1u << j.ringSlot);
+            j.start = ctx->globalCursor;
+            ctx->globalCursor += j.total;
+            ctx->active.push_back(j);
+        }
     }
-    uint32_t nCur = total;
-    const uint32_t *queue = nullptr;
-    int cur = 0;
-    int rc = TGPU_OK;
-    for (int iter = 0; nCur > 0; ++iter) {
-        if (ctx->abortFlag.load()) { rc = TGPU_ERR_ABORTED; break; }
-        (void)hipMemsetAsync(st.counters, 0, CNT_TOTAL*sizeof(uint32_t), stream);
+    JobRing ring{};
+    ring.n = uint32_t(ctx->active.size());
+    unsigned long long limit = ctx->sampleBase;
+    for (uint32_t i = 0; i < ring.n; ++i) {
+        const tgpu_ctx::Job &j = ctx->active[i];
+        ring.start[i] = j.start;
+        ring.sppBegin[i] = j.sppBegin;
+        ring.sppCount[i] = j.sppCount;
+        ring.ringSlot[i] = j.ringSlot;
+        limit = j.start + j.total;
+    }
+    // jobs whose samples have all been handed out need no entry for g -> job lookups of NEW samples, but
+    // the lookup walks start[] in order, so keep them: start[] is increasing and g >= sampleBase.
+
+    (void)hipMemsetAsync(st.counters, 0, CNT_PER_ITER*sizeof(uint32_t), stream);
+    uint32_t *next = st.extQ[ctx->curQ ^ 1];
+    const uint32_t nCur = ctx->nCur;
+    if (nCur == 0) {
+        // nothing in flight: every slot of the pool is free
+        Timer t(ctx, &ctx->stats.other_ms);
+        hipLaunchKernelGGL(k_regenerate<true>, dim3(gridFor(ctx, ctx->capacity)), dim3(256), 0, stream, sc, st, ring, uint32_t(ctx->capacity),
+                           ctx->sampleBase, limit, next);
+    } else {
+        const uint32_t *queue = st.extQ[ctx->curQ];
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
@@ -394,7 +471,6 @@ static int renderBatch(tgpu_ctx *ctx, hipStream_t stream, uint32_t pixBegin, uin
         }
         ctx->stats.extend_rays += nCur;
         ctx->stats.extend_launches++;
-        uint32_t *next = st.extQ[cur ^ 1];
         {
             Timer t(ctx, &ctx->stats.shade_ms);
             hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st);
@@ -409,25 +485,86 @@ static int renderBatch(tgpu_ctx *ctx, hipStream_t stream, uint32_t pixBegin, uin
             else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st);
         }
         ctx->stats.shadow_launches++;
-        hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) {
-            fail(ctx, "wavefront iteration %d failed: %s", iter, hipGetErrorString(e));
-            rc = TGPU_ERR_HIP;
-            break;
+        {
+            Timer t(ctx, &ctx->stats.other_ms);
+            hipLaunchKernelGGL(k_regenerate<false>, dim3(grid), dim3(256), 0, stream, sc, st, ring, uint32_t(ctx->capacity), ctx->sampleBase, limit, next);
         }
-        nCur = ctx->hostCounters[CNT_EXT_NEXT];
-        if (nCur > total) { fail(ctx, "internal error: queue overflow (%u > %u)", nCur, total); rc = TGPU_ERR_HIP; break; }
-        queue = next;
-        cur ^= 1;
     }
-    if (rc == TGPU_OK) {
-        Timer t(ctx, &ctx->stats.other_ms);
-        hipLaunchKernelGGL(k_accumulate, dim3(gridFor(ctx, pixCount)), dim3(256), 0, stream, sc, st, pixBegin, pixCount, sppCount);
-        ctx->stats.samples += total;
+    hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        fail(ctx, "wavefront iteration failed: %s", hipGetErrorString(e));
+        return TGPU_ERR_HIP;
     }
-    ctx->stream = saved;
-    return rc;
+    const uint32_t *hc = ctx->hostCounters;
+    if (hc[CNT_EXT_NEXT] > ctx->capacity) { fail(ctx, "internal error: queue overflow (%u > %llu)", hc[CNT_EXT_NEXT], (unsigned long long)ctx->capacity); return TGPU_ERR_HIP; }
+    ctx->nCur = hc[CNT_EXT_NEXT];
+    ctx->curQ ^= 1;
+    unsigned long long room = limit - ctx->sampleBase;
+    ctx->sampleBase += std::min<unsigned long long>(hc[CNT_REGEN], room);
+
+    bool retired = false;
+    // retire finished jobs in order
+    while (!ctx->active.empty()) {
+        tgpu_ctx::Job &j = ctx->active.front();
+        if (hc[CNT_JOB_DONE0 + j.ringSlot] != j.total) break;
+        {
+            Timer t(ctx, &ctx->stats.other_ms);
+            hipLaunchKernelGGL(k_accumulate, dim3(gridFor(ctx, ctx->nPixels)), dim3(256), 0, stream, st, j.ringSlot, j.sppCount);
+        }
+        (void)hipMemsetAsync(st.counters + CNT_JOB_DONE0 + j.ringSlot, 0, sizeof(uint32_t), stream);
+        ctx->stats.samples += j.total;
+        ctx->ringFree |= 1u << j.ringSlot;
+        ctx->active.pop_front();
+        retired = true;
+    }
+    // every iteration must start samples, advance paths or retire a job; anything else is a bookkeeping bug
+    if (nCur == 0 && ctx->nCur == 0 && !retired && !ctx->active.empty()) {
+        fail(ctx, "internal error: wavefront stalled with %zu unfinished job(s)", ctx->active.size());
+        return TGPU_ERR_HIP;
+    }
+    return TGPU_OK;
+}
+
+static void workerMain(tgpu_ctx *ctx)
+{
+    (void)hipSetDevice(ctx->device);
+    while (true) {
+        {
+            std::unique_lock<std::mutex> lk(ctx->mtx);
+            ctx->cvWork.wait(lk, [&] { return ctx->shutdown || !ctx->pending.empty(); });
+            if (ctx->shutdown) return;
+        }
+        int rc = TGPU_OK;
+        while (rc == TGPU_OK) {
+            bool more;
+            {
+                std::lock_guard<std::mutex> lk(ctx->mtx);
+                more = !ctx->pending.empty() || !ctx->active.empty() || ctx->nCur > 0;
+            }
+            if (!more) break;
+            if (ctx->abortFlag.load()) { rc = TGPU_ERR_ABORTED; break; }
+            rc = driveIteration(ctx);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        {
+            std::lock_guard<std::mutex> lk(ctx->mtx);
+            if (rc != TGPU_OK) {
+                // drop everything that was in flight; the framebuffer keeps the passes accumulated so far
+                ctx->pending.clear();
+                ctx->active.clear();
+                ctx->nCur = 0;
+                ctx->ringFree = (1u << TG_RING) - 1u;
+                ctx->sampleBase = ctx->globalCursor;
+                (void)hipMemsetAsync(ctx->st.counters, 0, CNT_TOTAL*sizeof(uint32_t), ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+                if (rc == TGPU_ERR_ABORTED) ctx->error = "render aborted";
+                ctx->lastRc = rc;
+            }
+            ctx->idle = ctx->pending.empty();
+            if (ctx->idle) ctx->cvIdle.notify_all();
+        }
+    }
 }
 
 int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *streamPtr)
@@ -435,31 +572,46 @@ int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *
     if (!ctx) return TGPU_ERR_INVALID;
     if (!ctx->uploaded) { fail(ctx, "tgpu_render_pass before tgpu_upload_scene"); return TGPU_ERR_STATE; }
     if (sppCount == 0) return TGPU_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t stream = streamPtr ? static_cast<hipStream_t>(streamPtr) : ctx->stream;
-    if (uint64_t(sppCount) > ctx->capacity) { fail(ctx, "spp_count %u exceeds the paths-in-flight capacity %llu", sppCount, (unsigned long long)ctx->capacity); return TGPU_ERR_INVALID; }
-    ctx->abortFlag = false;
-    uint32_t pixPerBatch = uint32_t(std::min<uint64_t>(ctx->capacity/sppCount, ctx->nPixels));
-    for (uint32_t p = 0; p < ctx->nPixels; p += pixPerBatch) {
-        uint32_t n = std::min(pixPerBatch, ctx->nPixels - p);
-        int rc = renderBatch(ctx, stream, p, n, sppBegin, sppCount);
-        if (rc != TGPU_OK) return rc;
+    if (streamPtr) {
+        // work submitted so far on the caller's stream must precede the pass: order the context stream after it
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipEvent_t ev;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ev, static_cast<hipStream_t>(streamPtr)));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+        HIP_TRY(ctx, hipEventDestroy(ev));
     }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        ctx->abortFlag = false;
+        for (uint32_t s = 0; s < sppCount; s += ctx->resultSpp) { // one job per result-ring slice
+            uint32_t n = std::min(ctx->resultSpp, sppCount - s);
+            ctx->pending.push_back(tgpu_ctx::Job{sppBegin + s, n, 0ull, (unsigned long long)n*ctx->nPixels, 0u});
+        }
+        ctx->idle = false;
+    }
+    ctx->cvWork.notify_one();
     return TGPU_OK;
 }
 
 int tgpu_wait(tgpu_ctx *ctx)
 {
     if (!ctx) return TGPU_ERR_INVALID;
+    int rc = waitIdle(ctx, true);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return TGPU_OK;
+    return rc;
 }
 
 int tgpu_abort(tgpu_ctx *ctx)
 {
     if (!ctx) return TGPU_ERR_INVALID;
-    ctx->abortFlag = true;
+    bool busy;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        busy = !ctx->idle;
+    }
+    if (busy) ctx->abortFlag = true;
     return TGPU_OK;
 }
 
@@ -467,6 +619,7 @@ int tgpu_download(tgpu_ctx *ctx, float *rgb, uint32_t *cnt)
 {
     if (!ctx) return TGPU_ERR_INVALID;
     if (!ctx->uploaded) { fail(ctx, "tgpu_download before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    (void)waitIdle(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (rgb) HIP_TRY(ctx, hipMemcpy(rgb, ctx->st.fbMean, size_t(ctx->nPixels)*3*sizeof(float), hipMemcpyDeviceToHost));
@@ -478,6 +631,7 @@ int tgpu_resolve_to_device(tgpu_ctx *ctx, void *deviceRgb, void *streamPtr)
 {
     if (!ctx || !deviceRgb) return TGPU_ERR_INVALID;
     if (!ctx->uploaded) { fail(ctx, "tgpu_resolve_to_device before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    (void)waitIdle(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = streamPtr ? static_cast<hipStream_t>(streamPtr) : ctx->stream;
     if (stream != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -489,6 +643,7 @@ int tgpu_upload_framebuffer(tgpu_ctx *ctx, const float *rgb, const uint32_t *cnt
 {
     if (!ctx || !rgb || !cnt) return TGPU_ERR_INVALID;
     if (!ctx->uploaded) { fail(ctx, "tgpu_upload_framebuffer before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    (void)waitIdle(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->st.fbMean, rgb, size_t(ctx->nPixels)*3*sizeof(float), hipMemcpyHostToDevice));
@@ -500,6 +655,7 @@ static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, u
 {
     if (!ctx || !rays || (!hits && !occ)) return TGPU_ERR_INVALID;
     if (!ctx->uploaded) { fail(ctx, "ray query before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    (void)waitIdle(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DState &st = ctx->st;
     std::vector<float> o, d;
@@ -548,6 +704,7 @@ int tgpu_trace_occluded(tgpu_ctx *ctx, const float *rays, uint32_t n, uint8_t *o
 int tgpu_set_profiling(tgpu_ctx *ctx, uint32_t flags)
 {
     if (!ctx) return TGPU_ERR_INVALID;
+    (void)waitIdle(ctx);
     ctx->profFlags = flags;
     return TGPU_OK;
 }
@@ -555,6 +712,7 @@ int tgpu_set_profiling(tgpu_ctx *ctx, uint32_t flags)
 int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out)
 {
     if (!ctx || !out) return TGPU_ERR_INVALID;
+    (void)waitIdle(ctx);
     if (ctx->uploaded) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -574,6 +732,7 @@ int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out)
 int tgpu_reset_stats(tgpu_ctx *ctx)
 {
     if (!ctx) return TGPU_ERR_INVALID;
+    (void)waitIdle(ctx);
     ctx->stats = tgpu_stats{};
     if (ctx->uploaded) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -586,6 +745,7 @@ int tgpu_reset_stats(tgpu_ctx *ctx)
 int tgpu_eval_math(tgpu_ctx *ctx, int kind, const float *a, const float *b, uint32_t n, float *out)
 {
     if (!ctx || !a || !b || !out) return TGPU_ERR_INVALID;
+    (void)waitIdle(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *da = nullptr, *db = nullptr, *dout = nullptr;
     size_t bytes = size_t(n ? n : 1)*sizeof(float);

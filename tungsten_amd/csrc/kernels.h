@@ -22,9 +22,14 @@ namespace tg {
 enum { CNT_EXT_NEXT = 0, CNT_MISS = 1, CNT_CLASS0 = 2, CNT_SHADOW = 2 + TGPU_BSDF_NUM_CLASSES,
        CNT_HEAD_EXT = 3 + TGPU_BSDF_NUM_CLASSES, CNT_HEAD_SHADOW = 4 + TGPU_BSDF_NUM_CLASSES,
        CNT_END = 5 + TGPU_BSDF_NUM_CLASSES, CNT_REGEN = 6 + TGPU_BSDF_NUM_CLASSES,
-       CNT_JOB_DONE0 = 7 + TGPU_BSDF_NUM_CLASSES /* TG_RING entries, persistent across iterations */,
-       CNT_PER_ITER = CNT_JOB_DONE0 /* everything below is zeroed every iteration */, CNT_TOTAL = 16 };
-#define TG_RING 4
+       CNT_PER_ITER = 7 + TGPU_BSDF_NUM_CLASSES /* everything below is zeroed every iteration */,
+       CNT_FREE = CNT_PER_ITER /* persistent: length of the free-slot list */,
+       CNT_JOB_DONE0 = CNT_FREE + 1 /* TG_RING persistent per-job retire counters */, CNT_TOTAL = 32 };
+// Result-ring slices (= jobs that may be in flight).  A job can only be folded into the framebuffer
+// once its slowest path has ended (~max_bounces iterations after its last sample started), and during
+// that time the pool keeps starting samples of later jobs: the ring must hold ~26 x pool size samples.
+#define TG_RING 16
+static_assert(CNT_JOB_DONE0 + TG_RING <= CNT_TOTAL, "counter block too small");
 
 // Samples are handed out in global order: job by job, inside a job sample-major then shard pixel
 // (coalesced accumulate).  A job = one spp range over all shard pixels (one tgpu_render_pass chunk).
@@ -64,6 +69,7 @@ struct DState {
     uint32_t *missQ;
     uint32_t *shadowQ;
     uint32_t *endQ;      // slots whose path ended this iteration
+    uint32_t *freeQ;     // idle slots: ended while no sample was admitted (ring full / end of render)
     uint32_t *counters;
     uint32_t nPixels;
     uint32_t resultSlice; // samples per ring slot = nPixels * resultSpp
@@ -134,40 +140,68 @@ TG_DEV void cameraRay(const tgpu_camera &cam, uint32_t px, uint32_t py, float xi
     dir = mulVector(cam.rot, localD);
 }
 
-// Retire + regenerate.  For every slot in the end queue (INITIAL: every slot of the pool):
+// Start sample g of the render in path slot `slot`: sampler + camera ray
+// (PathTraceIntegrator.cpp:143-147, PathTracer.cpp:23-31).
+TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs, unsigned long long g, uint32_t slot)
+{
+    uint32_t j = 0;
+    for (uint32_t t = 1; t < jobs.n; ++t)
+        if (g >= jobs.start[t]) j = t;
+    uint32_t e = uint32_t(g - jobs.start[j]);
+    uint32_t s = e/st.nPixels, k = e - s*st.nPixels;
+    uint32_t pixel = st.pixelIndex[k];
+    Sampler smp;
+    smp.matrices = sc.sobol;
+    smp.sobol = sc.settings.use_sobol;
+    smp.scramble = st.scramble[k];
+    smp.index = jobs.sppBegin[j] + s;
+    smp.dimension = 0;
+    smp.seedPathLocal(smp.scramble, smp.index);
+    float xi0 = smp.next1D(), xi1 = smp.next1D();
+    V3 pos, dir;
+    cameraRay(sc.cam, pixel % sc.cam.res_x, pixel/sc.cam.res_x, xi0, xi1, pos, dir);
+    st.rayO[slot] = mk4(pos, 1e-4f); // math/Ray.hpp:24
+    st.rayD[slot] = mk4(dir, TG_INF);
+    st.tp[slot] = mk4u(V3(1.0f), packFlags(0, true, END_ALIVE));
+    st.em[slot] = mk4u(V3(0.0f), smp.scramble);
+    st.samp[slot] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
+    st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
+}
+
+// Retire + regenerate, for every slot in the end queue:
 //  1. retire: the finished path's radiance, with traceSample's exit rules applied (PathTracer.cpp:119-131),
 //     goes to the result ring; the job's completion counter is bumped;
-//  2. regenerate: the slot takes the next sample in global order, if any is admitted (< limit), sets up
-//     sampler + camera ray (PathTraceIntegrator.cpp:143-147, PathTracer.cpp:23-31) and joins the next extend queue.
-template <bool INITIAL>
-__global__ void __launch_bounds__(256) k_regenerate(DScene sc, DState st, JobRing jobs, uint32_t poolSize, unsigned long long sampleBase,
-                                                    unsigned long long limit, uint32_t *extNext)
+//  2. regenerate: the slot takes the next sample in global order if one is admitted (< limit) and joins the
+//     next extend queue; otherwise it goes to the free list.
+__global__ void __launch_bounds__(256) k_retire_regenerate(DScene sc, DState st, JobRing jobs, unsigned long long sampleBase,
+                                                           unsigned long long limit, uint32_t *extNext)
 {
-    const uint32_t count = INITIAL ? poolSize : st.counters[CNT_END];
+    const uint32_t count = st.counters[CNT_END];
     const uint32_t stride = gridDim.x*blockDim.x;
     const uint32_t rounded = (count + 63u) & ~63u;
     const int lane = threadIdx.x & 63;
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
         const bool active = q < count;
-        uint32_t slot = 0;
-        if (active) slot = INITIAL ? q : st.endQ[q];
-        if (!INITIAL) {
-            uint32_t ring = 0xFFFFFFFFu;
-            if (active) {
-                float4 tpw = st.tp[slot], emw = st.em[slot];
-                V3 c = xyz(emw);
-                int end = flagsEnd(__float_as_uint(tpw.w));
-                if (end == END_ZERO) c = V3(0.0f);
-                else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
-                uint32_t ref = st.sampleRef[slot];
-                st.results[ref] = mk4(c, 0.0f);
-                ring = ref/st.resultSlice;
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < TG_RING; ++r) {
-                unsigned long long m = __ballot(ring == r);
-                if (m && lane == __builtin_ctzll(m)) atomicAdd(&st.counters[CNT_JOB_DONE0 + r], uint32_t(__builtin_popcountll(m)));
-            }
+        uint32_t slot = 0, ring = 0xFFFFFFFFu;
+        if (active) {
+            slot = st.endQ[q];
+            float4 tpw = st.tp[slot], emw = st.em[slot];
+            V3 c = xyz(emw);
+            int end = flagsEnd(__float_as_uint(tpw.w));
+            if (end == END_ZERO) c = V3(0.0f);
+            else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
+            uint32_t ref = st.sampleRef[slot];
+            st.results[ref] = mk4(c, 0.0f);
+            ring = ref/st.resultSlice;
+        }
+        // one atomic per distinct job present in the wave
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            int leader = __builtin_ctzll(todo);
+            uint32_t r = __shfl(ring, leader);
+            unsigned long long m = __ballot(active && ring == r);
+            if (lane == leader) atomicAdd(&st.counters[CNT_JOB_DONE0 + r], uint32_t(__builtin_popcountll(m)));
+            todo &= ~m;
         }
         // claim the next samples for the active lanes of this wave
         unsigned long long mask = __ballot(active);
@@ -180,33 +214,23 @@ __global__ void __launch_bounds__(256) k_regenerate(DScene sc, DState st, JobRin
             g = sampleBase + base + uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
         }
         bool started = active && g < limit;
-        if (started) {
-            uint32_t j = 0;
-#pragma unroll
-            for (uint32_t t = 1; t < TG_RING; ++t)
-                if (t < jobs.n && g >= jobs.start[t]) j = t;
-            uint32_t e = uint32_t(g - jobs.start[j]);
-            uint32_t s = e/st.nPixels, k = e - s*st.nPixels;
-            uint32_t pixel = st.pixelIndex[k];
-            Sampler smp;
-            smp.matrices = sc.sobol;
-            smp.sobol = sc.settings.use_sobol;
-            smp.scramble = st.scramble[k];
-            smp.index = jobs.sppBegin[j] + s;
-            smp.dimension = 0;
-            smp.seedPathLocal(smp.scramble, smp.index);
-            float xi0 = smp.next1D(), xi1 = smp.next1D();
-            V3 pos, dir;
-            cameraRay(sc.cam, pixel % sc.cam.res_x, pixel/sc.cam.res_x, xi0, xi1, pos, dir);
-            st.rayO[slot] = mk4(pos, 1e-4f); // math/Ray.hpp:24
-            st.rayD[slot] = mk4(dir, TG_INF);
-            st.tp[slot] = mk4u(V3(1.0f), packFlags(0, true, END_ALIVE));
-            st.em[slot] = mk4u(V3(0.0f), smp.scramble);
-            st.samp[slot] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
-            st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
-        }
+        if (started) startSample(sc, st, jobs, g, slot);
         queueAppend(started, extNext, &st.counters[CNT_EXT_NEXT], slot);
+        queueAppend(active && !started, st.freeQ, &st.counters[CNT_FREE], slot);
     }
+}
+
+// Refill from the free list: the host knows how many samples are admitted, so slot freeQ[freeBase + q]
+// takes sample sampleBase + q and is written straight into the current extend queue at queueBase + q.
+__global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, JobRing jobs, unsigned long long sampleBase, uint32_t nStart,
+                                                uint32_t freeBase, uint32_t *queue, uint32_t queueBase)
+{
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < nStart; q += gridDim.x*blockDim.x) {
+        uint32_t slot = st.freeQ[freeBase + q];
+        startSample(sc, st, jobs, sampleBase + q, slot);
+        queue[queueBase + q] = slot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[CNT_FREE] = freeBase;
 }
 
 // =================================================================================================

@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -53,7 +54,7 @@ struct tgpu_ctx {
     int lastRc = TGPU_OK;
     std::thread worker;
     unsigned long long sampleBase = 0, globalCursor = 0;
-    uint32_t nCur = 0;
+    uint32_t nCur = 0, freeCount = 0;
     int curQ = 0;
     uint32_t ringFree = (1u << TG_RING) - 1u;
     int numCUs = 256;
@@ -395,6 +396,11 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (float4 **pp : f4)
         if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
+    {
+        std::vector<uint32_t> ident(cap);
+        for (uint64_t i = 0; i < cap; ++i) ident[i] = uint32_t(i);
+        if ((rc = upload(ctx, ctx->stateAllocs, ident.data(), ident.size(), &st.freeQ))) return rc;
+    }
     uint32_t **qs[] = {&st.extQ[0], &st.extQ[1], &st.missQ, &st.shadowQ, &st.endQ, &st.sampleRef};
     for (uint32_t **pp : qs)
         if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
@@ -402,8 +408,13 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.classQ[c]))) return rc;
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL, &st.counters))) return rc;
     if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8, &st.stats))) return rc;
+    {
+        uint32_t freeInit = uint32_t(cap);
+        HIP_TRY(ctx, hipMemcpy(st.counters + CNT_FREE, &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice));
+        ctx->freeCount = freeInit;
+    }
     ctx->resultSpp = 16;
-    while (uint64_t(shard->n_pixels)*ctx->resultSpp*TG_RING > (1ull << 31) && ctx->resultSpp > 1) ctx->resultSpp /= 2;
+    while (uint64_t(shard->n_pixels)*ctx->resultSpp*TG_RING > (1ull << 30) && ctx->resultSpp > 1) ctx->resultSpp /= 2; // <= 16 GiB of results
     st.nPixels = shard->n_pixels;
     st.resultSlice = shard->n_pixels*ctx->resultSpp;
     if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, size_t(st.resultSlice)*TG_RING, &st.results))) return rc;
@@ -419,6 +430,30 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
 // One iteration = extend -> miss/shade (per BSDF class) -> shadow -> retire+regenerate, followed by one readback
 // of the queue counters.  Jobs (spp ranges) are admitted while a slot of the result ring is free; a job's
 // samples are folded into the framebuffer (k_accumulate) once all of them have retired, in job order.
+// Poll instead of blocking: the per-iteration readback is latency critical, and a blocking
+// hipStreamSynchronize from a non-main thread was measured at ~140 ms per call when another HIP user
+// (torch) lives in the same process.
+static hipError_t spinSync(hipStream_t stream)
+{
+    hipError_t e;
+    while ((e = hipStreamQuery(stream)) == hipErrorNotReady) std::this_thread::yield();
+    return e;
+}
+
+// every slot back on the free list, all counters cleared (after an abort or an error)
+static void resetPool(tgpu_ctx *ctx)
+{
+    std::vector<uint32_t> ident(ctx->capacity);
+    for (uint64_t i = 0; i < ctx->capacity; ++i) ident[i] = uint32_t(i);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(ctx->st.freeQ, ident.data(), ident.size()*sizeof(uint32_t), hipMemcpyHostToDevice);
+    (void)hipMemset(ctx->st.counters, 0, CNT_TOTAL*sizeof(uint32_t));
+    uint32_t freeInit = uint32_t(ctx->capacity);
+    (void)hipMemcpy(ctx->st.counters + CNT_FREE, &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice);
+    ctx->freeCount = freeInit;
+    ctx->nCur = 0;
+}
+
 static int driveIteration(tgpu_ctx *ctx)
 {
     DScene &sc = ctx->sc;
@@ -455,19 +490,27 @@ static int driveIteration(tgpu_ctx *ctx)
 
     (void)hipMemsetAsync(st.counters, 0, CNT_PER_ITER*sizeof(uint32_t), stream);
     uint32_t *next = st.extQ[ctx->curQ ^ 1];
-    const uint32_t nCur = ctx->nCur;
-    if (nCur == 0) {
-        // nothing in flight: every slot of the pool is free
-        Timer t(ctx, &ctx->stats.other_ms);
-        hipLaunchKernelGGL(k_regenerate<true>, dim3(gridFor(ctx, ctx->capacity)), dim3(256), 0, stream, sc, st, ring, uint32_t(ctx->capacity),
-                           ctx->sampleBase, limit, next);
-    } else {
-        const uint32_t *queue = st.extQ[ctx->curQ];
+    uint32_t *queue = st.extQ[ctx->curQ];
+    uint32_t nCur = ctx->nCur;
+    // idle slots take admitted samples first and join THIS iteration's extend queue
+    {
+        unsigned long long room = limit - ctx->sampleBase;
+        uint32_t nStart = uint32_t(std::min<unsigned long long>(room, ctx->freeCount));
+        if (nStart) {
+            Timer t(ctx, &ctx->stats.other_ms);
+            uint32_t freeBase = ctx->freeCount - nStart;
+            hipLaunchKernelGGL(k_refill, dim3(gridFor(ctx, nStart)), dim3(256), 0, stream, sc, st, ring, ctx->sampleBase, nStart, freeBase, queue, nCur);
+            ctx->freeCount = freeBase;
+            ctx->sampleBase += nStart;
+            nCur += nStart;
+        }
+    }
+    if (nCur > 0) {
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
-            if (count) hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, queue, nCur);
-            else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, queue, nCur);
+            if (count) hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, (const uint32_t *)queue, nCur);
+            else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, (const uint32_t *)queue, nCur);
         }
         ctx->stats.extend_rays += nCur;
         ctx->stats.extend_launches++;
@@ -487,19 +530,22 @@ static int driveIteration(tgpu_ctx *ctx)
         ctx->stats.shadow_launches++;
         {
             Timer t(ctx, &ctx->stats.other_ms);
-            hipLaunchKernelGGL(k_regenerate<false>, dim3(grid), dim3(256), 0, stream, sc, st, ring, uint32_t(ctx->capacity), ctx->sampleBase, limit, next);
+            hipLaunchKernelGGL(k_retire_regenerate, dim3(grid), dim3(256), 0, stream, sc, st, ring, ctx->sampleBase, limit, next);
         }
     }
     hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = spinSync(stream);
     if (e != hipSuccess) {
         fail(ctx, "wavefront iteration failed: %s", hipGetErrorString(e));
         return TGPU_ERR_HIP;
     }
     const uint32_t *hc = ctx->hostCounters;
+    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] iter nCur=%u next=%u regen=%u end=%u shadow=%u miss=%u base=%llu limit=%llu active=%zu done=[%u %u %u %u]\n", nCur, hc[CNT_EXT_NEXT], hc[CNT_REGEN], hc[CNT_END], hc[CNT_SHADOW], hc[CNT_MISS], ctx->sampleBase, limit, ctx->active.size(), hc[CNT_JOB_DONE0], hc[CNT_JOB_DONE0+1], hc[CNT_JOB_DONE0+2], hc[CNT_JOB_DONE0+3]);
     if (hc[CNT_EXT_NEXT] > ctx->capacity) { fail(ctx, "internal error: queue overflow (%u > %llu)", hc[CNT_EXT_NEXT], (unsigned long long)ctx->capacity); return TGPU_ERR_HIP; }
     ctx->nCur = hc[CNT_EXT_NEXT];
     ctx->curQ ^= 1;
+    ctx->freeCount = hc[CNT_FREE];
+    if (ctx->freeCount > ctx->capacity) { fail(ctx, "internal error: free list overflow"); return TGPU_ERR_HIP; }
     unsigned long long room = limit - ctx->sampleBase;
     ctx->sampleBase += std::min<unsigned long long>(hc[CNT_REGEN], room);
 
@@ -556,8 +602,7 @@ static void workerMain(tgpu_ctx *ctx)
                 ctx->nCur = 0;
                 ctx->ringFree = (1u << TG_RING) - 1u;
                 ctx->sampleBase = ctx->globalCursor;
-                (void)hipMemsetAsync(ctx->st.counters, 0, CNT_TOTAL*sizeof(uint32_t), ctx->stream);
-                (void)hipStreamSynchronize(ctx->stream);
+                resetPool(ctx);
                 if (rc == TGPU_ERR_ABORTED) ctx->error = "render aborted";
                 ctx->lastRc = rc;
             }
@@ -673,7 +718,7 @@ static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, u
         }
         hipError_t e = hipMemcpyAsync(st.rayO, o.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(st.rayD, d.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(st.counters, 0, CNT_TOTAL*sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(st.counters, 0, CNT_PER_ITER*sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) {
             if (hits) {
                 hipLaunchKernelGGL((k_extend<false, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, (const uint32_t *)nullptr, m);

@@ -36,6 +36,18 @@ NODE_BYTES, TRI_BYTES, RAY_QUEUE_BYTES = 64, 48, 56  # DESIGN.md "algorithmic by
 HBM_PEAK_GBS = 8000.0
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota)/int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,15 +143,17 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's shard) -------------------------------------
     if not args.no_roofline and rank == 0:
+        rsteps = max(1, min(args.steps, 8))  # same pipelined regime as the timed region
         ctx.set_profiling(1)  # visit counters (k_extend<true,..>)
         ctx.reset_stats()
-        ctx.render_pass(done, spp_step)
+        for i in range(rsteps):
+            ctx.render_pass(done + spp_step*i, spp_step)
         ctx.wait()
         c = ctx.stats()
         ctx.set_profiling(2)  # HIP-event timing of the production kernels
         ctx.reset_stats()
-        for i in range(2):
-            ctx.render_pass(done + spp_step*(1 + i), spp_step)
+        for i in range(rsteps):
+            ctx.render_pass(done + spp_step*(rsteps + i), spp_step)
         ctx.wait()
         t = ctx.stats()
         ctx.set_profiling(0)
@@ -159,19 +173,19 @@ def main():
             "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "avg_launch_ms": round(avg_ms, 5),
-            "launches_per_step": launches,
+            "launches_per_step": round(launches/rsteps, 2),
             "per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
                         "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)},
             "per_sample": {"extend_rays": round(c["extend_rays"]/max(1, c["samples"]), 3),
                            "shadow_rays": round(c["shadow_rays"]/max(1, c["samples"]), 3),
                            "surface_events": round(c["surface_events"]/max(1, c["samples"]), 3)},
-            "kernel_ms_per_step": {k: round(t[k]/2, 3) for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms")},
+            "kernel_ms_per_step": {k: round(t[k]/rsteps, 3) for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms")},
         }
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) ----------------------
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle.oracle_py import Oracle
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores()
         orc = Oracle(scene, rng=1, math=1, rcp=0)
         full = ta.Shard(scene.res_x, scene.res_y)
         tc = time.perf_counter()

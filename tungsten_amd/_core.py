@@ -17,19 +17,17 @@ class CoreError(RuntimeError):
 TgpuStats = _abi.Stats
 
 
-def core_lib():
-    """Load the HIP core.  torch (when installed) is imported first so that both share ONE HIP
-    runtime (torch bundles libamdhip64.so.7; the loader then reuses it for our NEEDED entry)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_CORE_LIB_PATH):
-            raise CoreError(f"{_CORE_LIB_PATH} is missing: the HIP extension has not been built "
+def load_core(path):
+    """Load one build of the HIP core from `path` and declare its C ABI (A/B benchmarking loads two)."""
+    if True:
+        if not os.path.exists(path):
+            raise CoreError(f"{path} is missing: the HIP extension has not been built "
                             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
         try:
             import torch  # noqa: F401
         except Exception:
             pass
-        L = C.CDLL(_CORE_LIB_PATH)
+        L = C.CDLL(path)
         vp = C.c_void_p
         L.tgpu_init.argtypes = [C.c_int, C.POINTER(vp)]
         L.tgpu_destroy.argtypes = [vp]
@@ -48,7 +46,15 @@ def core_lib():
         L.tgpu_get_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
         L.tgpu_reset_stats.argtypes = [vp]
         L.tgpu_eval_math.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp]
-        _lib = L
+    return L
+
+
+def core_lib():
+    """The in-tree HIP core.  torch (when installed) is imported first so that both share ONE HIP
+    runtime (torch bundles libamdhip64.so.7; the loader then reuses it for our NEEDED entry)."""
+    global _lib
+    if _lib is None:
+        _lib = load_core(_CORE_LIB_PATH)
     return _lib
 
 
@@ -62,8 +68,8 @@ EXPORTED_SYMBOLS = [
 class Context:
     """One GPU, one scene, one image-plane shard (the Integrator-side view of the C ABI)."""
 
-    def __init__(self, device=0):
-        L = core_lib()
+    def __init__(self, device=0, lib=None):
+        L = self._lib = lib if lib is not None else core_lib()
         h = C.c_void_p()
         rc = L.tgpu_init(int(device), C.byref(h))
         if rc != 0 or not h:
@@ -74,19 +80,19 @@ class Context:
 
     def _check(self, rc):
         if rc != 0:
-            msg = core_lib().tgpu_last_error(self._h)
+            msg = self._lib.tgpu_last_error(self._h)
             raise CoreError(f"tgpu error {rc}: {msg.decode() if msg else ''}")
 
     def upload(self, host_scene, shard, max_paths=0):
         self._scene, self._shard = host_scene, shard
-        self._check(core_lib().tgpu_upload_scene(self._h, C.cast(host_scene.desc, C.c_void_p),
+        self._check(self._lib.tgpu_upload_scene(self._h, C.cast(host_scene.desc, C.c_void_p),
                                                  C.cast(shard.desc, C.c_void_p), int(max_paths)))
 
     def render_pass(self, spp_begin, spp_count, stream=None):
-        self._check(core_lib().tgpu_render_pass(self._h, spp_begin, spp_count, C.c_void_p(stream or 0)))
+        self._check(self._lib.tgpu_render_pass(self._h, spp_begin, spp_count, C.c_void_p(stream or 0)))
 
     def wait(self):
-        self._check(core_lib().tgpu_wait(self._h))
+        self._check(self._lib.tgpu_wait(self._h))
 
     def render(self, spp, spp_step=16, spp_begin=0):
         done = spp_begin
@@ -100,45 +106,45 @@ class Context:
         n = self._shard.n_pixels
         rgb = np.zeros((n, 3), np.float32)
         cnt = np.zeros(n, np.uint32)
-        self._check(core_lib().tgpu_download(self._h, rgb.ctypes.data, cnt.ctypes.data))
+        self._check(self._lib.tgpu_download(self._h, rgb.ctypes.data, cnt.ctypes.data))
         return rgb, cnt
 
     def resolve_to_device(self, device_ptr, stream=None):
-        self._check(core_lib().tgpu_resolve_to_device(self._h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)))
+        self._check(self._lib.tgpu_resolve_to_device(self._h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)))
 
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros((len(rays), 4), np.float32)
-        self._check(core_lib().tgpu_trace_closest(self._h, rays.ctypes.data, len(rays), hits.ctypes.data))
+        self._check(self._lib.tgpu_trace_closest(self._h, rays.ctypes.data, len(rays), hits.ctypes.data))
         return hits
 
     def trace_occluded(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         occ = np.zeros(len(rays), np.uint8)
-        self._check(core_lib().tgpu_trace_occluded(self._h, rays.ctypes.data, len(rays), occ.ctypes.data))
+        self._check(self._lib.tgpu_trace_occluded(self._h, rays.ctypes.data, len(rays), occ.ctypes.data))
         return occ
 
     def eval_math(self, kind, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), np.float32)
         out = np.zeros_like(a)
-        self._check(core_lib().tgpu_eval_math(self._h, kind, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
+        self._check(self._lib.tgpu_eval_math(self._h, kind, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
         return out
 
     def set_profiling(self, flags):
-        self._check(core_lib().tgpu_set_profiling(self._h, flags))
+        self._check(self._lib.tgpu_set_profiling(self._h, flags))
 
     def stats(self):
         s = _abi.Stats()
-        self._check(core_lib().tgpu_get_stats(self._h, C.byref(s)))
+        self._check(self._lib.tgpu_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
 
     def reset_stats(self):
-        self._check(core_lib().tgpu_reset_stats(self._h))
+        self._check(self._lib.tgpu_reset_stats(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
-            core_lib().tgpu_destroy(self._h)
+            self._lib.tgpu_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -19,17 +19,25 @@
 namespace tg {
 
 // ---- path-state streams ---------------------------------------------------------------------
-enum { CNT_EXT_NEXT = 0, CNT_MISS = 1, CNT_CLASS0 = 2, CNT_SHADOW = 2 + TGPU_BSDF_NUM_CLASSES,
-       CNT_HEAD_EXT = 3 + TGPU_BSDF_NUM_CLASSES, CNT_HEAD_SHADOW = 4 + TGPU_BSDF_NUM_CLASSES,
-       CNT_END = 5 + TGPU_BSDF_NUM_CLASSES, CNT_REGEN = 6 + TGPU_BSDF_NUM_CLASSES,
-       CNT_PER_ITER = 7 + TGPU_BSDF_NUM_CLASSES /* everything below is zeroed every iteration */,
-       CNT_FREE = CNT_PER_ITER /* persistent: length of the free-slot list */,
-       CNT_JOB_DONE0 = CNT_FREE + 1 /* TG_RING persistent per-job retire counters */, CNT_TOTAL = 32 };
+// Slot lists: two sets (ping-pong) of 1 + TGPU_BSDF_NUM_CLASSES lists.  List 0 holds the slots whose ray
+// escaped (and freshly started / just-died slots), list 1 + c the slots whose hit has BSDF class c.
+// The extend kernel reads the concatenation of the current set and writes the other set; every other
+// kernel works in place on the set extend just wrote, so a slot keeps its list entry while its path is
+// retired and the next sample is started in it.
+#define TG_LISTS (1 + TGPU_BSDF_NUM_CLASSES)
+enum { CNT_LIST0 = 0 /* 2 x TG_LISTS list lengths */, CNT_HEAD_EXT = 2*TG_LISTS, CNT_HEAD_SHADOW = CNT_HEAD_EXT + 1,
+       CNT_REGEN = CNT_HEAD_EXT + 2 /* samples claimed this iteration */,
+       CNT_FREE = CNT_HEAD_EXT + 3 /* persistent: length of the free-slot list */,
+       CNT_JOB_DONE0 = CNT_HEAD_EXT + 4 /* TG_RING persistent per-job retire counters */, CNT_TOTAL = 32 };
 // Result-ring slices (= jobs that may be in flight).  A job can only be folded into the framebuffer
 // once its slowest path has ended (~max_bounces iterations after its last sample started), and during
 // that time the pool keeps starting samples of later jobs: the ring must hold ~26 x pool size samples.
 #define TG_RING 16
 static_assert(CNT_JOB_DONE0 + TG_RING <= CNT_TOTAL, "counter block too small");
+// Every counter lives on its own 128-byte line: the hot ones (dequeue heads, list lengths) are hit by
+// atomics from every CU, and an L2 channel serialises the requests to one line (~88 atomics/us).
+#define TG_CNT_STRIDE 32
+#define CNT(i) ((i)*TG_CNT_STRIDE)
 
 // Samples are handed out in global order: job by job, inside a job sample-major then shard pixel
 // (coalesced accumulate).  A job = one spp range over all shard pixels (one tgpu_render_pass chunk).
@@ -41,7 +49,7 @@ struct JobRing {
     uint32_t n;
 };
 
-enum { END_ALIVE = 0, END_RAW = 1, END_ZERO = 2, END_CHECKED = 3 };
+enum { END_ALIVE = 0, END_RAW = 1, END_ZERO = 2, END_CHECKED = 3, END_DEAD = 4 /* slot idle: no sample */ };
 // flags word (bits of tp.w): [15:0] bounce, [16] wasSpecular, [27:24] end state
 TG_DEV uint32_t packFlags(int bounce, bool wasSpecular, int end) { return uint32_t(bounce) | (wasSpecular ? 1u << 16 : 0u) | (uint32_t(end) << 24); }
 TG_DEV int flagsBounce(uint32_t f) { return int(f & 0xFFFFu); }
@@ -64,12 +72,9 @@ struct DState {
     float4 *shF;    // emitter term to add after the NEE term.xyz
     uint32_t *sampleRef; // per slot: index into `results` of the sample the slot is tracing
     float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w unused)
-    uint32_t *extQ[2];
-    uint32_t *classQ[TGPU_BSDF_NUM_CLASSES];
-    uint32_t *missQ;
-    uint32_t *shadowQ;
-    uint32_t *endQ;      // slots whose path ended this iteration
-    uint32_t *freeQ;     // idle slots: ended while no sample was admitted (ring full / end of render)
+    uint32_t *lists[2][TG_LISTS];
+    uint32_t *freeQ;     // idle slots that were dropped from the lists (no sample admitted / end of render)
+    uint32_t *shFlag;    // per slot: 1 when the current vertex queued NEE rays (shA..shF valid)
     uint32_t *counters;
     uint32_t nPixels;
     uint32_t resultSlice; // samples per ring slot = nPixels * resultSpp
@@ -99,6 +104,39 @@ TG_DEV void queueAppend(bool pred, uint32_t *queue, uint32_t *counter, uint32_t 
         uint32_t off = uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
         queue[base + off] = value;
     }
+}
+
+// List lengths of a set, read once per kernel (never per lane: the counter lines are hot)
+struct ListCounts { uint32_t n[TG_LISTS]; };
+TG_DEV ListCounts loadListCounts(const DState &st, int set)
+{
+    ListCounts c;
+#pragma unroll
+    for (int l = 0; l < TG_LISTS; ++l) c.n[l] = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + l)];
+    return c;
+}
+// Entry `idx` of the concatenation of lists [first, TG_LISTS) of `set`; false when idx is past the end.
+TG_DEV bool listFetch(const DState &st, const ListCounts &lc, int set, int first, uint32_t idx, uint32_t &slot)
+{
+#pragma unroll
+    for (int l = 0; l < TG_LISTS; ++l) {
+        if (l < first) continue;
+        uint32_t n = lc.n[l];
+        if (idx < n) {
+            slot = st.lists[set][l][idx];
+            return true;
+        }
+        idx -= n;
+    }
+    return false;
+}
+TG_DEV uint32_t listTotal(const ListCounts &lc, int first)
+{
+    uint32_t n = 0;
+#pragma unroll
+    for (int l = 0; l < TG_LISTS; ++l)
+        if (l >= first) n += lc.n[l];
+    return n;
 }
 
 // =================================================================================================
@@ -168,69 +206,91 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
     st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
 }
 
-// Retire + regenerate, for every slot in the end queue:
-//  1. retire: the finished path's radiance, with traceSample's exit rules applied (PathTracer.cpp:119-131),
-//     goes to the result ring; the job's completion counter is bumped;
-//  2. regenerate: the slot takes the next sample in global order if one is admitted (< limit) and joins the
-//     next extend queue; otherwise it goes to the free list.
-__global__ void __launch_bounds__(256) k_retire_regenerate(DScene sc, DState st, JobRing jobs, unsigned long long sampleBase,
-                                                           unsigned long long limit, uint32_t *extNext)
+// Retire + regenerate IN PLACE over every entry of the set extend just wrote:
+//  - alive paths are left alone;
+//  - an ended path is retired: its radiance, with traceSample's exit rules applied (PathTracer.cpp:119-131),
+//    goes to the result ring and the job's completion counter is bumped;
+//  - ended and idle slots then claim the next sample in global order; when one is admitted (< limit) the
+//    slot starts it and simply stays in its list (the next extend traces its camera ray), otherwise the
+//    slot is marked idle and the next extend drops it onto the free list.
+// Claims are aggregated per 1024-thread block (one global atomic per 1024 entries), job counters per block
+// in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
+__global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
+                                                            unsigned long long limit)
 {
-    const uint32_t count = st.counters[CNT_END];
+    __shared__ uint32_t sWave[16];
+    __shared__ uint32_t sHist[TG_RING];
+    __shared__ uint32_t sBase;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t total = listTotal(lc, 0);
     const uint32_t stride = gridDim.x*blockDim.x;
-    const uint32_t rounded = (count + 63u) & ~63u;
-    const int lane = threadIdx.x & 63;
+    const uint32_t rounded = (total + blockDim.x - 1u)/blockDim.x*blockDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < TG_RING) sHist[threadIdx.x] = 0;
+    __syncthreads();
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
-        const bool active = q < count;
         uint32_t slot = 0, ring = 0xFFFFFFFFu;
-        if (active) {
-            slot = st.endQ[q];
-            float4 tpw = st.tp[slot], emw = st.em[slot];
-            V3 c = xyz(emw);
+        bool needs = false;
+        if (q < total && listFetch(st, lc, set, 0, q, slot)) {
+            float4 tpw = st.tp[slot];
             int end = flagsEnd(__float_as_uint(tpw.w));
-            if (end == END_ZERO) c = V3(0.0f);
-            else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
-            uint32_t ref = st.sampleRef[slot];
-            st.results[ref] = mk4(c, 0.0f);
-            ring = ref/st.resultSlice;
+            if (end != END_ALIVE) {
+                needs = true;
+                if (end != END_DEAD) {
+                    V3 c = xyz(st.em[slot]);
+                    if (end == END_ZERO) c = V3(0.0f);
+                    else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
+                    uint32_t ref = st.sampleRef[slot];
+                    st.results[ref] = mk4(c, 0.0f);
+                    ring = ref/st.resultSlice;
+                }
+            }
         }
-        // one atomic per distinct job present in the wave
-        unsigned long long todo = __ballot(active);
-        while (todo) {
+        unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
+        while (todo) { // one LDS atomic per distinct job present in the wave
             int leader = __builtin_ctzll(todo);
             uint32_t r = __shfl(ring, leader);
-            unsigned long long m = __ballot(active && ring == r);
-            if (lane == leader) atomicAdd(&st.counters[CNT_JOB_DONE0 + r], uint32_t(__builtin_popcountll(m)));
+            unsigned long long m = __ballot(ring == r);
+            if (lane == leader) atomicAdd(&sHist[r], uint32_t(__builtin_popcountll(m)));
             todo &= ~m;
         }
-        // claim the next samples for the active lanes of this wave
-        unsigned long long mask = __ballot(active);
-        unsigned long long g = 0;
-        if (mask) {
-            int leader = __builtin_ctzll(mask);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&st.counters[CNT_REGEN], uint32_t(__builtin_popcountll(mask)));
-            base = __shfl(base, leader);
-            g = sampleBase + base + uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+        unsigned long long mask = __ballot(needs);
+        if (lane == 0) sWave[wave] = uint32_t(__builtin_popcountll(mask));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { uint32_t n = sWave[w]; sWave[w] = sum; sum += n; }
+            sBase = sum ? atomicAdd(&st.counters[CNT(CNT_REGEN)], sum) : 0u;
         }
-        bool started = active && g < limit;
-        if (started) startSample(sc, st, jobs, g, slot);
-        queueAppend(started, extNext, &st.counters[CNT_EXT_NEXT], slot);
-        queueAppend(active && !started, st.freeQ, &st.counters[CNT_FREE], slot);
+        __syncthreads();
+        if (needs) {
+            unsigned long long g = sampleBase + sBase + sWave[wave] + uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+            if (g < limit) {
+                startSample(sc, st, jobs, g, slot);
+            } else {
+                float4 tpw = st.tp[slot];
+                st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
+            }
+        }
+        __syncthreads();
     }
+    if (threadIdx.x < TG_RING && sHist[threadIdx.x]) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + threadIdx.x)], sHist[threadIdx.x]);
 }
 
 // Refill from the free list: the host knows how many samples are admitted, so slot freeQ[freeBase + q]
-// takes sample sampleBase + q and is written straight into the current extend queue at queueBase + q.
-__global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, JobRing jobs, unsigned long long sampleBase, uint32_t nStart,
-                                                uint32_t freeBase, uint32_t *queue, uint32_t queueBase)
+// takes sample sampleBase + q and is appended to list 0 of the current set at listBase + q.
+__global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase, uint32_t nStart,
+                                                uint32_t freeBase, uint32_t listBase)
 {
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < nStart; q += gridDim.x*blockDim.x) {
         uint32_t slot = st.freeQ[freeBase + q];
         startSample(sc, st, jobs, sampleBase + q, slot);
-        queue[queueBase + q] = slot;
+        st.lists[set][0][listBase + q] = slot;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[CNT_FREE] = freeBase;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st.counters[CNT(CNT_FREE)] = freeBase;
+        st.counters[CNT(CNT_LIST0 + set*TG_LISTS)] = listBase + nStart;
+    }
 }
 
 // =================================================================================================
@@ -416,39 +476,81 @@ TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
 }
 
 // =================================================================================================
-// K2 extend: persistent waves pull 64 rays at a time from the queue; per-lane traversal stack in LDS
-// (stack[level][thread], bank = lane -> conflict free); hits are appended to per-BSDF-class queues.
-// RAW = true: ray-level entry point (tgpu_trace_closest), no classification.
+// K2 extend: persistent waves pull 64 list entries per head atomic; per-lane traversal stack in LDS
+// (stack[level][thread], bank = lane -> conflict free); after 4 such batches the wave appends its slots
+// to the per-BSDF-class lists of the other set with ONE atomic per class.  Idle slots are
+// dropped onto the free list.  RAW = true: ray-level entry point (tgpu_trace_closest): identity queue,
+// no classification.
 // =================================================================================================
 template <bool COUNT, bool RAW>
-__global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, const uint32_t *queue, uint32_t count)
+__global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, uint32_t rawCount)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    ListCounts lc{};
+    if (!RAW) lc = loadListCounts(st, set);
+    const uint32_t count = RAW ? rawCount : listTotal(lc, 0);
     TraceCounters tc{0, 0};
-    while (true) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&st.counters[CNT_HEAD_EXT], 64u);
-        base = __shfl(base, 0);
-        if (base >= count) break;
-        uint32_t idx = base + lane;
-        bool active = idx < count;
-        uint32_t path = 0, cls = 0xFEu;
-        if (active) {
-            path = queue ? queue[idx] : idx;
-            float4 ro = st.rayO[path], rd = st.rayD[path];
-            V3 O = xyz(ro), D = xyz(rd);
-            float tfar = rd.w, u = 0.0f, v = 0.0f;
-            uint32_t prim = closestHit<COUNT>(sc, stack, O, D, ro.w, tfar, u, v, tc);
-            st.hit[path] = make_float4(tfar, u, v, __uint_as_float(prim));
-            if (!RAW) cls = hitClass(sc, prim);
+    bool drained = false;
+    while (!drained) {
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, cls4 = 0xFEFEFEFEu; // 0xFE = no entry
+        for (int b = 0; b < 4; ++b) {
+            // one head atomic per 64 entries keeps the waves balanced; the list appends below are the
+            // expensive atomics (few hot words) and are shared by the 4 batches
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&st.counters[CNT(CNT_HEAD_EXT)], 64u);
+            base = __shfl(base, 0);
+            if (base >= count) {
+                drained = true;
+                break;
+            }
+            uint32_t idx = base + lane;
+            uint32_t path = 0, cls = 0xFEu;
+            bool have = idx < count;
+            if (have) {
+                if (RAW) path = idx;
+                else have = listFetch(st, lc, set, 0, idx, path);
+            }
+            if (have) {
+                bool dead = !RAW && flagsEnd(__float_as_uint(st.tp[path].w)) == END_DEAD;
+                if (dead) {
+                    cls = 0xFDu;
+                } else {
+                    float4 ro = st.rayO[path], rd = st.rayD[path];
+                    V3 O = xyz(ro), D = xyz(rd);
+                    float tfar = rd.w, u = 0.0f, v = 0.0f;
+                    uint32_t prim = closestHit<COUNT>(sc, stack, O, D, ro.w, tfar, u, v, tc);
+                    st.hit[path] = make_float4(tfar, u, v, __uint_as_float(prim));
+                    if (!RAW) cls = hitClass(sc, prim);
+                }
+            }
+            p0 = b == 0 ? path : p0; p1 = b == 1 ? path : p1; p2 = b == 2 ? path : p2; p3 = b == 3 ? path : p3;
+            cls4 = (cls4 & ~(0xFFu << (8*b))) | (cls << (8*b));
         }
         if (!RAW) {
-            queueAppend(active && cls == 0xFFu, st.missQ, &st.counters[CNT_MISS], path);
+            const int out = set ^ 1;
+            // class 0xFF (miss) -> list 0, class c -> list 1 + c, 0xFD (idle) -> free list
 #pragma unroll
-            for (uint32_t c = 0; c < TGPU_BSDF_NUM_CLASSES; ++c)
-                queueAppend(active && cls == c, st.classQ[c], &st.counters[CNT_CLASS0 + c], path);
+            for (int l = 0; l <= TG_LISTS; ++l) {
+                const uint32_t want = l == 0 ? 0xFFu : (l == TG_LISTS ? 0xFDu : uint32_t(l - 1));
+                unsigned long long m0 = __ballot((cls4 & 0xFFu) == want), m1 = __ballot(((cls4 >> 8) & 0xFFu) == want);
+                unsigned long long m2 = __ballot(((cls4 >> 16) & 0xFFu) == want), m3 = __ballot((cls4 >> 24) == want);
+                uint32_t n0 = uint32_t(__builtin_popcountll(m0)), n1 = uint32_t(__builtin_popcountll(m1));
+                uint32_t n2 = uint32_t(__builtin_popcountll(m2)), n3 = uint32_t(__builtin_popcountll(m3));
+                uint32_t n = n0 + n1 + n2 + n3;
+                if (n == 0) continue;
+                uint32_t *dst = l == TG_LISTS ? st.freeQ : st.lists[out][l];
+                uint32_t *ctr = l == TG_LISTS ? &st.counters[CNT(CNT_FREE)] : &st.counters[CNT(CNT_LIST0 + out*TG_LISTS + l)];
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(ctr, n);
+                wbase = __shfl(wbase, 0);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if ((m0 >> lane) & 1ull) dst[wbase + uint32_t(__builtin_popcountll(m0 & below))] = p0;
+                if ((m1 >> lane) & 1ull) dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))] = p1;
+                if ((m2 >> lane) & 1ull) dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))] = p2;
+                if ((m3 >> lane) & 1ull) dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))] = p3;
+            }
         }
     }
     if (COUNT) flushCounters(st.stats, 0, tc);
@@ -457,44 +559,40 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, const uint
 // =================================================================================================
 // K5 miss: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) + end of traceSample
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_miss(DScene sc, DState st)
+__global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
 {
-    const uint32_t count = st.counters[CNT_MISS];
-    const uint32_t stride = gridDim.x*blockDim.x;
-    const uint32_t rounded = (count + 63u) & ~63u;
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
-        const bool active = q < count;
-        uint32_t path = 0;
-        if (active) {
-            path = st.missQ[q];
-            float4 tpw = st.tp[path], emw = st.em[path];
-            V3 tp = xyz(tpw), em = xyz(emw);
-            uint32_t flags = __float_as_uint(tpw.w);
-            int bounce = flagsBounce(flags);
-            bool wasSpecular = flagsSpecular(flags);
-            int end = END_CHECKED;
-            // per-bounce NaN guard of the previous vertex (PathTracer.cpp:121-122), evaluated once its NEE is in
-            if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
-                end = END_ZERO;
-            } else if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
-                bool nee = sc.settings.enable_light_sampling != 0;
-                if (!nee || wasSpecular || !sc.env.samplable) {
-                    V3 D = xyz(st.rayD[path]);
-                    V3 E;
-                    if (sc.envConstant) {
-                        E = V3(sc.textures[sc.env.emission_tex].value);
-                    } else {
-                        float ux, uy;
-                        directionToUV(sc, D, ux, uy, nullptr);
-                        E = texEval(sc, sc.env.emission_tex, ux, uy);
-                    }
-                    em += tp*E;
-                    st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
+    const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS)];
+    const uint32_t *list = st.lists[set][0];
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) {
+        uint32_t path = list[q];
+        float4 tpw = st.tp[path];
+        uint32_t flags = __float_as_uint(tpw.w);
+        if (flagsEnd(flags) != END_ALIVE) continue; // slot without a live path (refilled later)
+        float4 emw = st.em[path];
+        V3 tp = xyz(tpw), em = xyz(emw);
+        int bounce = flagsBounce(flags);
+        bool wasSpecular = flagsSpecular(flags);
+        int end = END_CHECKED;
+        // per-bounce NaN guard of the previous vertex (PathTracer.cpp:121-122), evaluated once its NEE is in
+        if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
+            end = END_ZERO;
+        } else if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
+            bool nee = sc.settings.enable_light_sampling != 0;
+            if (!nee || wasSpecular || !sc.env.samplable) {
+                V3 D = xyz(st.rayD[path]);
+                V3 E;
+                if (sc.envConstant) {
+                    E = V3(sc.textures[sc.env.emission_tex].value);
+                } else {
+                    float ux, uy;
+                    directionToUV(sc, D, ux, uy, nullptr);
+                    E = texEval(sc, sc.env.emission_tex, ux, uy);
                 }
+                em += tp*E;
+                st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
             }
-            st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
         }
-        queueAppend(active, st.endQ, &st.counters[CNT_END], path);
+        st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
     }
 }
 
@@ -640,20 +738,18 @@ TG_DEV int chooseLight(const DScene &sc, const V3 &p, Sampler &smp, float &weigh
 }
 
 template <int CLASS>
-__global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, uint32_t *extNext)
+__global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, int set)
 {
-    const uint32_t count = st.counters[CNT_CLASS0 + CLASS];
+    const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + CLASS)];
+    const uint32_t *list = st.lists[set][1 + CLASS];
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
     const bool neeEnabled = sc.settings.enable_light_sampling != 0;
-    // round the trip count up to whole waves so that ballots in queueAppend see uniform control flow
     const uint32_t stride = gridDim.x*blockDim.x;
-    const uint32_t rounded = (count + 63u) & ~63u;
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
-        bool active = q < count;
-        bool pushShadow = false, pushExt = false, ended = false;
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) {
+        bool pushShadow = false;
         uint32_t path = 0;
-        if (active) {
-            path = st.classQ[CLASS][q];
+        {
+            path = list[q];
             float4 ro = st.rayO[path], rd = st.rayD[path], hw = st.hit[path], tpw = st.tp[path], emw = st.em[path];
             uint4 sw = st.samp[path];
             V3 O = xyz(ro), D = xyz(rd), tp = xyz(tpw), em = xyz(emw);
@@ -856,8 +952,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, uint32_t *e
                             end = END_ZERO;
                         } else {
                             bounce++;
-                            if (bounce < maxBounces) pushExt = true;
-                            else end = END_CHECKED;
+                            if (bounce >= maxBounces) end = END_CHECKED;
                         }
                     }
                 }
@@ -876,11 +971,8 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, uint32_t *e
                 st.em[path] = mk4u(em, smp.scramble);
             }
             st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
-            ended = end != END_ALIVE;
+            st.shFlag[path] = pushShadow ? 1u : 0u;
         }
-        queueAppend(pushShadow, st.shadowQ, &st.counters[CNT_SHADOW], path);
-        queueAppend(pushExt, extNext, &st.counters[CNT_EXT_NEXT], path);
-        queueAppend(ended, st.endQ, &st.counters[CNT_END], path);
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&st.stats[5], (unsigned long long)count);
 }
@@ -890,22 +982,24 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, uint32_t *e
 //   emission += ((0 + L*visL) + B*visB) * weight * throughput   (TraceBase.cpp:383-400,483-494,537-538)
 // =================================================================================================
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st)
+__global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const uint32_t count = st.counters[CNT_SHADOW];
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 1); // every shaded slot; those without NEE rays are skipped
     TraceCounters tc{0, 0};
     uint32_t rays = 0;
     while (true) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&st.counters[CNT_HEAD_SHADOW], 64u);
+        if (lane == 0) base = atomicAdd(&st.counters[CNT(CNT_HEAD_SHADOW)], 64u);
         base = __shfl(base, 0);
         if (base >= count) break;
         uint32_t idx = base + lane;
-        if (idx < count) {
-            uint32_t path = st.shadowQ[idx];
+        uint32_t path = 0;
+        // no `continue` here: the dequeue above must be executed by the whole wave together
+        if (idx < count && listFetch(st, lc, set, 1, idx, path) && st.shFlag[path]) {
             float4 ro = st.rayO[path], a = st.shA[path], b = st.shB[path], c = st.shC[path], d = st.shD[path], e = st.shE[path];
             V3 O = xyz(ro);
             uint32_t endCap = __float_as_uint(d.w);

@@ -55,6 +55,8 @@ struct tgpu_ctx {
     std::thread worker;
     unsigned long long sampleBase = 0, globalCursor = 0;
     uint32_t nCur = 0, freeCount = 0;
+    uint32_t listCount[TG_LISTS] = {0};
+    uint64_t aliveCount = 0;
     int curQ = 0;
     uint32_t ringFree = (1u << TG_RING) - 1u;
     int numCUs = 256;
@@ -198,7 +200,7 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
 
 void resetDequeueHeads(tgpu_ctx *ctx)
 {
-    (void)hipMemsetAsync(ctx->st.counters, 0, CNT_TOTAL*sizeof(uint32_t), ctx->stream);
+    (void)hipMemsetAsync(ctx->st.counters, 0, CNT_TOTAL*TG_CNT_STRIDE*sizeof(uint32_t), ctx->stream);
 }
 
 } // namespace
@@ -218,7 +220,7 @@ int tgpu_init(int device, tgpu_ctx **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->numCUs = prop.multiProcessorCount;
     ctx->maxGrid = ctx->numCUs*8;
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev[0]) != hipSuccess ||
-        hipEventCreate(&ctx->ev[1]) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCounters), CNT_TOTAL*sizeof(uint32_t)) != hipSuccess) {
+        hipEventCreate(&ctx->ev[1]) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCounters), CNT_TOTAL*TG_CNT_STRIDE*sizeof(uint32_t)) != hipSuccess) {
         delete ctx;
         return TGPU_ERR_NO_DEVICE;
     }
@@ -279,6 +281,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     ctx->uploaded = false;
     ctx->sampleBase = ctx->globalCursor = 0;
     ctx->nCur = 0;
+    ctx->aliveCount = 0;
+    for (int l = 0; l < TG_LISTS; ++l) ctx->listCount[l] = 0;
     ctx->curQ = 0;
     ctx->ringFree = (1u << TG_RING) - 1u;
     ctx->sc = DScene{};
@@ -401,16 +405,17 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         for (uint64_t i = 0; i < cap; ++i) ident[i] = uint32_t(i);
         if ((rc = upload(ctx, ctx->stateAllocs, ident.data(), ident.size(), &st.freeQ))) return rc;
     }
-    uint32_t **qs[] = {&st.extQ[0], &st.extQ[1], &st.missQ, &st.shadowQ, &st.endQ, &st.sampleRef};
+    uint32_t **qs[] = {&st.sampleRef, &st.shFlag};
     for (uint32_t **pp : qs)
         if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
-    for (int c = 0; c < TGPU_BSDF_NUM_CLASSES; ++c)
-        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.classQ[c]))) return rc;
-    if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL, &st.counters))) return rc;
+    for (int set = 0; set < 2; ++set)
+        for (int l = 0; l < TG_LISTS; ++l)
+            if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.lists[set][l]))) return rc;
+    if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL*TG_CNT_STRIDE, &st.counters))) return rc;
     if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8, &st.stats))) return rc;
     {
         uint32_t freeInit = uint32_t(cap);
-        HIP_TRY(ctx, hipMemcpy(st.counters + CNT_FREE, &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(st.counters + CNT(CNT_FREE), &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice));
         ctx->freeCount = freeInit;
     }
     ctx->resultSpp = 16;
@@ -447,11 +452,13 @@ static void resetPool(tgpu_ctx *ctx)
     for (uint64_t i = 0; i < ctx->capacity; ++i) ident[i] = uint32_t(i);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemcpy(ctx->st.freeQ, ident.data(), ident.size()*sizeof(uint32_t), hipMemcpyHostToDevice);
-    (void)hipMemset(ctx->st.counters, 0, CNT_TOTAL*sizeof(uint32_t));
+    (void)hipMemset(ctx->st.counters, 0, CNT_TOTAL*TG_CNT_STRIDE*sizeof(uint32_t));
     uint32_t freeInit = uint32_t(ctx->capacity);
-    (void)hipMemcpy(ctx->st.counters + CNT_FREE, &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->st.counters + CNT(CNT_FREE), &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice);
     ctx->freeCount = freeInit;
     ctx->nCur = 0;
+    ctx->aliveCount = 0;
+    for (int l = 0; l < TG_LISTS; ++l) ctx->listCount[l] = 0;
 }
 
 static int driveIteration(tgpu_ctx *ctx)
@@ -488,19 +495,21 @@ static int driveIteration(tgpu_ctx *ctx)
     // jobs whose samples have all been handed out need no entry for g -> job lookups of NEW samples, but
     // the lookup walks start[] in order, so keep them: start[] is increasing and g >= sampleBase.
 
-    (void)hipMemsetAsync(st.counters, 0, CNT_PER_ITER*sizeof(uint32_t), stream);
-    uint32_t *next = st.extQ[ctx->curQ ^ 1];
-    uint32_t *queue = st.extQ[ctx->curQ];
+    const int cur = ctx->curQ, out = cur ^ 1;
+    // zero the output set's list lengths, the two dequeue heads and the claim counter
+    (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0 + out*TG_LISTS), 0, TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(st.counters + CNT(CNT_HEAD_EXT), 0, 3*TG_CNT_STRIDE*sizeof(uint32_t), stream);
     uint32_t nCur = ctx->nCur;
-    // idle slots take admitted samples first and join THIS iteration's extend queue
+    // idle slots on the free list take admitted samples first and join THIS iteration's input (list 0)
     {
         unsigned long long room = limit - ctx->sampleBase;
         uint32_t nStart = uint32_t(std::min<unsigned long long>(room, ctx->freeCount));
         if (nStart) {
             Timer t(ctx, &ctx->stats.other_ms);
             uint32_t freeBase = ctx->freeCount - nStart;
-            hipLaunchKernelGGL(k_refill, dim3(gridFor(ctx, nStart)), dim3(256), 0, stream, sc, st, ring, ctx->sampleBase, nStart, freeBase, queue, nCur);
+            hipLaunchKernelGGL(k_refill, dim3(gridFor(ctx, nStart)), dim3(256), 0, stream, sc, st, ring, cur, ctx->sampleBase, nStart, freeBase, ctx->listCount[0]);
             ctx->freeCount = freeBase;
+            ctx->listCount[0] += nStart;
             ctx->sampleBase += nStart;
             nCur += nStart;
         }
@@ -509,63 +518,79 @@ static int driveIteration(tgpu_ctx *ctx)
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
-            if (count) hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, (const uint32_t *)queue, nCur);
-            else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, (const uint32_t *)queue, nCur);
+            if (count) hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
+            else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
         }
-        ctx->stats.extend_rays += nCur;
         ctx->stats.extend_launches++;
         {
             Timer t(ctx, &ctx->stats.shade_ms);
-            hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st);
-            hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(256), 0, stream, sc, st, next);
-            hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(256), 0, stream, sc, st, next);
-            hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(256), 0, stream, sc, st, next);
-            hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(256), 0, stream, sc, st, next);
+            hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st, out);
+            hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(256), 0, stream, sc, st, out);
+            hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(256), 0, stream, sc, st, out);
+            hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(256), 0, stream, sc, st, out);
+            hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(256), 0, stream, sc, st, out);
         }
         {
             Timer t(ctx, &ctx->stats.shadow_ms);
-            if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st);
+            if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
         }
         ctx->stats.shadow_launches++;
         {
             Timer t(ctx, &ctx->stats.other_ms);
-            hipLaunchKernelGGL(k_retire_regenerate, dim3(grid), dim3(256), 0, stream, sc, st, ring, ctx->sampleBase, limit, next);
+            int g1024 = int(std::min<uint64_t>((uint64_t(nCur) + 1023)/1024, uint64_t(ctx->numCUs)*2));
+            hipLaunchKernelGGL(k_retire_regenerate, dim3(std::max(g1024, 1)), dim3(1024), 0, stream, sc, st, ring, out, ctx->sampleBase, limit);
         }
     }
-    hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*TG_CNT_STRIDE*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = spinSync(stream);
     if (e != hipSuccess) {
         fail(ctx, "wavefront iteration failed: %s", hipGetErrorString(e));
         return TGPU_ERR_HIP;
     }
     const uint32_t *hc = ctx->hostCounters;
-    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] iter nCur=%u next=%u regen=%u end=%u shadow=%u miss=%u base=%llu limit=%llu active=%zu done=[%u %u %u %u]\n", nCur, hc[CNT_EXT_NEXT], hc[CNT_REGEN], hc[CNT_END], hc[CNT_SHADOW], hc[CNT_MISS], ctx->sampleBase, limit, ctx->active.size(), hc[CNT_JOB_DONE0], hc[CNT_JOB_DONE0+1], hc[CNT_JOB_DONE0+2], hc[CNT_JOB_DONE0+3]);
-    if (hc[CNT_EXT_NEXT] > ctx->capacity) { fail(ctx, "internal error: queue overflow (%u > %llu)", hc[CNT_EXT_NEXT], (unsigned long long)ctx->capacity); return TGPU_ERR_HIP; }
-    ctx->nCur = hc[CNT_EXT_NEXT];
-    ctx->curQ ^= 1;
-    ctx->freeCount = hc[CNT_FREE];
-    if (ctx->freeCount > ctx->capacity) { fail(ctx, "internal error: free list overflow"); return TGPU_ERR_HIP; }
+    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] iter in=%u out=[%u %u %u %u %u] claims=%u free=%u base=%llu limit=%llu active=%zu\n", nCur,
+                                      hc[CNT(CNT_LIST0 + out*TG_LISTS)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 1)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 2)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 3)],
+                                      hc[CNT(CNT_LIST0 + out*TG_LISTS + 4)], hc[CNT(CNT_REGEN)], hc[CNT(CNT_FREE)], ctx->sampleBase, limit, ctx->active.size());
+    uint64_t nNext = 0;
+    if (nCur > 0) {
+        for (int l = 0; l < TG_LISTS; ++l) {
+            ctx->listCount[l] = hc[CNT(CNT_LIST0 + out*TG_LISTS + l)];
+            nNext += ctx->listCount[l];
+        }
+        ctx->curQ = out;
+    } else {
+        for (int l = 0; l < TG_LISTS; ++l) nNext += ctx->listCount[l];
+    }
+    const uint32_t dropped = hc[CNT(CNT_FREE)] - ctx->freeCount; // idle slots extend moved to the free list
+    ctx->freeCount = hc[CNT(CNT_FREE)];
+    if (nNext + ctx->freeCount != ctx->capacity) { fail(ctx, "internal error: slot accounting broke (%llu listed + %u free != %llu)", (unsigned long long)nNext, ctx->freeCount, (unsigned long long)ctx->capacity); return TGPU_ERR_HIP; }
+    ctx->stats.extend_rays += nCur - dropped;
     unsigned long long room = limit - ctx->sampleBase;
-    ctx->sampleBase += std::min<unsigned long long>(hc[CNT_REGEN], room);
+    unsigned long long started = std::min<unsigned long long>(hc[CNT(CNT_REGEN)], room);
+    ctx->sampleBase += started;
+    // slots that asked for a sample and did not get one are idle: alive = listed - idle
+    uint64_t idle = hc[CNT(CNT_REGEN)] - started;
+    ctx->nCur = uint32_t(nNext);
+    ctx->aliveCount = nNext - idle;
 
     bool retired = false;
     // retire finished jobs in order
     while (!ctx->active.empty()) {
         tgpu_ctx::Job &j = ctx->active.front();
-        if (hc[CNT_JOB_DONE0 + j.ringSlot] != j.total) break;
+        if (hc[CNT(CNT_JOB_DONE0 + j.ringSlot)] != j.total) break;
         {
             Timer t(ctx, &ctx->stats.other_ms);
             hipLaunchKernelGGL(k_accumulate, dim3(gridFor(ctx, ctx->nPixels)), dim3(256), 0, stream, st, j.ringSlot, j.sppCount);
         }
-        (void)hipMemsetAsync(st.counters + CNT_JOB_DONE0 + j.ringSlot, 0, sizeof(uint32_t), stream);
+        (void)hipMemsetAsync(st.counters + CNT(CNT_JOB_DONE0 + j.ringSlot), 0, sizeof(uint32_t), stream);
         ctx->stats.samples += j.total;
         ctx->ringFree |= 1u << j.ringSlot;
         ctx->active.pop_front();
         retired = true;
     }
     // every iteration must start samples, advance paths or retire a job; anything else is a bookkeeping bug
-    if (nCur == 0 && ctx->nCur == 0 && !retired && !ctx->active.empty()) {
+    if (ctx->aliveCount == 0 && ctx->sampleBase == limit && !retired && !ctx->active.empty()) {
         fail(ctx, "internal error: wavefront stalled with %zu unfinished job(s)", ctx->active.size());
         return TGPU_ERR_HIP;
     }
@@ -586,7 +611,7 @@ static void workerMain(tgpu_ctx *ctx)
             bool more;
             {
                 std::lock_guard<std::mutex> lk(ctx->mtx);
-                more = !ctx->pending.empty() || !ctx->active.empty() || ctx->nCur > 0;
+                more = !ctx->pending.empty() || !ctx->active.empty() || ctx->aliveCount > 0;
             }
             if (!more) break;
             if (ctx->abortFlag.load()) { rc = TGPU_ERR_ABORTED; break; }
@@ -718,10 +743,10 @@ static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, u
         }
         hipError_t e = hipMemcpyAsync(st.rayO, o.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(st.rayD, d.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(st.counters, 0, CNT_PER_ITER*sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(st.counters + CNT(CNT_HEAD_EXT), 0, 3*TG_CNT_STRIDE*sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) {
             if (hits) {
-                hipLaunchKernelGGL((k_extend<false, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, (const uint32_t *)nullptr, m);
+                hipLaunchKernelGGL((k_extend<false, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
                 e = hipMemcpyAsync(hits + base*4, st.hit, size_t(m)*16, hipMemcpyDeviceToHost, ctx->stream);
             } else {
                 hipLaunchKernelGGL(k_occluded_raw, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);

@@ -7,19 +7,26 @@ CXXFLAGS  := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -DTUNGSTEN_AMD
 HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function
 
 HOST_SRC  := tungsten_amd/host/scene.cpp tungsten_amd/host/capi.cpp
+CLI_SRC   := tungsten_amd/host/scene.cpp tungsten_amd/host/integrator.cpp tungsten_amd/host/tungsten_cli.cpp
+CLI_BIN   := tungsten_amd/tungsten_amd_cli
 HOST_LIB  := tungsten_amd/libtungsten_host.so
 CORE_SRC  := tungsten_amd/csrc/tgpu_api.hip
 CORE_DEPS := $(wildcard tungsten_amd/csrc/*.h tungsten_amd/csrc/*.hip include/*.h)
 CORE_LIB  := tungsten_amd/libtungsten_amd.so
 ORACLE_LIB:= oracle/liboracle.so
 
-all: host core oracle
+all: host core oracle cli
+cli: $(CLI_BIN)
 host: $(HOST_LIB)
 core: $(CORE_LIB)
 oracle: $(ORACLE_LIB)
 
 $(HOST_LIB): $(HOST_SRC) $(wildcard tungsten_amd/host/*.hpp) include/tungsten_amd.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lpthread
+
+# the reference-shaped C++ host (Integrator + StandaloneRenderer loop) linked against the C ABI
+$(CLI_BIN): $(CLI_SRC) $(wildcard tungsten_amd/host/*.hpp) $(CORE_LIB)
+	$(CXX) $(CXXFLAGS) -o $@ $(CLI_SRC) -Ltungsten_amd -ltungsten_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -lpthread
 
 $(CORE_LIB): $(CORE_DEPS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CORE_SRC)
@@ -29,5 +36,5 @@ $(ORACLE_LIB): oracle/oracle.cpp oracle/oracle.h include/tungsten_amd.h include/
 	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -mfma -shared -o $@ oracle/oracle.cpp -lpthread
 
 clean:
-	rm -f $(HOST_LIB) $(CORE_LIB) $(ORACLE_LIB)
-.PHONY: all host core oracle clean
+	rm -f $(HOST_LIB) $(CORE_LIB) $(ORACLE_LIB) $(CLI_BIN)
+.PHONY: all host core oracle cli clean

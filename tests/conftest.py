@@ -17,6 +17,7 @@ def pytest_configure(config):
             os.path.join(REPO, "tungsten_amd", "libtungsten_amd.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.run(["make", "-j", "8", "host", "core", "oracle"], cwd=REPO, check=True)
+        subprocess.run(["make", "cli"], cwd=REPO, check=True)
 
 
 @pytest.fixture(scope="session")

@@ -190,3 +190,31 @@ def test_errors_are_reported_not_swallowed(ta, gpu_ctx):
     with pytest.raises(ta.CoreError, match="empty shard"):
         fresh.upload(hs, empty)
     fresh.close()
+
+
+def test_cpp_host_integrator_cli(ta, oracle_py, tmp_path):
+    """The reference-shaped C++ host (Integrator::prepareForRender/startRender/waitForCompletion/saveOutputs
+    driven by the StandaloneRenderer loop) produces the same image as the ctypes harness path."""
+    import json
+    import subprocess
+    from conftest import REPO, ASSETS
+    d = json.load(open(scene_path("materialtest/c2.json")))
+    d["camera"]["resolution"] = [96, 54]
+    d["renderer"].update({"spp": 20, "spp_step": 8, "output_file": "cli.png", "hdr_output_file": "cli.pfm"})
+    for p in d["primitives"]:
+        for key in ("file", "emission"):
+            if isinstance(p.get(key), str):
+                p[key] = os.path.join(ASSETS, "materialtest", p[key])
+    scene_file = tmp_path / "cli_scene.json"
+    scene_file.write_text(json.dumps(d))
+    exe = os.path.join(REPO, "tungsten_amd", "tungsten_amd_cli")
+    r = subprocess.run([exe, "-d", str(tmp_path), str(scene_file)], capture_output=True, text=True,
+                       env=dict(os.environ, TUNGSTEN_AMD_ASSETS=ASSETS))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Completed 20/20 spp" in r.stdout
+    img = ta.load_pfm(tmp_path / "cli.pfm")
+    hs = ta.HostScene(str(scene_file))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    ref, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 20, spp_step=8)
+    assert np.array_equal(img, shard.scatter(ref))
+    assert os.path.getsize(tmp_path / "cli.png") > 1000

@@ -201,7 +201,7 @@ private:
     {
         for (int k = 0; k < 3; ++k) {
             float m = std::max(std::abs(b.lo[k]), std::abs(b.hi[k]));
-            float eps = m*4.8e-7f + 1e-30f;
+            float eps = m*2e-6f + 1e-30f;
             b.lo[k] -= eps;
             b.hi[k] += eps;
         }
@@ -213,6 +213,130 @@ private:
     std::vector<Box> _boxes;
     std::vector<float> _cent;
     std::vector<uint32_t> _order;
+};
+
+
+// ---------------------------------------------------------------------------------------------------
+// BVH4 with 8-bit quantised child boxes (the layout the traversal kernels use).
+//
+// The traversal kernels are bound by the number of divergent load instructions a CU's texture-address
+// path can retire (every lane walks its own node), not by bytes.  A BVH2 step costs 4 x 16-byte loads
+// for 2 child boxes; collapsing to 4 children with boxes quantised to 8 bits in the node's own frame keeps
+// the node at 64 bytes = 4 loads while halving the number of steps per ray.
+//
+//   q0 = (origin.x, origin.y, origin.z, bits(ex | ey << 8 | ez << 16))     scale_a = 2^(e_a - 127)
+//   q1 = bits(LOx, LOy, LOz, HIx)    one byte per child: child c's quantised bound = (W >> 8c) & 255
+//   q2 = bits(HIy, HIz, 0, 0)
+//   q3 = bits(child0, child1, child2, child3)   same encoding as the BVH2; 0xFFFFFFFF = empty slot
+// box_c = [origin + LO*scale, origin + HI*scale] contains the (padded) child box; empty slots hold LO = 255,
+// HI = 0 and can never be hit.  Box tests only steer the traversal: hits are decided by the exact triangle test.
+struct Bvh4 {
+    std::vector<Float4> nodes; // 4 per node
+    uint32_t rootChild = 0x80000000u;
+    int maxDepth = 0;          // in BVH4 levels
+    uint32_t nodeCount = 0;
+};
+
+class Collapser {
+public:
+    explicit Collapser(const Bvh &b) : _b(b) {}
+
+    Bvh4 run()
+    {
+        Bvh4 out;
+        _out = &out;
+        out.rootChild = _b.rootChild;
+        if (!(_b.rootChild & 0x80000000u)) out.rootChild = emit(_b.rootChild, 1);
+        out.nodeCount = uint32_t(out.nodes.size()/4);
+        return out;
+    }
+
+private:
+    struct Child { uint32_t ref; Box box; };
+
+    static uint32_t bitsOf(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+    static float floatOf(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+    void children2(uint32_t node, Child out[2]) const
+    {
+        const Float4 *q = &_b.nodes[size_t(node)*4];
+        out[0].box = Box{{q[0].x, q[0].y, q[0].z}, {q[0].w, q[1].x, q[1].y}};
+        out[1].box = Box{{q[1].z, q[1].w, q[2].x}, {q[2].y, q[2].z, q[2].w}};
+        out[0].ref = bitsOf(q[3].x);
+        out[1].ref = bitsOf(q[3].y);
+    }
+
+    uint32_t emit(uint32_t node2, int depth)
+    {
+        _out->maxDepth = std::max(_out->maxDepth, depth);
+        Child c[4];
+        int n = 2;
+        children2(node2, c);
+        // open the inner child with the largest surface area until four slots are used
+        while (n < 4) {
+            int best = -1;
+            float bestArea = -1.0f;
+            for (int i = 0; i < n; ++i)
+                if (!(c[i].ref & 0x80000000u) && c[i].box.halfArea() > bestArea) { bestArea = c[i].box.halfArea(); best = i; }
+            if (best < 0) break;
+            Child two[2];
+            children2(c[best].ref, two);
+            c[best] = two[0];
+            c[n++] = two[1];
+        }
+        uint32_t idx = uint32_t(_out->nodes.size()/4);
+        _out->nodes.resize(_out->nodes.size() + 4);
+        uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (int i = 0; i < n; ++i) refs[i] = (c[i].ref & 0x80000000u) ? c[i].ref : emit(c[i].ref, depth + 1);
+
+        Box frame;
+        frame.reset();
+        for (int i = 0; i < n; ++i) frame.grow(c[i].box);
+        uint32_t e[3];
+        float scale[3];
+        for (int a = 0; a < 3; ++a) {
+            float ext = frame.hi[a] - frame.lo[a];
+            int ex = 1;
+            if (ext > 0.0f) {
+                int fe;
+                std::frexp(ext/255.0f, &fe); // ext/255 = m * 2^fe, m in [0.5, 1)  -> 2^fe >= ext/255
+                ex = fe + 127;
+            }
+            ex = std::min(std::max(ex, 1), 254);
+            // make sure 255 quanta really cover the extent after float rounding
+            while (ex < 254 && frame.lo[a] + 255.0f*floatOf(uint32_t(ex) << 23) < frame.hi[a]) ++ex;
+            e[a] = uint32_t(ex);
+            scale[a] = floatOf(uint32_t(ex) << 23);
+        }
+        uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int i = 0; i < 4; ++i) {
+            for (int a = 0; a < 3; ++a) {
+                uint32_t ql = 255, qh = 0; // empty slot: inverted box
+                if (i < n) {
+                    float o = frame.lo[a], s = scale[a];
+                    int l = int(std::floor((c[i].box.lo[a] - o)/s));
+                    l = std::min(std::max(l, 0), 255);
+                    while (l > 0 && o + float(l)*s > c[i].box.lo[a]) --l;
+                    int h = int(std::ceil((c[i].box.hi[a] - o)/s));
+                    h = std::min(std::max(h, 0), 255);
+                    while (h < 255 && o + float(h)*s < c[i].box.hi[a]) ++h;
+                    ql = uint32_t(l);
+                    qh = uint32_t(h);
+                }
+                lo[a] |= ql << (8*i);
+                hi[a] |= qh << (8*i);
+            }
+        }
+        Float4 *q = &_out->nodes[size_t(idx)*4];
+        q[0] = {frame.lo[0], frame.lo[1], frame.lo[2], floatOf(e[0] | (e[1] << 8) | (e[2] << 16))};
+        q[1] = {floatOf(lo[0]), floatOf(lo[1]), floatOf(lo[2]), floatOf(hi[0])};
+        q[2] = {floatOf(hi[1]), floatOf(hi[2]), 0.0f, 0.0f};
+        q[3] = {floatOf(refs[0]), floatOf(refs[1]), floatOf(refs[2]), floatOf(refs[3])};
+        return idx;
+    }
+
+    const Bvh &_b;
+    Bvh4 *_out = nullptr;
 };
 
 } // namespace tgpu_bvh

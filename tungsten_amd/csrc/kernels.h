@@ -86,6 +86,21 @@ struct DState {
     uint32_t *fbCount;
 };
 
+// Streaming accesses to the path state: non-temporal, so that the 4 MB L2 of each XCD keeps the BVH
+// and triangle data the traversal re-reads instead of state that is touched once per iteration.
+typedef float tg_f4 __attribute__((ext_vector_type(4)));
+TG_DEV float4 ldStream(const float4 *p)
+{
+    tg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const tg_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+TG_DEV uint32_t ldStream(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+TG_DEV void stStream(float4 *p, const float4 &v)
+{
+    tg_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<tg_f4 *>(p));
+}
+TG_DEV void stStream(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 TG_DEV float4 mk4(const V3 &v, float w) { return make_float4(v.x, v.y, v.z, w); }
 TG_DEV float4 mk4u(const V3 &v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 TG_DEV V3 xyz(const float4 &f) { return V3(f.x, f.y, f.z); }
@@ -123,7 +138,7 @@ TG_DEV bool listFetch(const DState &st, const ListCounts &lc, int set, int first
         if (l < first) continue;
         uint32_t n = lc.n[l];
         if (idx < n) {
-            slot = st.lists[set][l][idx];
+            slot = ldStream(&st.lists[set][l][idx]);
             return true;
         }
         idx -= n;
@@ -322,6 +337,7 @@ TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, const 
     return true;
 }
 
+// Traversal of the quantised BVH4 (bvh_build.h).
 // Closest (ANY = false): lexicographic minimum of (t, soup triangle id) over all valid triangles.
 // Any-hit (ANY = true): returns true at the first valid triangle.
 template <bool ANY, bool COUNT>
@@ -338,41 +354,52 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
     const int maxSp = sc.stackEntries;
     int sp = 0;
     uint32_t node = sc.rootChild;
+    // per-axis choice of the near/far byte plane (bvh_build.h, Bvh4): for a negative direction the near
+    // plane of the box is HI
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     while (true) {
         if (!(node & 0x80000000u)) {
             const float4 *n = sc.nodes + size_t(node)*4;
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
             if (COUNT) tc.nodes++;
-            float a, b;
-            a = TGPU_FMA(q0.x, inv.x, noi.x); b = TGPU_FMA(q0.w, inv.x, noi.x);
-            float mn0 = fminf(a, b), mx0 = fmaxf(a, b);
-            a = TGPU_FMA(q0.y, inv.y, noi.y); b = TGPU_FMA(q1.x, inv.y, noi.y);
-            mn0 = fmaxf(mn0, fminf(a, b)); mx0 = fminf(mx0, fmaxf(a, b));
-            a = TGPU_FMA(q0.z, inv.z, noi.z); b = TGPU_FMA(q1.y, inv.z, noi.z);
-            mn0 = fmaxf(mn0, fminf(a, b)); mx0 = fminf(mx0, fmaxf(a, b));
-            a = TGPU_FMA(q1.z, inv.x, noi.x); b = TGPU_FMA(q2.y, inv.x, noi.x);
-            float mn1 = fminf(a, b), mx1 = fmaxf(a, b);
-            a = TGPU_FMA(q1.w, inv.y, noi.y); b = TGPU_FMA(q2.z, inv.y, noi.y);
-            mn1 = fmaxf(mn1, fminf(a, b)); mx1 = fminf(mx1, fmaxf(a, b));
-            a = TGPU_FMA(q2.x, inv.z, noi.z); b = TGPU_FMA(q2.w, inv.z, noi.z);
-            mn1 = fmaxf(mn1, fminf(a, b)); mx1 = fminf(mx1, fmaxf(a, b));
-            mn0 = fmaxf(mn0, tnear); mx0 = fminf(mx0, bestT);
-            mn1 = fmaxf(mn1, tnear); mx1 = fminf(mx1, bestT);
-            bool h0 = mn0 <= mx0, h1 = mn1 <= mx1;
-            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            if (h0 && h1) {
-                bool swap = mn1 < mn0;
-                uint32_t nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
-                if (sp < maxSp) stack[(sp++)*256] = farC;
-                node = nearC;
-                continue;
-            } else if (h0) {
-                node = c0;
-                continue;
-            } else if (h1) {
-                node = c1;
+            const uint32_t eb = __float_as_uint(q0.w);
+            // t = q*(scale*inv) + (origin - O)*inv, one fma per plane
+            const float ax = __uint_as_float((eb & 0xFFu) << 23)*inv.x, ay = __uint_as_float(((eb >> 8) & 0xFFu) << 23)*inv.y,
+                        az = __uint_as_float(((eb >> 16) & 0xFFu) << 23)*inv.z;
+            const float bx = TGPU_FMA(q0.x, inv.x, noi.x), by = TGPU_FMA(q0.y, inv.y, noi.y), bz = TGPU_FMA(q0.z, inv.z, noi.z);
+            const uint32_t LOx = __float_as_uint(q1.x), LOy = __float_as_uint(q1.y), LOz = __float_as_uint(q1.z);
+            const uint32_t HIx = __float_as_uint(q1.w), HIy = __float_as_uint(q2.x), HIz = __float_as_uint(q2.y);
+            const uint32_t Nx = nx ? HIx : LOx, Fx = nx ? LOx : HIx, Ny = ny ? HIy : LOy, Fy = ny ? LOy : HIy, Nz = nz ? HIz : LOz, Fz = nz ? LOz : HIz;
+            uint32_t key[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int sh = 8*c;
+                float tn = TGPU_FMA(float((Nx >> sh) & 0xFFu), ax, bx);
+                tn = fmaxf(tn, TGPU_FMA(float((Ny >> sh) & 0xFFu), ay, by));
+                tn = fmaxf(tn, TGPU_FMA(float((Nz >> sh) & 0xFFu), az, bz));
+                tn = fmaxf(tn, tnear);
+                float tf = TGPU_FMA(float((Fx >> sh) & 0xFFu), ax, bx);
+                tf = fminf(tf, TGPU_FMA(float((Fy >> sh) & 0xFFu), ay, by));
+                tf = fminf(tf, TGPU_FMA(float((Fz >> sh) & 0xFFu), az, bz));
+                tf = fminf(tf, bestT);
+                // tn >= tnear > 0: its bit pattern orders like the float; the low 2 bits carry the slot
+                key[c] = tn <= tf ? ((__float_as_uint(tn) & ~3u) | uint32_t(c)) : 0xFFFFFFFFu;
+            }
+            // sort the four keys ascending (5-comparator network)
+#define TG_CSWAP(i, j) { uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+            TG_CSWAP(0, 1) TG_CSWAP(2, 3) TG_CSWAP(0, 2) TG_CSWAP(1, 3) TG_CSWAP(1, 2)
+#undef TG_CSWAP
+            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y), c2 = __float_as_uint(q3.z), c3 = __float_as_uint(q3.w);
+#define TG_CHILD(k) (((k) & 3u) == 0u ? c0 : (((k) & 3u) == 1u ? c1 : (((k) & 3u) == 2u ? c2 : c3)))
+            if (key[0] != 0xFFFFFFFFu) {
+                // push the farther hits, farthest first, so that the nearest of them pops first
+                if (key[3] != 0xFFFFFFFFu && sp < maxSp) stack[(sp++)*256] = TG_CHILD(key[3]);
+                if (key[2] != 0xFFFFFFFFu && sp < maxSp) stack[(sp++)*256] = TG_CHILD(key[2]);
+                if (key[1] != 0xFFFFFFFFu && sp < maxSp) stack[(sp++)*256] = TG_CHILD(key[1]);
+                node = TG_CHILD(key[0]);
                 continue;
             }
+#undef TG_CHILD
         } else {
             uint32_t payload = node & 0x7FFFFFFFu;
             uint32_t first = payload >> 2, cnt = (payload & 3u) + 1u;
@@ -513,15 +540,15 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, u
                 else have = listFetch(st, lc, set, 0, idx, path);
             }
             if (have) {
-                bool dead = !RAW && flagsEnd(__float_as_uint(st.tp[path].w)) == END_DEAD;
+                bool dead = !RAW && flagsEnd(__float_as_uint(ldStream(&st.tp[path]).w)) == END_DEAD;
                 if (dead) {
                     cls = 0xFDu;
                 } else {
-                    float4 ro = st.rayO[path], rd = st.rayD[path];
+                    float4 ro = ldStream(&st.rayO[path]), rd = ldStream(&st.rayD[path]);
                     V3 O = xyz(ro), D = xyz(rd);
                     float tfar = rd.w, u = 0.0f, v = 0.0f;
                     uint32_t prim = closestHit<COUNT>(sc, stack, O, D, ro.w, tfar, u, v, tc);
-                    st.hit[path] = make_float4(tfar, u, v, __uint_as_float(prim));
+                    stStream(&st.hit[path], make_float4(tfar, u, v, __uint_as_float(prim)));
                     if (!RAW) cls = hitClass(sc, prim);
                 }
             }
@@ -546,10 +573,10 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, u
                 if (lane == 0) wbase = atomicAdd(ctr, n);
                 wbase = __shfl(wbase, 0);
                 const unsigned long long below = (1ull << lane) - 1ull;
-                if ((m0 >> lane) & 1ull) dst[wbase + uint32_t(__builtin_popcountll(m0 & below))] = p0;
-                if ((m1 >> lane) & 1ull) dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))] = p1;
-                if ((m2 >> lane) & 1ull) dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))] = p2;
-                if ((m3 >> lane) & 1ull) dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))] = p3;
+                if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p0);
+                if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p1);
+                if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p2);
+                if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p3);
             }
         }
     }
@@ -999,8 +1026,8 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
         uint32_t idx = base + lane;
         uint32_t path = 0;
         // no `continue` here: the dequeue above must be executed by the whole wave together
-        if (idx < count && listFetch(st, lc, set, 1, idx, path) && st.shFlag[path]) {
-            float4 ro = st.rayO[path], a = st.shA[path], b = st.shB[path], c = st.shC[path], d = st.shD[path], e = st.shE[path];
+        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) {
+            float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
             V3 O = xyz(ro);
             uint32_t endCap = __float_as_uint(d.w);
             V3 result(0.0f);
@@ -1012,11 +1039,11 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
                 rays++;
                 if (!occluded<COUNT>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
             }
-            float4 emw = st.em[path];
+            float4 emw = ldStream(&st.em[path]);
             V3 em = xyz(emw);
             em += (result*c.w)*xyz(e);
-            if (__float_as_uint(e.w) & 1u) em += xyz(st.shF[path]);
-            st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
+            if (__float_as_uint(e.w) & 1u) em += xyz(ldStream(&st.shF[path]));
+            stStream(&st.em[path], make_float4(em.x, em.y, em.z, emw.w));
         }
     }
     if (COUNT) flushCounters(st.stats, 2, tc);

@@ -294,19 +294,23 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     // ---- BVH ----
     tgpu_bvh::Builder builder(s->tri_pos, s->n_tris);
     tgpu_bvh::Bvh bvh = builder.build();
+    // collapse to the quantised BVH4 the kernels traverse (bvh_build.h)
+    tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run();
     sc.nTris = s->n_tris;
-    sc.rootChild = bvh.rootChild;
-    sc.stackEntries = bvh.maxDepth + 2;
+    sc.rootChild = bvh4.rootChild;
+    sc.stackEntries = 3*bvh4.maxDepth + 2; // at most 3 pushes per level
+    if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
+    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] bvh2: %u nodes depth %d -> bvh4: %u nodes depth %d, stack entries %d\n", bvh.nodeCount, bvh.maxDepth, bvh4.nodeCount, bvh4.maxDepth, sc.stackEntries);
     float4 *dNodes, *dTris;
     uint32_t *dTriId;
-    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh.nodes.data()), bvh.nodes.size(), &dNodes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh4.nodes.data()), bvh4.nodes.size(), &dNodes))) return rc;
     if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh.tris.data()), bvh.tris.size(), &dTris))) return rc;
     if ((rc = upload(ctx, ctx->allocs, bvh.triId.data(), bvh.triId.size(), &dTriId))) return rc;
     sc.nodes = dNodes;
     sc.tris = dTris;
     sc.triId = dTriId;
     ctx->ldsBytes = size_t(sc.stackEntries)*256*sizeof(uint32_t);
-    if (ctx->ldsBytes > 160*1024) { fail(ctx, "BVH depth %d needs more LDS than a CU has", bvh.maxDepth); return TGPU_ERR_UNSUPPORTED; }
+    if (ctx->ldsBytes > 160*1024) { fail(ctx, "BVH depth %d needs more LDS than a CU has", bvh4.maxDepth); return TGPU_ERR_UNSUPPORTED; }
 
     // ---- shading records ----
     std::vector<tgpu_bvh::Float4> shade(size_t(s->n_tris)*5);

@@ -196,6 +196,7 @@ typedef struct tgpu_stats {
     uint64_t surface_events;
     double   extend_ms, shadow_ms, shade_ms, other_ms; /* HIP-event kernel time, when timing on */
     uint64_t extend_launches, shadow_launches;
+    uint64_t tail_launches;    /* fused tail-kernel launches                  */
 } tgpu_stats;
 
 typedef struct tgpu_ctx tgpu_ctx;

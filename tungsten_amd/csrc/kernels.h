@@ -78,7 +78,7 @@ struct DState {
     uint32_t *counters;
     uint32_t nPixels;
     uint32_t resultSlice; // samples per ring slot = nPixels * resultSpp
-    unsigned long long *stats; // [0] ext nodes [1] ext tris [2] shadow nodes [3] shadow tris [4] shadow rays [5] surface events
+    unsigned long long *stats; // [0] ext nodes [1] ext tris [2] shadow nodes [3] shadow tris [4] shadow rays [5] surface events [6] extend rays traced by the tail kernel
     // shard
     const uint32_t *pixelIndex;
     const uint32_t *scramble;
@@ -586,41 +586,43 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, u
 // =================================================================================================
 // K5 miss: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) + end of traceSample
 // =================================================================================================
+TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
+{
+    float4 tpw = st.tp[path];
+    uint32_t flags = __float_as_uint(tpw.w);
+    if (flagsEnd(flags) != END_ALIVE) return; // slot without a live path (refilled later)
+    float4 emw = st.em[path];
+    V3 tp = xyz(tpw), em = xyz(emw);
+    int bounce = flagsBounce(flags);
+    bool wasSpecular = flagsSpecular(flags);
+    int end = END_CHECKED;
+    // per-bounce NaN guard of the previous vertex (PathTracer.cpp:121-122), evaluated once its NEE is in
+    if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
+        end = END_ZERO;
+    } else if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
+        bool nee = sc.settings.enable_light_sampling != 0;
+        if (!nee || wasSpecular || !sc.env.samplable) {
+            V3 D = xyz(st.rayD[path]);
+            V3 E;
+            if (sc.envConstant) {
+                E = V3(sc.textures[sc.env.emission_tex].value);
+            } else {
+                float ux, uy;
+                directionToUV(sc, D, ux, uy, nullptr);
+                E = texEval(sc, sc.env.emission_tex, ux, uy);
+            }
+            em += tp*E;
+            st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
+        }
+    }
+    st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
+}
+
 __global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS)];
     const uint32_t *list = st.lists[set][0];
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) {
-        uint32_t path = list[q];
-        float4 tpw = st.tp[path];
-        uint32_t flags = __float_as_uint(tpw.w);
-        if (flagsEnd(flags) != END_ALIVE) continue; // slot without a live path (refilled later)
-        float4 emw = st.em[path];
-        V3 tp = xyz(tpw), em = xyz(emw);
-        int bounce = flagsBounce(flags);
-        bool wasSpecular = flagsSpecular(flags);
-        int end = END_CHECKED;
-        // per-bounce NaN guard of the previous vertex (PathTracer.cpp:121-122), evaluated once its NEE is in
-        if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
-            end = END_ZERO;
-        } else if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
-            bool nee = sc.settings.enable_light_sampling != 0;
-            if (!nee || wasSpecular || !sc.env.samplable) {
-                V3 D = xyz(st.rayD[path]);
-                V3 E;
-                if (sc.envConstant) {
-                    E = V3(sc.textures[sc.env.emission_tex].value);
-                } else {
-                    float ux, uy;
-                    directionToUV(sc, D, ux, uy, nullptr);
-                    E = texEval(sc, sc.env.emission_tex, ux, uy);
-                }
-                em += tp*E;
-                st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
-            }
-        }
-        st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
-    }
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) missPath(sc, st, list[q]);
 }
 
 // =================================================================================================
@@ -764,243 +766,244 @@ TG_DEV int chooseLight(const DScene &sc, const V3 &p, Sampler &smp, float &weigh
     return result;
 }
 
+// One surface vertex of one path (the body of the shade kernels; the tail kernel calls it too):
+// TraceBase::handleSurface + the loop tail of PathTracer::traceSample.
+TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
+{
+    const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
+    const bool neeEnabled = sc.settings.enable_light_sampling != 0;
+    bool pushShadow = false;
+    float4 ro = st.rayO[path], rd = st.rayD[path], hw = st.hit[path], tpw = st.tp[path], emw = st.em[path];
+    uint4 sw = st.samp[path];
+    V3 O = xyz(ro), D = xyz(rd), tp = xyz(tpw), em = xyz(emw);
+    uint32_t flags = __float_as_uint(tpw.w);
+    int bounce = flagsBounce(flags);
+    bool wasSpecular = flagsSpecular(flags);
+    int end = END_ALIVE;
+
+    if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
+        end = END_ZERO; // PathTracer.cpp:121-122 for the previous vertex
+    } else {
+        Sampler smp;
+        smp.matrices = sc.sobol;
+        smp.sobol = sc.settings.use_sobol;
+        smp.dimension = sw.x;
+        smp.pcg = (uint64_t(sw.z) << 32) | uint64_t(sw.y);
+        smp.scramble = __float_as_uint(emw.w); // em.w carries the Sobol scramble, samp.w the sample index
+        smp.index = sw.w;
+
+        uint32_t prim = __float_as_uint(hw.w);
+        HitInfo info;
+        fetchHitInfo(sc, prim, O, D, hw.x, hw.y, hw.z, info);
+        const tgpu_bsdf &bsdf = sc.bsdfs[info.bsdf];
+        const uint32_t lobes = bsdfLobes(sc, bsdf);
+
+        // makeLocalScatterEvent (TraceBase.cpp:24-51)
+        Event ev;
+        ev.frame = duffFrame(info.Ns);
+        bool hitBackside = ev.frame.normal.dot(D) > 0.0f;
+        bool flipFrame = sc.settings.enable_two_sided_shading && hitBackside && !(lobes & TransmissiveLobe);
+        if (flipFrame) {
+            ev.frame.normal = -ev.frame.normal;
+            ev.frame.tangent = -ev.frame.tangent;
+        }
+        ev.wi = ev.frame.toLocal(-D);
+        ev.wo = V3(0.0f);
+        ev.weight = V3(1.0f);
+        ev.pdf = 1.0f;
+        ev.uvx = info.uvx;
+        ev.uvy = info.uvy;
+        ev.flippedFrame = flipFrame;
+        ev.sampledLobe = 0;
+
+        // handleSurface (TraceBase.cpp:516-568): forward-lobe test draws from the supplemental
+        // stream for every surface hit; none of the BSDFs in scope has a forward lobe -> pTrue = 0
+        (void)smp.nextBoolean(0.0f);
+
+        const float eps = 5e-4f; // TraceableScene.hpp:39
+        V3 L(0.0f), B(0.0f);
+        float tfarL = -1.0f, tfarB = -1.0f, pickWeight = 1.0f;
+        V3 dL(0.0f), dB(0.0f);
+        uint32_t endCap = PRIM_MISS;
+        const V3 tpVertex = tp;
+
+        if (neeEnabled && bounce < maxBounces - 1 && sc.nLights > 0) {
+            // estimateDirect -> chooseLight (TraceBase.cpp:416-459)
+            int lightIdx = chooseLight(sc, info.p, smp, pickWeight);
+            bool haveLight = lightIdx >= 0;
+            bool pureSpecular = lobes != 0 && (lobes & ~uint32_t(SpecularLobe)) == 0;
+            if (haveLight && !pureSpecular && lobes != ForwardLobe) { // sampleDirect (TraceBase.cpp:383-400)
+                const tgpu_light light = sc.lights[lightIdx];
+                const bool isEnv = light.kind == TGPU_LIGHT_ENV;
+                endCap = isEnv ? ((KIND_ENV << 30) | 0u) : ((KIND_QUAD << 30) | uint32_t(light.index));
+                const bool shadowPasses = bounce + 1 >= minBounces; // generalizedShadowRay's minBounces rule
+
+                // ---- lightSample (TraceBase.cpp:246-285) ----
+                {
+                    LightSample ls;
+                    bool ok = isEnv ? envSampleDirect(sc, smp, ls) : quadSampleDirect(sc.quads[light.index], info.p, smp, ls);
+                    if (ok) {
+                        ev.wo = ev.frame.toLocal(ls.d);
+                        bool consistent = true;
+                        if (sc.settings.enable_consistency_checks) {
+                            bool geometricBackside = ls.d.dot(info.Ng) < 0.0f;
+                            bool shadingBackside = (ev.wo.z < 0.0f) ^ ev.flippedFrame;
+                            consistent = geometricBackside == shadingBackside;
+                        }
+                        ev.requestedLobe = AllButSpecular;
+                        V3 f = consistent ? bsdfEval(sc, bsdf, ev) : V3(0.0f);
+                        if (!f.isZero()) {
+                            // attenuatedEmission (TraceBase.cpp:144-174) up to the shadow test
+                            V3 E(0.0f);
+                            float farT = TG_INF;
+                            bool lit = true;
+                            if (isEnv) {
+                                float ux, uy;
+                                if (sc.envConstant) E = V3(sc.textures[sc.env.emission_tex].value);
+                                else { directionToUV(sc, ls.d, ux, uy, nullptr); E = texEval(sc, sc.env.emission_tex, ux, uy); }
+                            } else {
+                                QuadHit qh;
+                                const tgpu_quad &lq = sc.quads[light.index];
+                                lit = quadIntersect(lq, info.p, ls.d, eps, TG_INF, qh) && !(qh.t*(1.0f + 1e-3f) < ls.dist);
+                                if (lit) {
+                                    farT = qh.t;
+                                    E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
+                                }
+                            }
+                            if (lit && shadowPasses && !E.isZero()) {
+                                V3 lightF = f*E/ls.pdf;
+                                lightF *= powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
+                                L = lightF;
+                                dL = ls.d;
+                                tfarL = farT;
+                            }
+                        }
+                    }
+                }
+                // ---- bsdfSample (TraceBase.cpp:287-321) ----
+                {
+                    ev.requestedLobe = AllButSpecular;
+                    if (bsdfSample(sc, bsdf, ev, smp) && !ev.weight.isZero()) {
+                        V3 wo = ev.frame.toGlobal(ev.wo);
+                        bool consistent = true;
+                        if (sc.settings.enable_consistency_checks) {
+                            bool geometricBackside = wo.dot(info.Ng) < 0.0f;
+                            bool shadingBackside = (ev.wo.z < 0.0f) ^ ev.flippedFrame;
+                            consistent = geometricBackside == shadingBackside;
+                        }
+                        if (consistent) {
+                            V3 E(0.0f);
+                            float farT = TG_INF, lightPdf = 0.0f;
+                            bool lit = true;
+                            if (isEnv) {
+                                float ux, uy;
+                                lightPdf = envDirectPdf(sc, wo, ux, uy);
+                                E = sc.envConstant ? V3(sc.textures[sc.env.emission_tex].value) : texEval(sc, sc.env.emission_tex, ux, uy);
+                            } else {
+                                QuadHit qh;
+                                const tgpu_quad &lq = sc.quads[light.index];
+                                lit = quadIntersect(lq, info.p, wo, eps, TG_INF, qh); // expectedDist = -1 never rejects
+                                if (lit) {
+                                    farT = qh.t;
+                                    E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
+                                    V3 normal(lq.normal);
+                                    float cosTheta = __builtin_fabsf(normal.dot(wo));
+                                    float tq = normal.dot(V3(lq.base) - info.p)/normal.dot(wo);
+                                    lightPdf = tq*tq/(cosTheta*lq.area);
+                                }
+                            }
+                            if (lit && shadowPasses && !E.isZero()) {
+                                V3 bsdfF = E*ev.weight;
+                                bsdfF *= powerHeuristic(ev.pdf, lightPdf);
+                                B = bsdfF;
+                                dB = wo;
+                                tfarB = farT;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        pushShadow = tfarL >= 0.0f || tfarB >= 0.0f;
+
+        // emitter hit (TraceBase.cpp:540-543): added after the NEE term, as the reference does
+        V3 postAdd(0.0f);
+        bool hasPostAdd = false;
+        if (info.emissive && bounce >= minBounces) {
+            if (!neeEnabled || wasSpecular) { // every emissive primitive in scope is samplable
+                V3 Ed = info.backSide ? V3(0.0f) : texEval(sc, info.emissionTex, info.uvx, info.uvy);
+                postAdd = Ed*tp;
+                hasPostAdd = true;
+            }
+        }
+        if (hasPostAdd && !pushShadow) em += postAdd;
+
+        // continuation (TraceBase.cpp:546-565)
+        ev.requestedLobe = AllLobes;
+        bool sampled = bsdfSample(sc, bsdf, ev, smp);
+        V3 wo(0.0f);
+        bool alive = sampled;
+        if (sampled) {
+            wo = ev.frame.toGlobal(ev.wo);
+            if (sc.settings.enable_consistency_checks) {
+                bool geometricBackside = wo.dot(info.Ng) < 0.0f;
+                bool shadingBackside = (ev.wo.z < 0.0f) ^ ev.flippedFrame;
+                alive = geometricBackside == shadingBackside;
+            }
+        }
+        V3 hitpoint = O + D*hw.x;
+        if (!alive) {
+            end = END_RAW; // handleSurface returned false -> `return emission`
+        } else {
+            tp *= ev.weight;
+            wasSpecular = (ev.sampledLobe & SpecularLobe) != 0;
+            // PathTracer.cpp:108-126
+            if (tp.max() == 0.0f) {
+                end = END_CHECKED; // break: the environment term is throughput(=0)*E
+            } else {
+                float roulettePdf = vabs(tp).max();
+                bool cont = true;
+                if (bounce > 2 && roulettePdf < 0.1f) {
+                    if (smp.nextBoolean(roulettePdf))
+                        tp /= roulettePdf;
+                    else
+                        cont = false;
+                }
+                if (!cont) {
+                    end = END_RAW;
+                } else if (isnanf_(wo.sum() + hitpoint.sum())) {
+                    end = END_ZERO;
+                } else {
+                    bounce++;
+                    if (bounce >= maxBounces) end = END_CHECKED;
+                }
+            }
+        }
+        // NEE rays start at info.p, which for every primitive kind has the bits of the scatter origin
+        st.rayO[path] = mk4(hitpoint, eps);
+        st.rayD[path] = mk4(wo, TG_INF);
+        st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
+        if (pushShadow) {
+            st.shA[path] = mk4(dL, tfarL);
+            st.shB[path] = mk4(dB, tfarB);
+            st.shC[path] = mk4(L, pickWeight);
+            st.shD[path] = mk4u(B, endCap);
+            st.shE[path] = mk4u(tpVertex, hasPostAdd ? 1u : 0u);
+            if (hasPostAdd) st.shF[path] = mk4(postAdd, 0.0f);
+        }
+        st.em[path] = mk4u(em, smp.scramble);
+    }
+    st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
+    st.shFlag[path] = pushShadow ? 1u : 0u;
+}
+
 template <int CLASS>
 __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + CLASS)];
     const uint32_t *list = st.lists[set][1 + CLASS];
-    const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
-    const bool neeEnabled = sc.settings.enable_light_sampling != 0;
     const uint32_t stride = gridDim.x*blockDim.x;
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) {
-        bool pushShadow = false;
-        uint32_t path = 0;
-        {
-            path = list[q];
-            float4 ro = st.rayO[path], rd = st.rayD[path], hw = st.hit[path], tpw = st.tp[path], emw = st.em[path];
-            uint4 sw = st.samp[path];
-            V3 O = xyz(ro), D = xyz(rd), tp = xyz(tpw), em = xyz(emw);
-            uint32_t flags = __float_as_uint(tpw.w);
-            int bounce = flagsBounce(flags);
-            bool wasSpecular = flagsSpecular(flags);
-            int end = END_ALIVE;
-
-            if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
-                end = END_ZERO; // PathTracer.cpp:121-122 for the previous vertex
-            } else {
-                Sampler smp;
-                smp.matrices = sc.sobol;
-                smp.sobol = sc.settings.use_sobol;
-                smp.dimension = sw.x;
-                smp.pcg = (uint64_t(sw.z) << 32) | uint64_t(sw.y);
-                smp.scramble = __float_as_uint(emw.w); // em.w carries the Sobol scramble, samp.w the sample index
-                smp.index = sw.w;
-
-                uint32_t prim = __float_as_uint(hw.w);
-                HitInfo info;
-                fetchHitInfo(sc, prim, O, D, hw.x, hw.y, hw.z, info);
-                const tgpu_bsdf &bsdf = sc.bsdfs[info.bsdf];
-                const uint32_t lobes = bsdfLobes(sc, bsdf);
-
-                // makeLocalScatterEvent (TraceBase.cpp:24-51)
-                Event ev;
-                ev.frame = duffFrame(info.Ns);
-                bool hitBackside = ev.frame.normal.dot(D) > 0.0f;
-                bool flipFrame = sc.settings.enable_two_sided_shading && hitBackside && !(lobes & TransmissiveLobe);
-                if (flipFrame) {
-                    ev.frame.normal = -ev.frame.normal;
-                    ev.frame.tangent = -ev.frame.tangent;
-                }
-                ev.wi = ev.frame.toLocal(-D);
-                ev.wo = V3(0.0f);
-                ev.weight = V3(1.0f);
-                ev.pdf = 1.0f;
-                ev.uvx = info.uvx;
-                ev.uvy = info.uvy;
-                ev.flippedFrame = flipFrame;
-                ev.sampledLobe = 0;
-
-                // handleSurface (TraceBase.cpp:516-568): forward-lobe test draws from the supplemental
-                // stream for every surface hit; none of the BSDFs in scope has a forward lobe -> pTrue = 0
-                (void)smp.nextBoolean(0.0f);
-
-                const float eps = 5e-4f; // TraceableScene.hpp:39
-                V3 L(0.0f), B(0.0f);
-                float tfarL = -1.0f, tfarB = -1.0f, pickWeight = 1.0f;
-                V3 dL(0.0f), dB(0.0f);
-                uint32_t endCap = PRIM_MISS;
-                const V3 tpVertex = tp;
-
-                if (neeEnabled && bounce < maxBounces - 1 && sc.nLights > 0) {
-                    // estimateDirect -> chooseLight (TraceBase.cpp:416-459)
-                    int lightIdx = chooseLight(sc, info.p, smp, pickWeight);
-                    bool haveLight = lightIdx >= 0;
-                    bool pureSpecular = lobes != 0 && (lobes & ~uint32_t(SpecularLobe)) == 0;
-                    if (haveLight && !pureSpecular && lobes != ForwardLobe) { // sampleDirect (TraceBase.cpp:383-400)
-                        const tgpu_light light = sc.lights[lightIdx];
-                        const bool isEnv = light.kind == TGPU_LIGHT_ENV;
-                        endCap = isEnv ? ((KIND_ENV << 30) | 0u) : ((KIND_QUAD << 30) | uint32_t(light.index));
-                        const bool shadowPasses = bounce + 1 >= minBounces; // generalizedShadowRay's minBounces rule
-
-                        // ---- lightSample (TraceBase.cpp:246-285) ----
-                        {
-                            LightSample ls;
-                            bool ok = isEnv ? envSampleDirect(sc, smp, ls) : quadSampleDirect(sc.quads[light.index], info.p, smp, ls);
-                            if (ok) {
-                                ev.wo = ev.frame.toLocal(ls.d);
-                                bool consistent = true;
-                                if (sc.settings.enable_consistency_checks) {
-                                    bool geometricBackside = ls.d.dot(info.Ng) < 0.0f;
-                                    bool shadingBackside = (ev.wo.z < 0.0f) ^ ev.flippedFrame;
-                                    consistent = geometricBackside == shadingBackside;
-                                }
-                                ev.requestedLobe = AllButSpecular;
-                                V3 f = consistent ? bsdfEval(sc, bsdf, ev) : V3(0.0f);
-                                if (!f.isZero()) {
-                                    // attenuatedEmission (TraceBase.cpp:144-174) up to the shadow test
-                                    V3 E(0.0f);
-                                    float farT = TG_INF;
-                                    bool lit = true;
-                                    if (isEnv) {
-                                        float ux, uy;
-                                        if (sc.envConstant) E = V3(sc.textures[sc.env.emission_tex].value);
-                                        else { directionToUV(sc, ls.d, ux, uy, nullptr); E = texEval(sc, sc.env.emission_tex, ux, uy); }
-                                    } else {
-                                        QuadHit qh;
-                                        const tgpu_quad &lq = sc.quads[light.index];
-                                        lit = quadIntersect(lq, info.p, ls.d, eps, TG_INF, qh) && !(qh.t*(1.0f + 1e-3f) < ls.dist);
-                                        if (lit) {
-                                            farT = qh.t;
-                                            E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
-                                        }
-                                    }
-                                    if (lit && shadowPasses && !E.isZero()) {
-                                        V3 lightF = f*E/ls.pdf;
-                                        lightF *= powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
-                                        L = lightF;
-                                        dL = ls.d;
-                                        tfarL = farT;
-                                    }
-                                }
-                            }
-                        }
-                        // ---- bsdfSample (TraceBase.cpp:287-321) ----
-                        {
-                            ev.requestedLobe = AllButSpecular;
-                            if (bsdfSample(sc, bsdf, ev, smp) && !ev.weight.isZero()) {
-                                V3 wo = ev.frame.toGlobal(ev.wo);
-                                bool consistent = true;
-                                if (sc.settings.enable_consistency_checks) {
-                                    bool geometricBackside = wo.dot(info.Ng) < 0.0f;
-                                    bool shadingBackside = (ev.wo.z < 0.0f) ^ ev.flippedFrame;
-                                    consistent = geometricBackside == shadingBackside;
-                                }
-                                if (consistent) {
-                                    V3 E(0.0f);
-                                    float farT = TG_INF, lightPdf = 0.0f;
-                                    bool lit = true;
-                                    if (isEnv) {
-                                        float ux, uy;
-                                        lightPdf = envDirectPdf(sc, wo, ux, uy);
-                                        E = sc.envConstant ? V3(sc.textures[sc.env.emission_tex].value) : texEval(sc, sc.env.emission_tex, ux, uy);
-                                    } else {
-                                        QuadHit qh;
-                                        const tgpu_quad &lq = sc.quads[light.index];
-                                        lit = quadIntersect(lq, info.p, wo, eps, TG_INF, qh); // expectedDist = -1 never rejects
-                                        if (lit) {
-                                            farT = qh.t;
-                                            E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
-                                            V3 normal(lq.normal);
-                                            float cosTheta = __builtin_fabsf(normal.dot(wo));
-                                            float tq = normal.dot(V3(lq.base) - info.p)/normal.dot(wo);
-                                            lightPdf = tq*tq/(cosTheta*lq.area);
-                                        }
-                                    }
-                                    if (lit && shadowPasses && !E.isZero()) {
-                                        V3 bsdfF = E*ev.weight;
-                                        bsdfF *= powerHeuristic(ev.pdf, lightPdf);
-                                        B = bsdfF;
-                                        dB = wo;
-                                        tfarB = farT;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                pushShadow = tfarL >= 0.0f || tfarB >= 0.0f;
-
-                // emitter hit (TraceBase.cpp:540-543): added after the NEE term, as the reference does
-                V3 postAdd(0.0f);
-                bool hasPostAdd = false;
-                if (info.emissive && bounce >= minBounces) {
-                    if (!neeEnabled || wasSpecular) { // every emissive primitive in scope is samplable
-                        V3 Ed = info.backSide ? V3(0.0f) : texEval(sc, info.emissionTex, info.uvx, info.uvy);
-                        postAdd = Ed*tp;
-                        hasPostAdd = true;
-                    }
-                }
-                if (hasPostAdd && !pushShadow) em += postAdd;
-
-                // continuation (TraceBase.cpp:546-565)
-                ev.requestedLobe = AllLobes;
-                bool sampled = bsdfSample(sc, bsdf, ev, smp);
-                V3 wo(0.0f);
-                bool alive = sampled;
-                if (sampled) {
-                    wo = ev.frame.toGlobal(ev.wo);
-                    if (sc.settings.enable_consistency_checks) {
-                        bool geometricBackside = wo.dot(info.Ng) < 0.0f;
-                        bool shadingBackside = (ev.wo.z < 0.0f) ^ ev.flippedFrame;
-                        alive = geometricBackside == shadingBackside;
-                    }
-                }
-                V3 hitpoint = O + D*hw.x;
-                if (!alive) {
-                    end = END_RAW; // handleSurface returned false -> `return emission`
-                } else {
-                    tp *= ev.weight;
-                    wasSpecular = (ev.sampledLobe & SpecularLobe) != 0;
-                    // PathTracer.cpp:108-126
-                    if (tp.max() == 0.0f) {
-                        end = END_CHECKED; // break: the environment term is throughput(=0)*E
-                    } else {
-                        float roulettePdf = vabs(tp).max();
-                        bool cont = true;
-                        if (bounce > 2 && roulettePdf < 0.1f) {
-                            if (smp.nextBoolean(roulettePdf))
-                                tp /= roulettePdf;
-                            else
-                                cont = false;
-                        }
-                        if (!cont) {
-                            end = END_RAW;
-                        } else if (isnanf_(wo.sum() + hitpoint.sum())) {
-                            end = END_ZERO;
-                        } else {
-                            bounce++;
-                            if (bounce >= maxBounces) end = END_CHECKED;
-                        }
-                    }
-                }
-                // NEE rays start at info.p, which for every primitive kind has the bits of the scatter origin
-                st.rayO[path] = mk4(hitpoint, eps);
-                st.rayD[path] = mk4(wo, TG_INF);
-                st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
-                if (pushShadow) {
-                    st.shA[path] = mk4(dL, tfarL);
-                    st.shB[path] = mk4(dB, tfarB);
-                    st.shC[path] = mk4(L, pickWeight);
-                    st.shD[path] = mk4u(B, endCap);
-                    st.shE[path] = mk4u(tpVertex, hasPostAdd ? 1u : 0u);
-                    if (hasPostAdd) st.shF[path] = mk4(postAdd, 0.0f);
-                }
-                st.em[path] = mk4u(em, smp.scramble);
-            }
-            st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
-            st.shFlag[path] = pushShadow ? 1u : 0u;
-        }
-    }
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) shadePath(sc, st, list[q]);
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&st.stats[5], (unsigned long long)count);
 }
 
@@ -1008,6 +1011,29 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, int set)
 // K4 shadow: both NEE rays of a vertex are traced by one lane, then resolved in the reference's order
 //   emission += ((0 + L*visL) + B*visB) * weight * throughput   (TraceBase.cpp:383-400,483-494,537-538)
 // =================================================================================================
+// Both NEE rays of the path's current vertex, then the resolve (body of the shadow kernel and of the tail kernel)
+template <bool COUNT>
+TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint32_t path, TraceCounters &tc, uint32_t &rays)
+{
+    float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
+    V3 O = xyz(ro);
+    uint32_t endCap = __float_as_uint(d.w);
+    V3 result(0.0f);
+    if (a.w >= 0.0f) {
+        rays++;
+        if (!occluded<COUNT>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
+    }
+    if (b.w >= 0.0f) {
+        rays++;
+        if (!occluded<COUNT>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
+    }
+    float4 emw = ldStream(&st.em[path]);
+    V3 em = xyz(emw);
+    em += (result*c.w)*xyz(e);
+    if (__float_as_uint(e.w) & 1u) em += xyz(ldStream(&st.shF[path]));
+    stStream(&st.em[path], make_float4(em.x, em.y, em.z, emw.w));
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
 {
@@ -1026,25 +1052,7 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
         uint32_t idx = base + lane;
         uint32_t path = 0;
         // no `continue` here: the dequeue above must be executed by the whole wave together
-        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) {
-            float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
-            V3 O = xyz(ro);
-            uint32_t endCap = __float_as_uint(d.w);
-            V3 result(0.0f);
-            if (a.w >= 0.0f) {
-                rays++;
-                if (!occluded<COUNT>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
-            }
-            if (b.w >= 0.0f) {
-                rays++;
-                if (!occluded<COUNT>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
-            }
-            float4 emw = ldStream(&st.em[path]);
-            V3 em = xyz(emw);
-            em += (result*c.w)*xyz(e);
-            if (__float_as_uint(e.w) & 1u) em += xyz(ldStream(&st.shF[path]));
-            stStream(&st.em[path], make_float4(em.x, em.y, em.z, emw.w));
-        }
+        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) shadowPath<COUNT>(sc, st, stack, path, tc, rays);
     }
     if (COUNT) flushCounters(st.stats, 2, tc);
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
@@ -1060,6 +1068,81 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
     for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < count; i += gridDim.x*blockDim.x) {
         float4 ro = st.rayO[i], rd = st.rayD[i];
         out[i] = occluded<false>(sc, stack, xyz(ro), xyz(rd), ro.w, rd.w, PRIM_MISS, tc) ? 1 : 0;
+    }
+}
+
+// =================================================================================================
+// Tail kernel.  When no sample is left to start and only a few thousand long paths remain, finishing them
+// with one launch per bounce costs ~0.4 ms of latency per iteration for ~60 iterations.  Instead one
+// launch lets every remaining path run to its end in its own lane: extend -> miss | shade -> shadow ->
+// ..., using exactly the per-path functions of the wavefront kernels (so the bits do not change), then
+// retires it.  Every slot of the lists ends on the free list.
+// =================================================================================================
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
+{
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t total = listTotal(lc, 0);
+    const uint32_t stride = gridDim.x*blockDim.x;
+    const uint32_t rounded = (total + 63u) & ~63u;
+    TraceCounters tcE{0, 0}, tcS{0, 0};
+    uint32_t extRays = 0, shRays = 0, events = 0;
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
+        uint32_t slot = 0, ring = 0xFFFFFFFFu;
+        const bool have = q < total && listFetch(st, lc, set, 0, q, slot);
+        if (have) {
+            while (flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE) {
+                float4 ro = st.rayO[slot], rd = st.rayD[slot];
+                float tfar = rd.w, u = 0.0f, v = 0.0f;
+                uint32_t prim = closestHit<COUNT>(sc, stack, xyz(ro), xyz(rd), ro.w, tfar, u, v, tcE);
+                st.hit[slot] = make_float4(tfar, u, v, __uint_as_float(prim));
+                extRays++;
+                if (prim == PRIM_MISS) {
+                    missPath(sc, st, slot);
+                } else {
+                    shadePath(sc, st, slot);
+                    events++;
+                    if (st.shFlag[slot]) shadowPath<COUNT>(sc, st, stack, slot, tcS, shRays);
+                }
+            }
+            float4 tpw = st.tp[slot];
+            int end = flagsEnd(__float_as_uint(tpw.w));
+            if (end != END_DEAD) { // retire (k_retire_regenerate's rules)
+                V3 c = xyz(st.em[slot]);
+                if (end == END_ZERO) c = V3(0.0f);
+                else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f);
+                uint32_t ref = st.sampleRef[slot];
+                st.results[ref] = mk4(c, 0.0f);
+                ring = ref/st.resultSlice;
+                st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
+            }
+        }
+        unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
+        while (todo) {
+            int leader = __builtin_ctzll(todo);
+            uint32_t r = __shfl(ring, leader);
+            unsigned long long m = __ballot(ring == r);
+            if (lane == leader) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + r)], uint32_t(__builtin_popcountll(m)));
+            todo &= ~m;
+        }
+        queueAppend(have, st.freeQ, &st.counters[CNT(CNT_FREE)], slot);
+    }
+    if (COUNT) {
+        flushCounters(st.stats, 0, tcE);
+        flushCounters(st.stats, 2, tcS);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        extRays += __shfl_down(extRays, off);
+        shRays += __shfl_down(shRays, off);
+        events += __shfl_down(events, off);
+    }
+    if (lane == 0) {
+        if (shRays) atomicAdd(&st.stats[4], (unsigned long long)shRays);
+        if (events) atomicAdd(&st.stats[5], (unsigned long long)events);
+        if (extRays) atomicAdd(&st.stats[6], (unsigned long long)extRays);
     }
 }
 

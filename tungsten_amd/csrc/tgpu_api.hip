@@ -56,7 +56,8 @@ struct tgpu_ctx {
     unsigned long long sampleBase = 0, globalCursor = 0;
     uint32_t nCur = 0, freeCount = 0;
     uint32_t listCount[TG_LISTS] = {0};
-    uint64_t aliveCount = 0;
+    uint64_t tailMax = 65536; // switch to the tail kernel below this many live paths
+    uint64_t aliveCount = 0, hostExtendRays = 0;
     int curQ = 0;
     uint32_t ringFree = (1u << TG_RING) - 1u;
     int numCUs = 256;
@@ -299,6 +300,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.nTris = s->n_tris;
     sc.rootChild = bvh4.rootChild;
     sc.stackEntries = 3*bvh4.maxDepth + 2; // at most 3 pushes per level
+    if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
     if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
     if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] bvh2: %u nodes depth %d -> bvh4: %u nodes depth %d, stack entries %d\n", bvh.nodeCount, bvh.maxDepth, bvh4.nodeCount, bvh4.maxDepth, sc.stackEntries);
     float4 *dNodes, *dTris;
@@ -518,7 +520,21 @@ static int driveIteration(tgpu_ctx *ctx)
             nCur += nStart;
         }
     }
-    if (nCur > 0) {
+    // tail mode: nothing left to start and only a few long paths alive -> one launch finishes them all
+    bool tail = false;
+    if (nCur > 0 && ctx->aliveCount > 0 && ctx->aliveCount <= ctx->tailMax && ctx->sampleBase == limit) {
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        tail = ctx->pending.empty();
+    }
+    if (tail) {
+        Timer t(ctx, &ctx->stats.other_ms);
+        int grid = gridFor(ctx, nCur);
+        if (count) hipLaunchKernelGGL(k_tail<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+        else hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+        // every listed slot ends on the free list: both list sets are empty afterwards
+        (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0), 0, 2*TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
+        ctx->stats.tail_launches++;
+    } else if (nCur > 0) {
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
@@ -557,7 +573,9 @@ static int driveIteration(tgpu_ctx *ctx)
                                       hc[CNT(CNT_LIST0 + out*TG_LISTS)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 1)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 2)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 3)],
                                       hc[CNT(CNT_LIST0 + out*TG_LISTS + 4)], hc[CNT(CNT_REGEN)], hc[CNT(CNT_FREE)], ctx->sampleBase, limit, ctx->active.size());
     uint64_t nNext = 0;
-    if (nCur > 0) {
+    if (tail) {
+        for (int l = 0; l < TG_LISTS; ++l) ctx->listCount[l] = 0;
+    } else if (nCur > 0) {
         for (int l = 0; l < TG_LISTS; ++l) {
             ctx->listCount[l] = hc[CNT(CNT_LIST0 + out*TG_LISTS + l)];
             nNext += ctx->listCount[l];
@@ -569,7 +587,7 @@ static int driveIteration(tgpu_ctx *ctx)
     const uint32_t dropped = hc[CNT(CNT_FREE)] - ctx->freeCount; // idle slots extend moved to the free list
     ctx->freeCount = hc[CNT(CNT_FREE)];
     if (nNext + ctx->freeCount != ctx->capacity) { fail(ctx, "internal error: slot accounting broke (%llu listed + %u free != %llu)", (unsigned long long)nNext, ctx->freeCount, (unsigned long long)ctx->capacity); return TGPU_ERR_HIP; }
-    ctx->stats.extend_rays += nCur - dropped;
+    if (!tail) ctx->hostExtendRays += nCur - dropped; // the tail kernel counts its rays on the device
     unsigned long long room = limit - ctx->sampleBase;
     unsigned long long started = std::min<unsigned long long>(hc[CNT(CNT_REGEN)], room);
     ctx->sampleBase += started;
@@ -798,6 +816,7 @@ int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out)
         ctx->stats.shadow_tri_tests = d[3];
         ctx->stats.shadow_rays = d[4];
         ctx->stats.surface_events = d[5];
+        ctx->stats.extend_rays = ctx->hostExtendRays + d[6];
     }
     *out = ctx->stats;
     return TGPU_OK;
@@ -808,6 +827,7 @@ int tgpu_reset_stats(tgpu_ctx *ctx)
     if (!ctx) return TGPU_ERR_INVALID;
     (void)waitIdle(ctx);
     ctx->stats = tgpu_stats{};
+    ctx->hostExtendRays = 0;
     if (ctx->uploaded) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

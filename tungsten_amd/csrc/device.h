@@ -83,7 +83,7 @@ enum : uint32_t {
 };
 
 // ---- device scene -----------------------------------------------------------------------------
-struct DBitmap { int32_t w, h, clamp, linear; float scale; const float *texels; };
+struct DBitmap { int32_t w, h, clamp, linear; float scale; const float4 *texels; }; // RGB padded to 16 B: one load per texel
 
 struct DScene {
     tgpu_camera cam;
@@ -109,6 +109,10 @@ struct DScene {
     tgpu_env env;          // pointers are device pointers
     int32_t envConstant;   // emission texture is constant
     const uint32_t *sobol; // 1024 x 32
+    // guide tables for the env CDF inversion: entry g = index of the last CDF element <= g/N, so the
+    // std::upper_bound of Distribution2D::warp becomes one table read + a short forward scan
+    const uint16_t *envGuideMarginal;    // dist_h entries
+    const uint16_t *envGuideConditional; // dist_h x dist_w entries
 };
 
 // prim id encoding shared with the C ABI: kind << 30 | index; 0xFFFFFFFF = miss
@@ -172,7 +176,7 @@ struct Sampler {
 };
 
 // ---- textures ---------------------------------------------------------------------------------
-TG_DEV V3 loadRgb(const float *p) { return V3(p[0], p[1], p[2]); }
+TG_DEV V3 loadRgb(const float4 *p) { float4 t = *p; return V3(t.x, t.y, t.z); }
 
 TG_DEV V3 bitmapEval(const DBitmap &bm, float ux, float uy) // textures/BitmapTexture.cpp:298-352
 {
@@ -201,10 +205,10 @@ TG_DEV V3 bitmapEval(const DBitmap &bm, float ux, float uy) // textures/BitmapTe
         iv0 = min(max(iv0, 0), h - 1);
         iv1 = min(max(iv1, 0), h - 1);
     }
-    const float *t = bm.texels;
-    if (!linear) return loadRgb(t + (size_t(iu0) + size_t(iv0)*w)*3);
-    V3 x00 = loadRgb(t + (size_t(iu0) + size_t(iv0)*w)*3), x01 = loadRgb(t + (size_t(iu1) + size_t(iv0)*w)*3);
-    V3 x10 = loadRgb(t + (size_t(iu0) + size_t(iv1)*w)*3), x11 = loadRgb(t + (size_t(iu1) + size_t(iv1)*w)*3);
+    const float4 *t = bm.texels;
+    if (!linear) return loadRgb(t + (size_t(iu0) + size_t(iv0)*w));
+    V3 x00 = loadRgb(t + (size_t(iu0) + size_t(iv0)*w)), x01 = loadRgb(t + (size_t(iu1) + size_t(iv0)*w));
+    V3 x10 = loadRgb(t + (size_t(iu0) + size_t(iv1)*w)), x11 = loadRgb(t + (size_t(iu1) + size_t(iv1)*w));
     V3 l = (x00*(1.0f - u) + x01*u)*(1.0f - v) + (x10*(1.0f - u) + x11*u)*v;
     return bm.scale*l;
 }
@@ -250,6 +254,17 @@ TG_DEV float envPdf(const DScene &sc, float ux, float uy) // BitmapTexture.cpp:4
     return sc.env.pdf[size_t(row)*w + column]*sc.env.marginal_pdf[row]*w*h;
 }
 
+// (std::upper_bound(a, a + n, value) - a) - 1 using a guide table with `buckets` entries, guide[g] = index of the
+// last element <= g/buckets.  One bucket of slack absorbs the rounding of value*buckets.
+TG_DEV int upperBoundGuided(const float *a, int n, const uint16_t *guide, int buckets, float value)
+{
+    int g = int(value*float(buckets));
+    g = min(max(g - 1, 0), buckets - 1);
+    int i = int(guide[g]);
+    while (i + 1 < n && !(value < a[i + 1])) ++i;
+    return i;
+}
+
 // std::upper_bound(first, first + n, value) - first
 TG_DEV int upperBound(const float *a, int n, float value)
 {
@@ -285,10 +300,10 @@ TG_DEV bool envSampleDirect(const DScene &sc, Sampler &s, LightSample &out) // I
     float uvx = s.next1D(), uvy = s.next1D();
     int w = sc.env.dist_w, h = sc.env.dist_h; // Distribution2D::warp (sampling/Distribution2D.hpp:66-76)
     const float *mc = sc.env.marginal_cdf;
-    int row = upperBound(mc, h + 1, uvy) - 1;
+    int row = upperBoundGuided(mc, h + 1, sc.envGuideMarginal, h, uvy);
     uvy = clampf((uvy - mc[row])/sc.env.marginal_pdf[row], 0.0f, 1.0f);
     const float *rs = sc.env.cdf + size_t(row)*(w + 1);
-    int column = upperBound(rs, w + 1, uvx) - 1;
+    int column = upperBoundGuided(rs, w + 1, sc.envGuideConditional + size_t(row)*w, w, uvx);
     uvx = clampf((uvx - rs[column])/sc.env.pdf[size_t(row)*w + column], 0.0f, 1.0f);
     float ux = (uvx + column)/w; // BitmapTexture::sample (:433-439)
     float uy = 1.0f - (uvy + row)/h;

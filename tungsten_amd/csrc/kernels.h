@@ -998,7 +998,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
 }
 
 template <int CLASS>
-__global__ void __launch_bounds__(256) k_shade(DScene sc, DState st, int set)
+__global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + CLASS)];
     const uint32_t *list = st.lists[set][1 + CLASS];

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "bvh_build.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -355,8 +356,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     std::vector<DBitmap> bitmaps(s->n_bitmaps);
     for (uint32_t i = 0; i < s->n_bitmaps; ++i) {
         const tgpu_bitmap &b = s->bitmaps[i];
-        float *dTexels;
-        if ((rc = upload(ctx, ctx->allocs, b.texels, size_t(b.w)*b.h*3, &dTexels))) return rc;
+        std::vector<float4> padded(size_t(b.w)*b.h);
+        for (size_t t = 0; t < padded.size(); ++t) padded[t] = make_float4(b.texels[t*3], b.texels[t*3 + 1], b.texels[t*3 + 2], 0.0f);
+        float4 *dTexels;
+        if ((rc = upload(ctx, ctx->allocs, padded.data(), padded.size(), &dTexels))) return rc;
         bitmaps[i] = DBitmap{b.w, b.h, b.clamp, b.linear, b.scale, dTexels};
     }
     DBitmap *dBitmaps;
@@ -377,6 +380,20 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
             if ((rc = upload(ctx, ctx->allocs, s->env.marginal_pdf, h, &c))) return rc;
             if ((rc = upload(ctx, ctx->allocs, s->env.marginal_cdf, h + 1, &d))) return rc;
             sc.env.pdf = a; sc.env.cdf = b; sc.env.marginal_pdf = c; sc.env.marginal_cdf = d;
+            // guide tables (device.h: upperBoundGuided)
+            if (w > 65535 || h > 65535) { fail(ctx, "environment map larger than 65535 texels per side"); return TGPU_ERR_UNSUPPORTED; }
+            auto lastLE = [](const float *arr, size_t n, float v) { // (upper_bound - begin) - 1
+                return uint16_t((std::upper_bound(arr, arr + n, v) - arr) - 1);
+            };
+            std::vector<uint16_t> gm(h), gc(w*h);
+            for (size_t g = 0; g < h; ++g) gm[g] = lastLE(s->env.marginal_cdf, h + 1, float(g)/float(h));
+            for (size_t r = 0; r < h; ++r)
+                for (size_t g = 0; g < w; ++g) gc[r*w + g] = lastLE(s->env.cdf + r*(w + 1), w + 1, float(g)/float(w));
+            uint16_t *dgm, *dgc;
+            if ((rc = upload(ctx, ctx->allocs, gm.data(), gm.size(), &dgm))) return rc;
+            if ((rc = upload(ctx, ctx->allocs, gc.data(), gc.size(), &dgc))) return rc;
+            sc.envGuideMarginal = dgm;
+            sc.envGuideConditional = dgc;
         }
     }
     uint32_t *dSobol;

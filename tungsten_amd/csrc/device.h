@@ -165,6 +165,13 @@ struct Sampler {
         uint32_t result = scramble; // thirdparty/sobol/sobol.h:40-53
         uint32_t idx = (index & ~0xFFu) | ((index + scramble) & 0xFFu);
         const uint32_t *m = matrices + dimension*32u;
+        // columns 0..7 with two 16-byte loads (the low byte of the index is the part that varies from
+        // sample to sample), the rare higher bits one column at a time; XOR order is irrelevant
+        const uint4 lo = *reinterpret_cast<const uint4 *>(m), hi = *reinterpret_cast<const uint4 *>(m + 4);
+        result ^= (idx & 1u ? lo.x : 0u) ^ (idx & 2u ? lo.y : 0u) ^ (idx & 4u ? lo.z : 0u) ^ (idx & 8u ? lo.w : 0u);
+        result ^= (idx & 16u ? hi.x : 0u) ^ (idx & 32u ? hi.y : 0u) ^ (idx & 64u ? hi.z : 0u) ^ (idx & 128u ? hi.w : 0u);
+        idx >>= 8;
+        m += 8;
         while (idx) {
             int b = __builtin_ctz(idx);
             result ^= m[b];

@@ -142,6 +142,7 @@ typedef struct tgpu_settings {
     int32_t enable_two_sided_shading;
     int32_t enable_consistency_checks;
     int32_t use_sobol;        /* renderer "stratified_sampler"               */
+    int32_t adaptive_sampling;/* renderer "adaptive_sampling": keep per-4x4-tile SampleRecords (SampleRecord.hpp) */
 } tgpu_settings;
 
 /* A light is an emissive, samplable primitive, in scene order
@@ -221,6 +222,20 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *scene,
  * respect to the host up to internal queue-drain checks; `stream` is a
  * hipStream_t (NULL = the context's own stream).                             */
 int tgpu_render_pass(tgpu_ctx *ctx, uint32_t spp_begin, uint32_t spp_count, void *stream);
+
+/* Adaptive pass (PathTraceIntegrator::generateWork/renderTile with adaptive_sampling, PathTraceIntegrator.cpp:110-156):
+ * every pixel of variance tile v traces vt_sample_count[v] samples with sample indices vt_sample_index[v] + i.
+ * Variance tiles are the 4x4 pixel blocks of the image, row-major, ceil(res_x/4) x ceil(res_y/4) of them; both
+ * arrays cover the whole image, tiles outside the context's shard are ignored.  Needs settings.adaptive_sampling
+ * at upload.  The host computes the two arrays from tgpu_download_records (errorPercentile95, dilate,
+ * distribute: :44-108).                                                        */
+int tgpu_render_pass_adaptive(tgpu_ctx *ctx, const uint32_t *vt_sample_index, const uint32_t *vt_sample_count, void *stream);
+
+/* SampleRecord statistics (path_tracer/SampleRecord.hpp:44-66) of the shard's variance tiles, written into whole-image
+ * arrays (ceil(res_x/4)*ceil(res_y/4) entries; entries of tiles outside the shard are left untouched).       */
+typedef struct tgpu_sample_record { uint32_t sample_count; float mean; float running_variance; } tgpu_sample_record;
+int tgpu_download_records(tgpu_ctx *ctx, tgpu_sample_record *records);
+int tgpu_upload_records(tgpu_ctx *ctx, const tgpu_sample_record *records);
 
 /* Integrator::waitForCompletion (PathTraceIntegrator.cpp:241-247).           */
 int tgpu_wait(tgpu_ctx *ctx);

@@ -1729,3 +1729,206 @@ float oracle_embree_rcp(float a)
 }
 
 } // extern "C"
+
+// ========================================================================================
+// The whole StandaloneRenderer pass loop with the reference's adaptive sampling
+// (src/tungsten/Shared.hpp:283-311 ; PathTraceIntegrator.cpp:44-134,136-156,184-239 ;
+//  SampleRecord.hpp:44-66 ; Integrator.cpp:51-54)
+// ========================================================================================
+namespace {
+struct SampleRecord { // path_tracer/SampleRecord.hpp:11-66
+    uint32_t sampleCount = 0, nextSampleCount = 0, sampleIndex = 0;
+    float adaptiveWeight = 0.0f, mean = 0.0f, runningVariance = 0.0f;
+    void addSample(float x)
+    {
+        sampleCount++;
+        float delta = x - mean;
+        mean += delta/sampleCount;
+        runningVariance += delta*(x - mean);
+    }
+    float variance() const { return runningVariance/(sampleCount - 1); }
+    float errorEstimate() const { return variance()/(sampleCount*fmax2(mean*mean, 1e-3f)); }
+};
+} // namespace
+
+extern "C" int oracle_render_shard_adaptive(oracle_ctx *ctx, const tgpu_shard_desc *shard, const uint32_t *vtIndex,
+                                            const uint32_t *vtCount, float *rgb_mean, uint32_t *sample_count,
+                                            tgpu_sample_record *records, int n_threads)
+{
+    if (ctx->rngMode != 1) return -1;
+    const uint32_t W = ctx->sc.camera.res_x, H = ctx->sc.camera.res_y, VT = 4;
+    const uint32_t varW = (W + VT - 1)/VT;
+    // shard-local index of every image pixel, and the variance tiles the shard holds
+    std::vector<int32_t> local(size_t(W)*H, -1);
+    std::vector<uint32_t> tiles;
+    for (uint32_t k = 0; k < shard->n_pixels; ++k) {
+        uint32_t p = shard->pixel_index[k];
+        local[p] = int32_t(k);
+        tiles.push_back((p % W)/VT + ((p/W)/VT)*varW);
+    }
+    std::sort(tiles.begin(), tiles.end());
+    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        oracle_ctx::Counters c;
+        Sampler s;
+        s.matrices = ctx->sc.sobol_matrices;
+        s.sobol = ctx->sc.settings.use_sobol != 0;
+        while (true) {
+            uint32_t t = next.fetch_add(1);
+            if (t >= tiles.size()) break;
+            uint32_t vt = tiles[t], vx = (vt % varW)*VT, vy = (vt/varW)*VT;
+            SampleRecord record;
+            record.sampleCount = records[vt].sample_count;
+            record.mean = records[vt].mean;
+            record.runningVariance = records[vt].running_variance;
+            // renderTile order restricted to this variance tile: rows, then pixels, then the pixel's samples (:136-156)
+            for (uint32_t y = vy; y < std::min(vy + VT, H); ++y)
+                for (uint32_t x = vx; x < std::min(vx + VT, W); ++x) {
+                    uint32_t pixelIndex = x + y*W;
+                    int32_t k = local[pixelIndex];
+                    if (k < 0) continue;
+                    s.seed = shard->tile_seed[k];
+                    for (uint32_t i = 0; i < vtCount[vt]; ++i) {
+                        s.startPath(pixelIndex, vtIndex[vt] + i);
+                        s.local = pathLocalPcg(s.scramble, vtIndex[vt] + i);
+                        s.supplemental = &s.local;
+                        V3 col = ctx->traceSample(x, y, s, c);
+                        record.addSample(col.luminance());
+                        addSample(rgb_mean + size_t(k)*3, sample_count + k, col);
+                    }
+                }
+            records[vt] = tgpu_sample_record{record.sampleCount, record.mean, record.runningVariance};
+        }
+        flushCounters(ctx, c);
+    };
+    int nt = std::max(1, n_threads);
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; ++i) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return 0;
+}
+
+extern "C" int oracle_render_reference(oracle_ctx *ctx, uint32_t seed, uint32_t totalSpp, uint32_t sppStep, int adaptive,
+                                       float *rgb_mean, uint32_t *sample_count, float *record_out /* varW*varH*3 or NULL */, int n_threads)
+{
+    const uint32_t W = ctx->sc.camera.res_x, H = ctx->sc.camera.res_y, T = 16, VT = 4, AdaptiveThreshold = 16;
+    const uint32_t tilesX = (W + T - 1)/T, tilesY = (H + T - 1)/T, nTiles = tilesX*tilesY;
+    const uint32_t varW = (W + VT - 1)/VT, varH = (H + VT - 1)/VT;
+    Pcg32 integratorSampler(hash32(seed)); // PathTraceIntegrator::prepareForRender :187
+    std::vector<uint32_t> seeds(nTiles);
+    for (uint32_t i = 0; i < nTiles; ++i) seeds[i] = hash32(integratorSampler.nextI()); // diceTiles :29-38
+    std::vector<Pcg32> tilePcg(nTiles);
+    for (uint32_t i = 0; i < nTiles; ++i) tilePcg[i] = Pcg32(seeds[i]);
+    std::vector<SampleRecord> samples(size_t(varW)*varH);
+
+    uint32_t currentSpp = 0, nextSpp = std::min(sppStep, totalSpp);
+    while (currentSpp < totalSpp) { // Shared.hpp:283 while (!integrator.done())
+        // generateWork (:110-134)
+        for (SampleRecord &r : samples) r.sampleIndex += r.nextSampleCount;
+        int sppCount = int(nextSpp - currentSpp);
+        bool work = true;
+        if (adaptive && currentSpp >= AdaptiveThreshold) {
+            // errorPercentile95 (:44-59)
+            std::vector<float> errors;
+            errors.reserve(samples.size());
+            for (SampleRecord &r : samples) {
+                r.adaptiveWeight = r.errorEstimate();
+                if (r.adaptiveWeight > 0.0f) errors.push_back(r.adaptiveWeight);
+            }
+            float maxError = 0.0f;
+            if (!errors.empty()) {
+                std::sort(errors.begin(), errors.end());
+                maxError = errors[(errors.size()*95)/100];
+            }
+            if (maxError == 0.0f) {
+                work = false;
+            } else {
+                for (SampleRecord &r : samples) r.adaptiveWeight = fmin2(r.adaptiveWeight, maxError);
+                // dilateAdaptiveWeights (:61-85)
+                for (uint32_t y = 0; y < varH; ++y)
+                    for (uint32_t x = 0; x < varW; ++x) {
+                        size_t idx = x + size_t(y)*varW;
+                        if (y < varH - 1) samples[idx].adaptiveWeight = fmax2(samples[idx].adaptiveWeight, samples[idx + varW].adaptiveWeight);
+                        if (x < varW - 1) samples[idx].adaptiveWeight = fmax2(samples[idx].adaptiveWeight, samples[idx + 1].adaptiveWeight);
+                    }
+                for (int y = int(varH) - 1; y >= 0; --y)
+                    for (int x = int(varW) - 1; x >= 0; --x) {
+                        size_t idx = size_t(x) + size_t(y)*varW;
+                        if (y > 0) samples[idx].adaptiveWeight = fmax2(samples[idx].adaptiveWeight, samples[idx - varW].adaptiveWeight);
+                        if (x > 0) samples[idx].adaptiveWeight = fmax2(samples[idx].adaptiveWeight, samples[idx - 1].adaptiveWeight);
+                    }
+                // distributeAdaptiveSamples (:87-108)
+                double totalWeight = 0.0;
+                for (SampleRecord &r : samples) totalWeight += r.adaptiveWeight;
+                int adaptiveBudget = (sppCount - 1)*int(W)*int(H);
+                int budgetPerTile = adaptiveBudget/int(VT*VT);
+                float weightToSampleFactor = float(double(budgetPerTile)/totalWeight);
+                float pixelPdf = 0.0f;
+                for (SampleRecord &r : samples) {
+                    float fractionalSamples = r.adaptiveWeight*weightToSampleFactor;
+                    int adaptiveSamples = int(fractionalSamples);
+                    pixelPdf += fractionalSamples - float(adaptiveSamples);
+                    if (integratorSampler.next1D() < pixelPdf) {
+                        adaptiveSamples++;
+                        pixelPdf -= 1.0f;
+                    }
+                    r.nextSampleCount = uint32_t(adaptiveSamples + 1);
+                }
+            }
+        } else {
+            for (SampleRecord &r : samples) r.nextSampleCount = uint32_t(sppCount);
+        }
+        if (work) {
+            // renderTile for every tile (:136-156); tiles own disjoint records, so they can run concurrently
+            std::atomic<uint32_t> next{0};
+            auto worker = [&]() {
+                oracle_ctx::Counters c;
+                while (true) {
+                    uint32_t t = next.fetch_add(1);
+                    if (t >= nTiles) break;
+                    uint32_t tx = (t % tilesX)*T, ty = (t/tilesX)*T;
+                    uint32_t tw = std::min(T, W - tx), th = std::min(T, H - ty);
+                    Sampler s;
+                    s.matrices = ctx->sc.sobol_matrices;
+                    s.sobol = ctx->sc.settings.use_sobol != 0;
+                    s.seed = seeds[t];
+                    for (uint32_t y = 0; y < th; ++y)
+                        for (uint32_t x = 0; x < tw; ++x) {
+                            uint32_t px = tx + x, py = ty + y, pixelIndex = px + py*W;
+                            SampleRecord &record = samples[px/VT + size_t(py/VT)*varW];
+                            int spp = int(record.nextSampleCount);
+                            for (int i = 0; i < spp; ++i) {
+                                s.startPath(pixelIndex, record.sampleIndex + uint32_t(i));
+                                if (ctx->rngMode == 0) {
+                                    s.supplemental = &tilePcg[t];
+                                } else {
+                                    s.local = pathLocalPcg(s.scramble, record.sampleIndex + uint32_t(i));
+                                    s.supplemental = &s.local;
+                                }
+                                V3 col = ctx->traceSample(px, py, s, c);
+                                record.addSample(col.luminance());
+                                addSample(rgb_mean + size_t(pixelIndex)*3, sample_count + pixelIndex, col);
+                            }
+                        }
+                }
+                flushCounters(ctx, c);
+            };
+            int nt = std::max(1, n_threads);
+            std::vector<std::thread> th;
+            for (int i = 1; i < nt; ++i) th.emplace_back(worker);
+            worker();
+            for (auto &t : th) t.join();
+        }
+        currentSpp = nextSpp;                              // completion callback (:231-235)
+        nextSpp = std::min(currentSpp + sppStep, totalSpp); // Integrator::advanceSpp
+    }
+    if (record_out)
+        for (size_t i = 0; i < samples.size(); ++i) {
+            record_out[i*3] = float(samples[i].sampleCount);
+            record_out[i*3 + 1] = samples[i].mean;
+            record_out[i*3 + 2] = samples[i].runningVariance;
+        }
+    return 0;
+}

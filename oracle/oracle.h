@@ -49,6 +49,19 @@ int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint
 int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t spp_begin, uint32_t spp_count,
                         float *rgb_mean, uint32_t *sample_count, int n_threads);
 
+/* The whole render loop of the reference incl. generateWork / adaptive sampling (PathTraceIntegrator.cpp:44-156,
+ * StandaloneRenderer loop Shared.hpp:283): passes of spp_step up to total_spp.  record_out (may be NULL) receives
+ * {sampleCount, mean, runningVariance} as 3 floats per 4x4 variance tile. */
+int oracle_render_reference(oracle_ctx *ctx, uint32_t seed, uint32_t total_spp, uint32_t spp_step, int adaptive,
+                            float *rgb_mean, uint32_t *sample_count, float *record_out, int n_threads);
+
+/* Shard order, per-variance-tile sample counts (rng mode 1 only): same contract as
+ * tgpu_render_pass_adaptive + tgpu_download + tgpu_download_records.  vt_* and records are whole-image tables
+ * (varW*varH entries); records of the shard's tiles are updated in place. */
+int oracle_render_shard_adaptive(oracle_ctx *ctx, const tgpu_shard_desc *shard, const uint32_t *vt_sample_index,
+                                 const uint32_t *vt_sample_count, float *rgb_mean, uint32_t *sample_count,
+                                 tgpu_sample_record *records, int n_threads);
+
 /* Ray-level queries, same layout as tgpu_trace_closest / tgpu_trace_occluded. */
 int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *hits);
 int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_t *occluded);

@@ -29,6 +29,10 @@ def lib():
         L.oracle_destroy.argtypes = [C.c_void_p]
         L.oracle_render_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_render_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_render_reference.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int]
+        L.oracle_render_shard_adaptive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_int]
         L.oracle_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_trace_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_hash32.restype = C.c_uint32
@@ -70,6 +74,20 @@ class Oracle:
             done += k
         return rgb.reshape(self.res_y, self.res_x, 3), cnt.reshape(self.res_y, self.res_x)
 
+    def render_reference(self, spp, seed=0xBA5EBA11, spp_step=16, adaptive=True, threads=None):
+        """The whole StandaloneRenderer pass loop incl. generateWork / adaptive sampling
+        (PathTraceIntegrator.cpp:44-156); returns (H,W,3) mean, (H,W) counts and the (varH,varW,3)
+        {sampleCount, mean, runningVariance} SampleRecord table."""
+        threads = threads or os.cpu_count() or 1
+        n = self.res_x*self.res_y
+        var_w, var_h = (self.res_x + 3)//4, (self.res_y + 3)//4
+        rgb = np.zeros((n, 3), np.float32)
+        cnt = np.zeros(n, np.uint32)
+        rec = np.zeros((var_h, var_w, 3), np.float32)
+        lib().oracle_render_reference(self._h, seed & 0xFFFFFFFF, spp, spp_step, int(adaptive), rgb.ctypes.data,
+                                      cnt.ctypes.data, rec.ctypes.data, threads)
+        return rgb.reshape(self.res_y, self.res_x, 3), cnt.reshape(self.res_y, self.res_x), rec
+
     def render_shard(self, shard, spp, spp_step=16, threads=None, rgb=None, cnt=None, spp_begin=0):
         threads = threads or os.cpu_count() or 1
         n = shard.n_pixels
@@ -84,6 +102,20 @@ class Oracle:
                 raise RuntimeError("oracle_render_shard needs rng mode 1")
             done += k
         return rgb, cnt
+
+    def render_shard_adaptive(self, shard, vt_index, vt_count, rgb, cnt, records, threads=None):
+        """One pass with per-variance-tile counts; rgb/cnt (shard order) and the whole-image record table
+        (numpy, tungsten_amd.RECORD_DTYPE) are updated in place -- what tgpu_render_pass_adaptive does."""
+        threads = threads or os.cpu_count() or 1
+        vt_index = np.ascontiguousarray(vt_index, np.uint32)
+        vt_count = np.ascontiguousarray(vt_count, np.uint32)
+        assert records.flags.c_contiguous and records.itemsize == 12
+        rc = lib().oracle_render_shard_adaptive(self._h, C.cast(shard.desc, C.c_void_p), vt_index.ctypes.data,
+                                                vt_count.ctypes.data, rgb.ctypes.data, cnt.ctypes.data,
+                                                records.ctypes.data, threads)
+        if rc != 0:
+            raise RuntimeError("oracle_render_shard_adaptive needs rng mode 1")
+        return rgb, cnt, records
 
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -29,6 +29,8 @@ FIXTURES = [
     ("c1_128x72_4spp", "materialtest/c1_noadapt.json", (128, 72), 4),
     ("c1_128x72_32spp", "materialtest/c1_noadapt.json", (128, 72), 32),
     ("cornell_96x54_8spp", "cornell-box/scene_sobol.json", (96, 54), 8),
+    # the stock scene WITH its adaptive sampling (4 passes of 16 spp: 1 uniform + 3 redistributed)
+    ("c1_adaptive_128x72_64spp", "materialtest/materialtest.json", (128, 72), 64, True),
 ]
 
 
@@ -36,7 +38,7 @@ def main():
     if not os.path.exists(REF_BIN):
         sys.exit(f"reference binary {REF_BIN} not found; fixtures cannot be regenerated here")
     only = set(sys.argv[1:])
-    for name, scene, res, spp in FIXTURES:
+    for name, scene, res, spp, *adaptive in FIXTURES:
         if only and name not in only:
             continue
         src = os.path.join(REPO, "assets", scene)
@@ -46,7 +48,7 @@ def main():
         d = json.load(open(src))
         d["camera"]["resolution"] = list(res)
         d["renderer"].update({"spp": spp, "output_file": name + ".png", "hdr_output_file": name + ".pfm",
-                              "overwrite_output_files": True, "adaptive_sampling": False})
+                              "overwrite_output_files": True, "adaptive_sampling": bool(adaptive and adaptive[0])})
         tmp = os.path.join(os.path.dirname(src), f"_tmp_{name}.json")
         json.dump(d, open(tmp, "w"))
         try:

@@ -38,6 +38,65 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+class _OracleContext:
+    """Stands in for tungsten_amd.Context on this GPU-less box: same pass-level contract, CPU checker inside."""
+
+    def __init__(self, oracle, shard):
+        import tungsten_amd as ta
+        self.o, self.shard = oracle, shard
+        self.rgb = np.zeros((shard.n_pixels, 3), np.float32)
+        self.cnt = np.zeros(shard.n_pixels, np.uint32)
+        self.rec = np.zeros(((shard.res_x + 3)//4)*((shard.res_y + 3)//4), ta.RECORD_DTYPE)
+
+    def render_pass_adaptive(self, idx, cnt):
+        self.o.render_shard_adaptive(self.shard, idx, cnt, self.rgb, self.cnt, self.rec, threads=2)
+
+    def wait(self):
+        pass
+
+    def download_records(self):
+        # like tgpu_download_records: only this shard's variance tiles are filled in
+        out = np.zeros_like(self.rec)
+        px = self.shard.pixel_index
+        vt = (px % self.shard.res_x)//4 + ((px//self.shard.res_x)//4)*((self.shard.res_x + 3)//4)
+        out[np.unique(vt)] = self.rec[np.unique(vt)]
+        return out
+
+
+def _adaptive_worker(rank, world, port, out_path):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import tungsten_amd as ta
+    from tungsten_amd.dist import gather_framebuffer, exchange_records
+    from tungsten_amd.passes import render_passes
+    from oracle.oracle_py import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(72, 40))
+    shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank, world)
+    ctx = _OracleContext(Oracle(scene, rng=1, math=1), shard)
+    render_passes(ctx, scene.res_x, scene.res_y, 40, 8, adaptive=True, exchange=lambda t: exchange_records(t, dist))
+    img = gather_framebuffer(torch.from_numpy(ctx.rgb), shard, world, rank, dist)
+    if rank == 0:
+        np.save(out_path, img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_adaptive_sampling_across_ranks_equals_reference_loop(ta, oracle_py, tmp_path):
+    """Adaptive sampling is the one place the path has an exchange step (the SampleRecord table, all-reduced
+    once per pass): 2 ranks + scheduler + exchange must reproduce the single-process reference loop."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_adaptive_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    scene = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(72, 40))
+    img, cnt, _ = oracle_py.Oracle(scene, rng=1, math=1).render_reference(40, spp_step=8, adaptive=True, threads=4)
+    assert cnt.min() < 40 < cnt.max()
+    assert np.array_equal(got, img)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_tile_shard_gather_equals_single_rank(ta, oracle_py, tmp_path, world):
     import torch.multiprocessing as mp

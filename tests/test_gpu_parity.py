@@ -218,3 +218,114 @@ def test_cpp_host_integrator_cli(ta, oracle_py, tmp_path):
     ref, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 20, spp_step=8)
     assert np.array_equal(img, shard.scatter(ref))
     assert os.path.getsize(tmp_path / "cli.png") > 1000
+
+
+def _records_image(rec, hs):
+    """RECORD_DTYPE table -> (varH, varW, 3) float32 like Oracle.render_reference's third result."""
+    var_w, var_h = (hs.res_x + 3)//4, (hs.res_y + 3)//4
+    return np.stack([rec["sample_count"].astype(np.float32), rec["mean"], rec["running_variance"]], axis=1).reshape(var_h, var_w, 3)
+
+
+def test_adaptive_sampling_bit_exact(ta, oracle_py, gpu_ctx):
+    """settings.adaptive_sampling: SampleRecord statistics accumulated on the device in renderTile's order,
+    the host's generateWork in between, per-variance-tile sample counts in the next pass -- against the
+    oracle's restatement of the whole reference loop (itself pinned by c1_adaptive_128x72_64spp.pfm)."""
+    from tungsten_amd.passes import render_passes
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(128, 72))
+    assert hs.adaptive
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    render_passes(gpu_ctx, hs.res_x, hs.res_y, 64, 16, adaptive=True)
+    rgb, cnt = gpu_ctx.download()
+    rec = gpu_ctx.download_records()
+    ref_img, ref_cnt, ref_rec = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(64, spp_step=16, adaptive=True)
+    assert ref_cnt.min() < 64 < ref_cnt.max()
+    assert np.array_equal(shard.scatter(cnt.reshape(-1, 1).repeat(3, 1).astype(np.float32))[..., 0], ref_cnt.astype(np.float32))
+    assert np.array_equal(_records_image(rec, hs).view(np.uint32), ref_rec.view(np.uint32))
+    assert np.array_equal(shard.scatter(rgb), ref_img)
+
+
+def test_adaptive_sampling_ragged_image_and_two_shards(ta, oracle_py, gpu_ctx):
+    """100x57: ragged 16x16 tiles AND ragged 4x4 variance tiles; two shards on two contexts with the record
+    tables merged on the host (what dist.exchange_records does across processes)."""
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(100, 57))
+    shards = [ta.Shard(hs.res_x, hs.res_y, 0xBA5EBA11, r, 2) for r in range(2)]
+    ctxs = [gpu_ctx, ta.Context(0)]
+    for c, s in zip(ctxs, shards):
+        c.upload(hs, s)
+    work = ta.AdaptiveScheduler(hs.res_x, hs.res_y)
+    current = 0
+    while current < 40:
+        nxt = min(current + 8, 40)
+        if work.needs_statistics(True, current):
+            table = ctxs[0].download_records()
+            other = ctxs[1].download_records()
+            assert not ((table["sample_count"] > 0) & (other["sample_count"] > 0)).any()  # disjoint tiles
+            table["sample_count"] += other["sample_count"]
+            table["mean"] += other["mean"]
+            table["running_variance"] += other["running_variance"]
+            work.set_statistics(table)
+        job = work.generate(current, nxt, True)
+        assert job is not None
+        for c in ctxs:
+            c.render_pass_adaptive(*job)
+        for c in ctxs:
+            c.wait()
+        current = nxt
+    img = None
+    for c, s in zip(ctxs, shards):
+        img = s.scatter(c.download()[0], img)
+    ctxs[1].close()
+    ref_img, ref_cnt, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(40, spp_step=8, adaptive=True)
+    assert ref_cnt.min() < 40 < ref_cnt.max()
+    assert np.array_equal(img, ref_img)
+
+
+def test_adaptive_records_upload_and_errors(ta, gpu_ctx):
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(64, 36))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    n = 16*9
+    table = np.zeros(n, ta.RECORD_DTYPE)
+    table["sample_count"] = np.arange(n)
+    table["mean"] = np.linspace(0, 1, n, dtype=np.float32)
+    table["running_variance"] = np.linspace(2, 3, n, dtype=np.float32)
+    gpu_ctx.upload_records(table)                      # resume: records come back from a checkpoint
+    assert np.array_equal(gpu_ctx.download_records(), table)
+    with pytest.raises(ValueError):
+        gpu_ctx.render_pass_adaptive(np.zeros(3, np.uint32), np.zeros(3, np.uint32))
+    huge = np.full(n, 1000, np.uint32)                 # more samples than a result-ring slice holds
+    with pytest.raises(ta.CoreError, match="exceeds the result-ring slice"):
+        gpu_ctx.render_pass_adaptive(np.zeros(n, np.uint32), huge)
+    plain = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(64, 36))
+    gpu_ctx.upload(plain, shard)
+    with pytest.raises(ta.CoreError, match="adaptive_sampling"):
+        gpu_ctx.render_pass_adaptive(np.zeros(n, np.uint32), np.ones(n, np.uint32))
+    with pytest.raises(ta.CoreError, match="no sample records"):
+        gpu_ctx.download_records()
+
+
+def test_cpp_host_integrator_cli_adaptive(ta, oracle_py, tmp_path):
+    """The stock scene file as it ships (adaptive_sampling on) through the C++ Integrator mirror."""
+    import json
+    import subprocess
+    from conftest import REPO, ASSETS
+    d = json.load(open(scene_path("materialtest/materialtest.json")))
+    assert d["renderer"]["adaptive_sampling"]
+    d["camera"]["resolution"] = [96, 54]
+    d["renderer"].update({"spp": 48, "spp_step": 16, "output_file": "cli.png", "hdr_output_file": "cli.pfm"})
+    for p in d["primitives"]:
+        for key in ("file", "emission"):
+            if isinstance(p.get(key), str):
+                p[key] = os.path.join(ASSETS, "materialtest", p[key])
+    scene_file = tmp_path / "cli_scene.json"
+    scene_file.write_text(json.dumps(d))
+    exe = os.path.join(REPO, "tungsten_amd", "tungsten_amd_cli")
+    r = subprocess.run([exe, "-d", str(tmp_path), str(scene_file)], capture_output=True, text=True,
+                       env=dict(os.environ, TUNGSTEN_AMD_ASSETS=ASSETS))
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = ta.load_pfm(tmp_path / "cli.pfm")
+    hs = ta.HostScene(str(scene_file))
+    ref, cnt, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(48, spp_step=16, adaptive=True)
+    assert cnt.min() < 48 < cnt.max()
+    assert np.array_equal(img, ref)

@@ -47,6 +47,26 @@ def test_oracle_matches_reference(ta, oracle_py, name, scene, res, spp):
         assert np.abs(img - ref).max() < 1e-5
 
 
+def test_oracle_adaptive_sampling_matches_reference(ta, oracle_py):
+    """generateWork (error percentile, dilation, stochastic distribution of the budget with the integrator's
+    own PCG) + renderTile with per-variance-tile sample counts, against the reference run with
+    adaptive_sampling on: 1 uniform pass and 3 adaptive ones."""
+    ref = ta.load_pfm(os.path.join(GOLDEN, "c1_adaptive_128x72_64spp.pfm"))
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(128, 72))
+    assert hs.adaptive
+    img, cnt, rec = oracle_py.Oracle(hs, **oracle_py.REF_RCP).render_reference(64, spp_step=16, adaptive=True)
+    assert cnt.min() < 64 < cnt.max()            # samples really moved between regions
+    assert abs(float(cnt.mean()) - 64.0) < 0.5   # the budget is conserved (up to the stochastic rounding)
+    # a variance tile's record saw exactly the samples of its pixels
+    tiles = cnt.reshape(18, 4, 32, 4).sum(axis=(1, 3))
+    assert np.array_equal(tiles, rec[..., 0].astype(np.uint32))
+    rmse = float(np.sqrt(((img - ref)**2).mean()))
+    assert rmse < 1e-3, rmse
+    if intel_rcp(oracle_py):
+        assert float((img == ref).all(axis=2).mean()) > 0.999
+        assert np.abs(img - ref).max() < 1e-5
+
+
 def test_ieee_division_mode_stays_within_tolerance(ta, oracle_py):
     """What the GPU computes (IEEE division for t,u,v instead of RCPPS) differs from the reference
     only through chaotic path divergence: quantify it on a fixture."""

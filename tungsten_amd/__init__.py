@@ -6,8 +6,8 @@ product is ``libtungsten_amd.so`` (HIP kernels behind the C ABI declared in
 Both are bound with ctypes.  There is no CPU fallback: creating a
 :class:`Context` without the HIP library or without a GPU raises.
 """
-from ._host import HostScene, Shard, host_lib, save_pfm, load_pfm, REPO_ROOT  # noqa: F401
+from ._host import HostScene, Shard, AdaptiveScheduler, RECORD_DTYPE, host_lib, save_pfm, load_pfm, REPO_ROOT  # noqa: F401
 from ._core import Context, core_lib, CoreError, TgpuStats  # noqa: F401
 
-__all__ = ["HostScene", "Shard", "Context", "CoreError", "TgpuStats", "host_lib", "core_lib",
+__all__ = ["HostScene", "Shard", "AdaptiveScheduler", "RECORD_DTYPE", "Context", "CoreError", "TgpuStats", "host_lib", "core_lib",
            "save_pfm", "load_pfm", "REPO_ROOT"]

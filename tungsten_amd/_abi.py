@@ -52,7 +52,8 @@ class Camera(C.Structure):
 
 class Settings(C.Structure):
     _fields_ = [("min_bounces", i32), ("max_bounces", i32), ("enable_light_sampling", i32),
-                ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("use_sobol", i32)]
+                ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("use_sobol", i32),
+                ("adaptive_sampling", i32)]
 
 
 class Light(C.Structure):
@@ -85,3 +86,7 @@ class Stats(C.Structure):
                 ("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("other_ms", C.c_double),
                 ("extend_launches", u64), ("shadow_launches", u64), ("tail_launches", u64)]
+
+
+class SampleRecord(C.Structure):
+    _fields_ = [("sample_count", u32), ("mean", f32), ("running_variance", f32)]

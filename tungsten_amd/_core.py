@@ -46,6 +46,9 @@ def load_core(path):
         L.tgpu_get_stats.argtypes = [vp, C.POINTER(_abi.Stats)]
         L.tgpu_reset_stats.argtypes = [vp]
         L.tgpu_eval_math.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp]
+        L.tgpu_render_pass_adaptive.argtypes = [vp, vp, vp, vp]
+        L.tgpu_download_records.argtypes = [vp, vp]
+        L.tgpu_upload_records.argtypes = [vp, vp]
     return L
 
 
@@ -62,6 +65,7 @@ EXPORTED_SYMBOLS = [
     "tgpu_init", "tgpu_destroy", "tgpu_last_error", "tgpu_upload_scene", "tgpu_render_pass", "tgpu_wait",
     "tgpu_abort", "tgpu_download", "tgpu_resolve_to_device", "tgpu_upload_framebuffer", "tgpu_trace_closest",
     "tgpu_trace_occluded", "tgpu_set_profiling", "tgpu_get_stats", "tgpu_reset_stats", "tgpu_eval_math",
+    "tgpu_render_pass_adaptive", "tgpu_download_records", "tgpu_upload_records",
 ]
 
 
@@ -90,6 +94,29 @@ class Context:
 
     def render_pass(self, spp_begin, spp_count, stream=None):
         self._check(self._lib.tgpu_render_pass(self._h, spp_begin, spp_count, C.c_void_p(stream or 0)))
+
+    def render_pass_adaptive(self, vt_sample_index, vt_sample_count, stream=None):
+        """One pass with per-variance-tile sample counts (whole-image tables, varW*varH entries)."""
+        idx = np.ascontiguousarray(vt_sample_index, np.uint32)
+        cnt = np.ascontiguousarray(vt_sample_count, np.uint32)
+        n = ((self._shard.res_x + 3)//4)*((self._shard.res_y + 3)//4)
+        if idx.size != n or cnt.size != n:
+            raise ValueError(f"expected {n} variance tiles, got {idx.size}/{cnt.size}")
+        self._check(self._lib.tgpu_render_pass_adaptive(self._h, idx.ctypes.data, cnt.ctypes.data, C.c_void_p(stream or 0)))
+
+    def download_records(self, table=None):
+        """SampleRecord statistics of this shard's variance tiles, written into the whole-image table."""
+        from ._host import RECORD_DTYPE
+        n = ((self._shard.res_x + 3)//4)*((self._shard.res_y + 3)//4)
+        table = np.zeros(n, RECORD_DTYPE) if table is None else table
+        assert table.dtype == RECORD_DTYPE and table.size == n and table.flags.c_contiguous
+        self._check(self._lib.tgpu_download_records(self._h, table.ctypes.data))
+        return table
+
+    def upload_records(self, table):
+        from ._host import RECORD_DTYPE
+        table = np.ascontiguousarray(table, RECORD_DTYPE)
+        self._check(self._lib.tgpu_upload_records(self._h, table.ctypes.data))
 
     def wait(self):
         self._check(self._lib.tgpu_wait(self._h))

@@ -38,6 +38,14 @@ def host_lib():
         lib.tgh_shard_desc.argtypes = [C.c_void_p]
         lib.tgh_shard_size.restype = C.c_uint32
         lib.tgh_shard_size.argtypes = [C.c_void_p]
+        lib.tgh_adaptive_create.restype = C.c_void_p
+        lib.tgh_adaptive_create.argtypes = [C.c_uint32]*3
+        lib.tgh_adaptive_free.argtypes = [C.c_void_p]
+        lib.tgh_adaptive_tiles.restype = C.c_uint32
+        lib.tgh_adaptive_tiles.argtypes = [C.c_void_p]
+        lib.tgh_adaptive_needs_statistics.argtypes = [C.c_int, C.c_uint32]
+        lib.tgh_adaptive_set_statistics.argtypes = [C.c_void_p, C.c_void_p]
+        lib.tgh_adaptive_generate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         lib.tgh_save_pfm.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int]
         lib.tgh_save_png_tonemapped.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int]
         _lib = lib
@@ -86,6 +94,43 @@ class HostScene:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+RECORD_DTYPE = np.dtype([("sample_count", np.uint32), ("mean", np.float32), ("running_variance", np.float32)])
+
+
+class AdaptiveScheduler:
+    """generateWork of PathTraceIntegrator (PathTraceIntegrator.cpp:44-134) over the whole image's 4x4
+    variance tiles; the C++ class of host/adaptive.hpp, the same one the C++ Integrator mirror uses."""
+
+    def __init__(self, res_x, res_y, seed=0xBA5EBA11):
+        self._h = host_lib().tgh_adaptive_create(res_x, res_y, seed & 0xFFFFFFFF)
+        self.n_tiles = host_lib().tgh_adaptive_tiles(self._h)
+        self.var_w, self.var_h = (res_x + 3)//4, (res_y + 3)//4
+
+    @staticmethod
+    def needs_statistics(adaptive, current_spp):
+        return bool(host_lib().tgh_adaptive_needs_statistics(int(adaptive), current_spp))
+
+    def set_statistics(self, table):
+        table = np.ascontiguousarray(table, RECORD_DTYPE)
+        assert table.size == self.n_tiles
+        host_lib().tgh_adaptive_set_statistics(self._h, table.ctypes.data)
+
+    def generate(self, current_spp, next_spp, adaptive=True):
+        """(sample_index, sample_count) per variance tile for the pass, or None when converged."""
+        idx = np.zeros(self.n_tiles, np.uint32)
+        cnt = np.zeros(self.n_tiles, np.uint32)
+        ok = host_lib().tgh_adaptive_generate(self._h, current_spp, next_spp, int(adaptive), idx.ctypes.data, cnt.ctypes.data)
+        return (idx, cnt) if ok else None
+
+    def __del__(self):
+        try:
+            if self._h:
+                host_lib().tgh_adaptive_free(self._h)
+                self._h = None
         except Exception:
             pass
 

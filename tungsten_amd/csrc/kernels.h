@@ -46,6 +46,7 @@ struct JobRing {
     uint32_t sppBegin[TG_RING];
     uint32_t sppCount[TG_RING];
     uint32_t ringSlot[TG_RING];        // which slice of the result ring the job writes
+    uint32_t adaptive[TG_RING];        // 1: per-variance-tile sample counts (jobOffset/jobVtIndex of the ring slot)
     uint32_t n;
 };
 
@@ -84,6 +85,14 @@ struct DState {
     const uint32_t *scramble;
     float *fbMean;
     uint32_t *fbCount;
+    // adaptive sampling (settings.adaptive_sampling): SampleRecords of the shard's 4x4 variance tiles
+    uint32_t nVt;
+    const uint32_t *vtPix;      // nVt x 16 shard pixel ids in the order renderTile visits them (row-major), 0xFFFFFFFF = outside
+    const uint32_t *vtOfPixel;  // shard pixel -> local variance tile
+    uint32_t *recCount;         // SampleRecord::sampleCount
+    float *recMean, *recVar;    // SampleRecord::mean / runningVariance
+    uint32_t *jobOffset;        // TG_RING x (nPixels + 1): first sample of each pixel inside an adaptive job
+    uint32_t *jobVtIndex;       // TG_RING x nVt: SampleRecord::sampleIndex of the pass
 };
 
 // Streaming accesses to the path state: non-temporal, so that the 4 MB L2 of each XCD keeps the BVH
@@ -201,13 +210,29 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
     for (uint32_t t = 1; t < jobs.n; ++t)
         if (g >= jobs.start[t]) j = t;
     uint32_t e = uint32_t(g - jobs.start[j]);
-    uint32_t s = e/st.nPixels, k = e - s*st.nPixels;
+    uint32_t s, k, sampleIndex;
+    if (jobs.adaptive[j]) {
+        // pixel-major job: pixel k owns samples [offset[k], offset[k+1]); find k = last pixel with offset[k] <= e
+        const uint32_t *off = st.jobOffset + size_t(jobs.ringSlot[j])*(st.nPixels + 1u);
+        uint32_t lo = 0, hi = st.nPixels; // invariant: off[lo] <= e < off[hi]
+        while (hi - lo > 1u) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= e) lo = mid; else hi = mid;
+        }
+        k = lo;
+        s = e - off[k];
+        sampleIndex = st.jobVtIndex[size_t(jobs.ringSlot[j])*st.nVt + st.vtOfPixel[k]] + s;
+    } else {
+        s = e/st.nPixels;
+        k = e - s*st.nPixels;
+        sampleIndex = jobs.sppBegin[j] + s;
+    }
     uint32_t pixel = st.pixelIndex[k];
     Sampler smp;
     smp.matrices = sc.sobol;
     smp.sobol = sc.settings.use_sobol;
     smp.scramble = st.scramble[k];
-    smp.index = jobs.sppBegin[j] + s;
+    smp.index = sampleIndex;
     smp.dimension = 0;
     smp.seedPathLocal(smp.scramble, smp.index);
     float xi0 = smp.next1D(), xi1 = smp.next1D();
@@ -1165,6 +1190,45 @@ __global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot
         st.fbMean[size_t(k)*3 + 1] = mean.y;
         st.fbMean[size_t(k)*3 + 2] = mean.z;
         st.fbCount[k] = n;
+    }
+}
+
+// Accumulate with SampleRecords (adaptive_sampling): one lane per variance tile replays renderTile's order --
+// pixels of the 4x4 block row-major, the pixel's samples in sequence -- so that the Welford statistics of
+// SampleRecord::addSample (SampleRecord.hpp:44-55) and the per-pixel means come out with the reference's bits.
+// Uniform jobs (offset == nullptr) hold sample s of pixel k at s*nPixels + k, adaptive jobs at offset[k] + s.
+__global__ void __launch_bounds__(256) k_accumulate_records(DState st, uint32_t ringSlot, uint32_t sppCount, uint32_t adaptive)
+{
+    const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
+    const uint32_t *off = st.jobOffset + size_t(ringSlot)*(st.nPixels + 1u);
+    for (uint32_t vt = blockIdx.x*blockDim.x + threadIdx.x; vt < st.nVt; vt += gridDim.x*blockDim.x) {
+        uint32_t sampleCount = st.recCount[vt];
+        float mean = st.recMean[vt], runningVariance = st.recVar[vt];
+        for (uint32_t j = 0; j < 16u; ++j) {
+            uint32_t k = st.vtPix[size_t(vt)*16u + j];
+            if (k == 0xFFFFFFFFu) continue;
+            V3 pm(st.fbMean + size_t(k)*3);
+            uint32_t n = st.fbCount[k];
+            uint32_t first = adaptive ? off[k] : 0u, cnt = adaptive ? off[k + 1u] - off[k] : sppCount;
+            for (uint32_t s = 0; s < cnt; ++s) {
+                V3 c = xyz(res[adaptive ? size_t(first + s) : size_t(s)*st.nPixels + k]);
+                float x = c.x*0.2126f + c.y*0.7152f + c.z*0.0722f; // Vec::luminance (math/Vec.hpp:195-199)
+                sampleCount++;
+                float delta = x - mean;
+                mean += delta/float(sampleCount);
+                runningVariance += delta*(x - mean);
+                if (isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) continue;
+                pm = pm + (c - pm)/float(n + 1u);
+                n++;
+            }
+            st.fbMean[size_t(k)*3 + 0] = pm.x;
+            st.fbMean[size_t(k)*3 + 1] = pm.y;
+            st.fbMean[size_t(k)*3 + 2] = pm.z;
+            st.fbCount[k] = n;
+        }
+        st.recCount[vt] = sampleCount;
+        st.recMean[vt] = mean;
+        st.recVar[vt] = runningVariance;
     }
 }
 

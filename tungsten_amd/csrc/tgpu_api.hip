@@ -47,7 +47,17 @@ struct tgpu_ctx {
     uint32_t *hostCounters = nullptr; // pinned
 
     // job queue + worker thread: tgpu_render_pass enqueues, the worker drives the wavefront loop
-    struct Job { uint32_t sppBegin, sppCount; unsigned long long start, total; uint32_t ringSlot; };
+    struct Job {
+        uint32_t sppBegin, sppCount;
+        unsigned long long start, total;
+        uint32_t ringSlot;
+        bool adaptive = false;
+        std::vector<uint32_t> offsets, vtIndex; // adaptive jobs: per-pixel sample offsets, per-tile sample index
+    };
+    bool trackRecords = false;            // settings.adaptive_sampling
+    uint32_t varW = 0, varH = 0;
+    std::vector<uint32_t> vtGlobal;       // local variance tile -> whole-image variance tile
+    std::vector<uint32_t> vtOfPixelHost;  // shard pixel -> local variance tile
     std::mutex mtx;
     std::condition_variable cvWork, cvIdle;
     std::deque<Job> pending, active;
@@ -414,6 +424,50 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, shard->n_pixels, &dCnt))) return rc;
     st.pixelIndex = dPix; st.scramble = dScr; st.fbMean = dMean; st.fbCount = dCnt;
 
+    // ---- variance tiles (4x4 pixel blocks, PathTraceIntegrator.hpp:27-29) of the shard ----
+    ctx->trackRecords = s->settings.adaptive_sampling != 0;
+    ctx->varW = (s->camera.res_x + 3)/4;
+    ctx->varH = (s->camera.res_y + 3)/4;
+    ctx->vtGlobal.clear();
+    ctx->vtOfPixelHost.clear();
+    if (ctx->trackRecords) {
+        std::vector<uint32_t> gids(shard->n_pixels);
+        for (uint32_t i = 0; i < shard->n_pixels; ++i) {
+            uint32_t x = shard->pixel_index[i] % s->camera.res_x, y = shard->pixel_index[i]/s->camera.res_x;
+            gids[i] = x/4 + (y/4)*ctx->varW;
+        }
+        ctx->vtGlobal = gids;
+        std::sort(ctx->vtGlobal.begin(), ctx->vtGlobal.end());
+        ctx->vtGlobal.erase(std::unique(ctx->vtGlobal.begin(), ctx->vtGlobal.end()), ctx->vtGlobal.end());
+        const uint32_t nVt = uint32_t(ctx->vtGlobal.size());
+        std::vector<uint32_t> vtPix(size_t(nVt)*16, 0xFFFFFFFFu);
+        ctx->vtOfPixelHost.resize(shard->n_pixels);
+        for (uint32_t i = 0; i < shard->n_pixels; ++i) {
+            uint32_t local = uint32_t(std::lower_bound(ctx->vtGlobal.begin(), ctx->vtGlobal.end(), gids[i]) - ctx->vtGlobal.begin());
+            uint32_t x = shard->pixel_index[i] % s->camera.res_x, y = shard->pixel_index[i]/s->camera.res_x;
+            ctx->vtOfPixelHost[i] = local;
+            vtPix[size_t(local)*16 + (y % 4)*4 + (x % 4)] = i; // renderTile visits a block row by row (:136-156)
+        }
+        // a variance tile must be wholly inside the shard (16x16 tiles are dealt whole)
+        for (uint32_t v = 0; v < nVt; ++v) {
+            uint32_t gx = ctx->vtGlobal[v] % ctx->varW, gy = ctx->vtGlobal[v]/ctx->varW;
+            uint32_t expect = std::min(4u, s->camera.res_x - gx*4)*std::min(4u, s->camera.res_y - gy*4), have = 0;
+            for (int j = 0; j < 16; ++j) have += vtPix[size_t(v)*16 + j] != 0xFFFFFFFFu;
+            if (have != expect) { fail(ctx, "adaptive sampling needs shards made of whole 4x4 variance tiles"); return TGPU_ERR_INVALID; }
+        }
+        uint32_t *dVtPix, *dVtOf, *dRecCount, *dJobOff, *dJobIdx;
+        float *dRecMean, *dRecVar;
+        if ((rc = upload(ctx, ctx->stateAllocs, vtPix.data(), vtPix.size(), &dVtPix))) return rc;
+        if ((rc = upload(ctx, ctx->stateAllocs, ctx->vtOfPixelHost.data(), ctx->vtOfPixelHost.size(), &dVtOf))) return rc;
+        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, nVt, &dRecCount))) return rc;
+        if ((rc = upload<float>(ctx, ctx->stateAllocs, nullptr, nVt, &dRecMean))) return rc;
+        if ((rc = upload<float>(ctx, ctx->stateAllocs, nullptr, nVt, &dRecVar))) return rc;
+        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, size_t(TG_RING)*(shard->n_pixels + 1), &dJobOff))) return rc;
+        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, size_t(TG_RING)*nVt, &dJobIdx))) return rc;
+        st.nVt = nVt; st.vtPix = dVtPix; st.vtOfPixel = dVtOf; st.recCount = dRecCount; st.recMean = dRecMean; st.recVar = dRecVar;
+        st.jobOffset = dJobOff; st.jobVtIndex = dJobIdx;
+    }
+
     // ---- wavefront state: a pool of `cap` path slots + the per-sample result ring ----
     uint64_t cap = maxPaths ? maxPaths : std::min<uint64_t>(std::max<uint64_t>(uint64_t(shard->n_pixels)*16, 4096), 8ull << 20);
     if (cap < 64) cap = 64;
@@ -445,6 +499,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     while (uint64_t(shard->n_pixels)*ctx->resultSpp*TG_RING > (1ull << 30) && ctx->resultSpp > 1) ctx->resultSpp /= 2; // <= 16 GiB of results
     st.nPixels = shard->n_pixels;
     st.resultSlice = shard->n_pixels*ctx->resultSpp;
+    if (ctx->trackRecords) st.resultSlice += st.resultSlice/2 + 64; // adaptive passes move samples between regions/ranks
     if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, size_t(st.resultSlice)*TG_RING, &st.results))) return rc;
 
     ctx->stats = tgpu_stats{};
@@ -501,7 +556,12 @@ static int driveIteration(tgpu_ctx *ctx)
             ctx->ringFree &= ~(1u << j.ringSlot);
             j.start = ctx->globalCursor;
             ctx->globalCursor += j.total;
-            ctx->active.push_back(j);
+            ctx->active.push_back(std::move(j));
+            const tgpu_ctx::Job &a = ctx->active.back();
+            if (a.adaptive) {
+                (void)hipMemcpyAsync(st.jobOffset + size_t(a.ringSlot)*(ctx->nPixels + 1), a.offsets.data(), a.offsets.size()*sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+                (void)hipMemcpyAsync(st.jobVtIndex + size_t(a.ringSlot)*st.nVt, a.vtIndex.data(), a.vtIndex.size()*sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+            }
         }
     }
     JobRing ring{};
@@ -513,6 +573,7 @@ static int driveIteration(tgpu_ctx *ctx)
         ring.sppBegin[i] = j.sppBegin;
         ring.sppCount[i] = j.sppCount;
         ring.ringSlot[i] = j.ringSlot;
+        ring.adaptive[i] = j.adaptive ? 1u : 0u;
         limit = j.start + j.total;
     }
     // jobs whose samples have all been handed out need no entry for g -> job lookups of NEW samples, but
@@ -620,7 +681,8 @@ static int driveIteration(tgpu_ctx *ctx)
         if (hc[CNT(CNT_JOB_DONE0 + j.ringSlot)] != j.total) break;
         {
             Timer t(ctx, &ctx->stats.other_ms);
-            hipLaunchKernelGGL(k_accumulate, dim3(gridFor(ctx, ctx->nPixels)), dim3(256), 0, stream, st, j.ringSlot, j.sppCount);
+            if (ctx->trackRecords) hipLaunchKernelGGL(k_accumulate_records, dim3(gridFor(ctx, st.nVt)), dim3(256), 0, stream, st, j.ringSlot, j.sppCount, j.adaptive ? 1u : 0u);
+            else hipLaunchKernelGGL(k_accumulate, dim3(gridFor(ctx, ctx->nPixels)), dim3(256), 0, stream, st, j.ringSlot, j.sppCount);
         }
         (void)hipMemsetAsync(st.counters + CNT(CNT_JOB_DONE0 + j.ringSlot), 0, sizeof(uint32_t), stream);
         ctx->stats.samples += j.total;
@@ -681,6 +743,11 @@ int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *
     if (!ctx) return TGPU_ERR_INVALID;
     if (!ctx->uploaded) { fail(ctx, "tgpu_render_pass before tgpu_upload_scene"); return TGPU_ERR_STATE; }
     if (sppCount == 0) return TGPU_OK;
+    if (ctx->trackRecords && sppCount > ctx->resultSpp) {
+        // a SampleRecord sees ALL samples of a pixel before the next pixel's (renderTile order): the pass must fit one slice
+        fail(ctx, "with adaptive_sampling a pass holds at most %u spp (spp_step), got %u", ctx->resultSpp, sppCount);
+        return TGPU_ERR_UNSUPPORTED;
+    }
     if (streamPtr) {
         // work submitted so far on the caller's stream must precede the pass: order the context stream after it
         HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -695,11 +762,85 @@ int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *
         ctx->abortFlag = false;
         for (uint32_t s = 0; s < sppCount; s += ctx->resultSpp) { // one job per result-ring slice
             uint32_t n = std::min(ctx->resultSpp, sppCount - s);
-            ctx->pending.push_back(tgpu_ctx::Job{sppBegin + s, n, 0ull, (unsigned long long)n*ctx->nPixels, 0u});
+            {
+                tgpu_ctx::Job job;
+                job.sppBegin = sppBegin + s; job.sppCount = n; job.start = 0; job.total = (unsigned long long)n*ctx->nPixels; job.ringSlot = 0;
+                ctx->pending.push_back(std::move(job));
+            }
         }
         ctx->idle = false;
     }
     ctx->cvWork.notify_one();
+    return TGPU_OK;
+}
+
+int tgpu_render_pass_adaptive(tgpu_ctx *ctx, const uint32_t *vtSampleIndex, const uint32_t *vtSampleCount, void *streamPtr)
+{
+    if (!ctx || !vtSampleIndex || !vtSampleCount) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "tgpu_render_pass_adaptive before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    if (!ctx->trackRecords) { fail(ctx, "tgpu_render_pass_adaptive needs settings.adaptive_sampling at upload"); return TGPU_ERR_STATE; }
+    (void)streamPtr;
+    tgpu_ctx::Job job;
+    job.adaptive = true;
+    job.sppBegin = 0;
+    job.sppCount = 0;
+    job.start = 0;
+    job.ringSlot = 0;
+    job.offsets.resize(size_t(ctx->nPixels) + 1);
+    unsigned long long total = 0;
+    for (uint32_t k = 0; k < ctx->nPixels; ++k) {
+        job.offsets[k] = uint32_t(total);
+        total += vtSampleCount[ctx->vtGlobal[ctx->vtOfPixelHost[k]]];
+        if (total > ctx->st.resultSlice) { fail(ctx, "adaptive pass of %llu+ samples exceeds the result-ring slice (%u)", total, ctx->st.resultSlice); return TGPU_ERR_UNSUPPORTED; }
+    }
+    job.offsets[ctx->nPixels] = uint32_t(total);
+    job.total = total;
+    job.vtIndex.resize(ctx->vtGlobal.size());
+    for (size_t v = 0; v < ctx->vtGlobal.size(); ++v) job.vtIndex[v] = vtSampleIndex[ctx->vtGlobal[v]];
+    if (total == 0) return TGPU_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        ctx->abortFlag = false;
+        ctx->pending.push_back(std::move(job));
+        ctx->idle = false;
+    }
+    ctx->cvWork.notify_one();
+    return TGPU_OK;
+}
+
+int tgpu_download_records(tgpu_ctx *ctx, tgpu_sample_record *records)
+{
+    if (!ctx || !records) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded || !ctx->trackRecords) { fail(ctx, "no sample records: upload a scene with settings.adaptive_sampling"); return TGPU_ERR_STATE; }
+    (void)waitIdle(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = ctx->vtGlobal.size();
+    std::vector<uint32_t> cnt(n);
+    std::vector<float> mean(n), var(n);
+    HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->st.recCount, n*sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(mean.data(), ctx->st.recMean, n*sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(var.data(), ctx->st.recVar, n*sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < n; ++v) records[ctx->vtGlobal[v]] = tgpu_sample_record{cnt[v], mean[v], var[v]};
+    return TGPU_OK;
+}
+
+int tgpu_upload_records(tgpu_ctx *ctx, const tgpu_sample_record *records)
+{
+    if (!ctx || !records) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded || !ctx->trackRecords) { fail(ctx, "no sample records: upload a scene with settings.adaptive_sampling"); return TGPU_ERR_STATE; }
+    (void)waitIdle(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = ctx->vtGlobal.size();
+    std::vector<uint32_t> cnt(n);
+    std::vector<float> mean(n), var(n);
+    for (size_t v = 0; v < n; ++v) {
+        const tgpu_sample_record &r = records[ctx->vtGlobal[v]];
+        cnt[v] = r.sample_count; mean[v] = r.mean; var[v] = r.running_variance;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->st.recCount, cnt.data(), n*sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->st.recMean, mean.data(), n*sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->st.recVar, var.data(), n*sizeof(float), hipMemcpyHostToDevice));
     return TGPU_OK;
 }
 

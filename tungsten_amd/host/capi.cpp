@@ -1,6 +1,7 @@
 // C entry points of the host library (libtungsten_host.so) used by the Python
 // test/bench harness through ctypes.  Pure host code: scene loading and
 // flattening, shard construction, image I/O.  No GPU and no oracle here.
+#include "adaptive.hpp"
 #include "scene.hpp"
 
 #include <cstring>
@@ -83,6 +84,29 @@ void tgh_shard_free(tgh_shard *s) { delete s; }
 const tgpu_shard_desc *tgh_shard_desc(const tgh_shard *s) { return &s->desc; }
 uint32_t tgh_shard_size(const tgh_shard *s) { return s->desc.n_pixels; }
 const uint32_t *tgh_shard_pixels(const tgh_shard *s) { return s->desc.pixel_index; }
+
+// AdaptiveScheduler (adaptive.hpp): generateWork of PathTraceIntegrator for the Python harness
+struct tgh_adaptive { AdaptiveScheduler work; };
+tgh_adaptive *tgh_adaptive_create(uint32_t resX, uint32_t resY, uint32_t seed)
+{
+    tgh_adaptive *a = new tgh_adaptive;
+    a->work.init(resX, resY, seed);
+    return a;
+}
+void tgh_adaptive_free(tgh_adaptive *a) { delete a; }
+uint32_t tgh_adaptive_tiles(const tgh_adaptive *a) { return uint32_t(a->work.samples().size()); }
+int tgh_adaptive_needs_statistics(int adaptive, uint32_t currentSpp) { return AdaptiveScheduler::needsStatistics(adaptive != 0, currentSpp); }
+void tgh_adaptive_set_statistics(tgh_adaptive *a, const tgpu_sample_record *table) { a->work.setStatistics(table); }
+// returns 1 and fills sampleIndex/sampleCount (one entry per variance tile) when the pass has work, else 0
+int tgh_adaptive_generate(tgh_adaptive *a, uint32_t currentSpp, uint32_t nextSpp, int adaptive, uint32_t *sampleIndex, uint32_t *sampleCount)
+{
+    if (!a->work.generateWork(currentSpp, nextSpp, adaptive != 0)) return 0;
+    std::vector<uint32_t> idx, cnt;
+    a->work.passArrays(idx, cnt);
+    std::memcpy(sampleIndex, idx.data(), idx.size()*sizeof(uint32_t));
+    std::memcpy(sampleCount, cnt.data(), cnt.size()*sizeof(uint32_t));
+    return 1;
+}
 
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h) { return savePfm(path, rgb, w, h) ? 0 : -1; }
 int tgh_save_png_tonemapped(const char *path, const char *tonemap, const float *rgb, int w, int h)

@@ -52,8 +52,9 @@ void PathTraceIntegrator::prepareForRender(Scene &scene, uint32_t seed)
     _spp = scene.renderer.spp;
     _sppStep = std::max<uint32_t>(scene.renderer.sppStep, 1);
     advanceSpp();
-    if (scene.renderer.useAdaptiveSampling)
-        throw std::runtime_error("adaptive_sampling is a 'next' row of the scope table (SURVEY.md 8f): set it to false");
+    _work.init(scene.resX, scene.resY, seed);
+    if (scene.renderer.useAdaptiveSampling && _world > 1 && !recordExchange)
+        throw std::runtime_error("adaptive_sampling across processes needs PathTraceIntegrator::recordExchange (all-gather of the sample records)");
     const uint32_t nLocal = uint32_t(_devices.size());
     for (uint32_t i = 0; i < nLocal; ++i) {
         Device &d = _devices[i];
@@ -86,7 +87,20 @@ void PathTraceIntegrator::startRender(std::function<void()> completionCallback)
     _aborted = false;
     _error.clear();
     const uint32_t begin = _currentSpp, count = _nextSpp - _currentSpp;
-    for (Device &d : _devices) check(d.ctx, tgpu_render_pass(d.ctx, begin, count, nullptr), "tgpu_render_pass");
+    if (_scene->renderer.useAdaptiveSampling) {
+        if (AdaptiveScheduler::needsStatistics(true, _currentSpp)) collectRecords();
+        if (!_work.generateWork(_currentSpp, _nextSpp, true)) { // :229-232 -- converged: nothing to do in this pass
+            _currentSpp = _nextSpp;
+            advanceSpp();
+            completionCallback();
+            return;
+        }
+        std::vector<uint32_t> index, next;
+        _work.passArrays(index, next);
+        for (Device &d : _devices) check(d.ctx, tgpu_render_pass_adaptive(d.ctx, index.data(), next.data(), nullptr), "tgpu_render_pass_adaptive");
+    } else {
+        for (Device &d : _devices) check(d.ctx, tgpu_render_pass(d.ctx, begin, count, nullptr), "tgpu_render_pass");
+    }
     // the completion callback fires from a host thread once every device has finished the pass
     _waiter = std::thread([this, completionCallback]() {
         for (Device &d : _devices) {
@@ -100,6 +114,15 @@ void PathTraceIntegrator::startRender(std::function<void()> completionCallback)
             completionCallback();
         }
     });
+}
+
+// Bring the SampleRecords the devices accumulated (k_accumulate_records) back to the host table.
+void PathTraceIntegrator::collectRecords()
+{
+    std::vector<tgpu_sample_record> table(_work.samples().size(), tgpu_sample_record{0, 0.0f, 0.0f});
+    for (Device &d : _devices) check(d.ctx, tgpu_download_records(d.ctx, table.data()), "tgpu_download_records");
+    if (_world > 1) recordExchange(table);
+    _work.setStatistics(table.data());
 }
 
 void PathTraceIntegrator::waitForCompletion()

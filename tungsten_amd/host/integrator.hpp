@@ -7,6 +7,7 @@
 // role TraceableScene plays there (prepared scene + renderer settings + camera output buffers).
 #pragma once
 #include "../../include/tungsten_amd.h"
+#include "adaptive.hpp"
 #include "scene.hpp"
 
 #include <atomic>
@@ -61,7 +62,18 @@ public:
     void abortRender() override;                                   // :249-256
     void frameBuffer(std::vector<float> &rgb) override;
 
+    // SampleRecords (adaptive.hpp), one per 4x4 variance tile of the whole image
+    const std::vector<SampleRecord> &sampleRecords() const { return _work.samples(); }
+    // Multi-process renders with adaptive sampling: called once per pass with the whole-image
+    // {sampleCount, mean, runningVariance} table holding this process' variance tiles; must fill in the
+    // other ranks' tiles (an all-reduce/all-gather; tungsten_amd/dist.py does it over torch.distributed).
+    std::function<void(std::vector<tgpu_sample_record> &)> recordExchange;
+
 private:
+    void collectRecords();
+
+    AdaptiveScheduler _work;
+
     struct Device {
         int id;
         tgpu_ctx *ctx = nullptr;

@@ -759,6 +759,7 @@ void Scene::flatten()
 
     _desc.settings = settings;
     _desc.settings.use_sobol = renderer.useSobol ? 1 : 0;
+    _desc.settings.adaptive_sampling = renderer.useAdaptiveSampling ? 1 : 0;
 
     // ---- meshes: world-space bake (TriangleMesh.cpp:524-552) ----
     _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear();

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGPU_ABI_VERSION 1
+#define TGPU_ABI_VERSION 2
 
 typedef enum tgpu_status {
     TGPU_OK = 0,
@@ -150,6 +150,34 @@ typedef struct tgpu_settings {
 enum { TGPU_LIGHT_ENV = 0, TGPU_LIGHT_QUAD = 1 };
 typedef struct tgpu_light { int32_t kind; int32_t index; } tgpu_light;
 
+/* ---- "instances" primitives (src/core/primitives/Instance.cpp) -------------
+ * Rigid copies (translation + unit quaternion) of master primitives.  A master
+ * is a triangle mesh, a quad or a cube; its geometry sits at the TAIL of the
+ * scene arrays (after the n_tris / n_quads / n_cubes scene finites), baked by
+ * the master's own transform exactly like a scene primitive.  pos/rot are the
+ * values Instance::prepareForRender (:392-403) leaves in _instancePos /
+ * _instanceRot; bounds_* is Primitive::bounds() of the prepared master.  The
+ * core builds the BVH2 over instance boxes itself (bvh/BvhBuilder.cpp:99-185,
+ * BinaryBvh.hpp:120-146): its shape is part of the result, because
+ * Instance::intersect (:290-311) lets the LAST hit instance in traversal
+ * order win (local rays start at the node's entry distance with farT = inf).  */
+enum { TGPU_MASTER_MESH = 0, TGPU_MASTER_QUAD = 1, TGPU_MASTER_CUBE = 2 };
+
+typedef struct tgpu_master {
+    int32_t  kind;
+    uint32_t first, count;   /* mesh: triangle range [first, first+count) of tri_*; quad/cube: index `first` */
+    float    bounds_min[3], bounds_max[3];
+} tgpu_master;
+
+typedef struct tgpu_instances {
+    uint32_t           n_masters;    /* <= 256 (uint8 ids, Instance.hpp:23)       */
+    const tgpu_master *masters;
+    uint32_t           n_instances;
+    const float       *pos;          /* n_instances*3                             */
+    const float       *rot;          /* n_instances*4 : w x y z (Quaternion.hpp)  */
+    const uint8_t     *master_id;    /* n_instances                               */
+} tgpu_instances;
+
 typedef struct tgpu_scene_desc {
     uint32_t abi_version;     /* TGPU_ABI_VERSION */
 
@@ -171,6 +199,11 @@ typedef struct tgpu_scene_desc {
     uint32_t         n_bitmaps; const tgpu_bitmap  *bitmaps;
     uint32_t         n_lights;  const tgpu_light   *lights;
     tgpu_env         env;
+
+    /* instance masters: tri_* / quads / cubes hold n_tris + n_master_tris (etc.) entries; the tail
+     * entries are reachable only through instance_sets                         */
+    uint32_t n_master_tris, n_master_quads, n_master_cubes;
+    uint32_t n_instance_sets;  const tgpu_instances *instance_sets;
 
     /* Joe-Kuo Sobol' generator matrices, 1024 dimensions x 32 columns
      * (thirdparty/sobol/sobol.h:28-53; columns >= 32 are unreachable with a

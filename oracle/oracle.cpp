@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <thread>
 #include <vector>
 #if defined(__SSE__)
@@ -74,6 +75,15 @@ inline bool isinfV(const V3 &v) { return std::isinf(v.x) || std::isinf(v.y) || s
 inline V3 mulPoint0(const float *m, const V3 &b)
 {
     return V3(m[0]*b.x + m[1]*b.y + m[2]*b.z + 0.0f, m[3]*b.x + m[4]*b.y + m[5]*b.z + 0.0f, m[6]*b.x + m[7]*b.y + m[8]*b.z + 0.0f);
+}
+inline V3 qrotate(const float *q, const V3 &o) // Quaternion::operator*(Vec3) (math/Quaternion.hpp:74-84), q = w x y z
+{
+    float tx = 2.0f*(q[2]*o.z - q[3]*o.y);
+    float ty = 2.0f*(q[3]*o.x - q[1]*o.z);
+    float tz = 2.0f*(q[1]*o.y - q[2]*o.x);
+    return V3(o.x + q[0]*tx + q[2]*tz - q[3]*ty,
+              o.y + q[0]*ty + q[3]*tx - q[1]*tz,
+              o.z + q[0]*tz + q[1]*ty - q[2]*tx);
 }
 inline V3 mulVector(const float *m, const V3 &b) // Mat4f::transformVector (Mat4f.hpp:159-166)
 {
@@ -162,13 +172,14 @@ inline Pcg32 pathLocalPcg(uint32_t scramble, uint32_t sampleIndex)
 
 // ---- records ---------------------------------------------------------------------------
 struct Ray { V3 pos, dir; float nearT, farT; };
-enum PrimKind : int { PRIM_NONE = 0, PRIM_TRI = 1, PRIM_QUAD = 2, PRIM_CUBE = 3, PRIM_ENV = 4 };
+enum PrimKind : int { PRIM_NONE = 0, PRIM_TRI = 1, PRIM_QUAD = 2, PRIM_CUBE = 3, PRIM_ENV = 4, PRIM_INSTANCE = 5 };
 struct Temp { // IntersectionTemporary
     int kind = PRIM_NONE;
     uint32_t index = 0;
     float u = 0, v = 0;
     V3 p, w, Ng; // quad hit point / env origin ; env direction ; mesh unnormalised geometric normal
     bool backSide = false;
+    int32_t inst = -1, instSet = -1; // IntersectionTemporary::flags / primitive == an Instance (Instance.cpp:305-308)
 };
 struct Info { // primitives/IntersectionInfo.hpp
     V3 Ng, Ns, p, w;
@@ -206,16 +217,17 @@ struct LightSample { V3 d; float dist, pdf; };
 
 struct BvhNode { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; };
 struct TriIsect { V3 v0, e1, e2, Ng; };
+struct TriBvh { std::vector<BvhNode> nodes; std::vector<uint32_t> triOrder; }; // triOrder holds GLOBAL triangle ids
 
 } // namespace
 
+struct oracle_instances;
 // ========================================================================================
 struct oracle_ctx {
     tgpu_scene_desc sc;
     int rngMode, mathMode, rcpMode;
-    std::vector<BvhNode> nodes;
-    std::vector<uint32_t> triOrder;
-    std::vector<TriIsect> tris;
+    TriBvh sceneBvh;                 // scene finites: triangles [0, n_tris)
+    std::vector<TriIsect> tris;      // all triangles incl. the instance masters' (n_tris + n_master_tris)
     std::vector<Pcg32> tilePcg;
     uint32_t tileSeedBase = 0;
     bool tilesInit = false;
@@ -232,9 +244,14 @@ struct oracle_ctx {
     struct Counters { uint64_t extend = 0, shadow = 0, surface = 0, nodes = 0, tris = 0, samples = 0; };
 
     // ---- BVH ---------------------------------------------------------------------------
-    void buildBvh();
-    void intersectTris(const Ray &ray, float &bestT, float &bestU, float &bestV, uint32_t &bestPrim, Counters &c) const;
-    bool occludedTris(const Ray &ray, Counters &c) const;
+    std::unique_ptr<oracle_instances> inst;
+    void buildInstances();
+    bool masterIntersect(uint32_t setIndex, uint32_t master, Ray &ray, Temp &data, Counters &c) const;
+    bool instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Counters &c) const;
+    void prepareTris();
+    void buildBvh(uint32_t firstTri, uint32_t nTris, TriBvh &out) const;
+    void intersectTris(const TriBvh &bvh, const Ray &ray, float &bestT, float &bestU, float &bestV, uint32_t &bestPrim, Counters &c) const;
+    bool occludedTris(const TriBvh &bvh, const Ray &ray, Counters &c) const;
 
     // ---- textures ----------------------------------------------------------------------
     V3 bitmapEval(const tgpu_bitmap &bm, float ux, float uy) const;
@@ -280,14 +297,11 @@ struct oracle_ctx {
 // BVH over the triangle soup (own builder: binned SAH, leaves <= 4; the reference's
 // Embree BVH4 is replaced, nearest-hit results do not depend on the tree)
 // ========================================================================================
-void oracle_ctx::buildBvh()
+void oracle_ctx::prepareTris()
 {
-    uint32_t n = sc.n_tris;
+    uint32_t n = sc.n_tris + sc.n_master_tris;
     tris.resize(n);
-    triOrder.resize(n);
-    std::vector<float> cmin(size_t(n)*3), cmax(size_t(n)*3), cen(size_t(n)*3);
     for (uint32_t i = 0; i < n; ++i) {
-        triOrder[i] = i;
         V3 p0(sc.tri_pos + size_t(i)*9), p1(sc.tri_pos + size_t(i)*9 + 3), p2(sc.tri_pos + size_t(i)*9 + 6);
         // Embree TriangleM: v0, e1 = v0 - v1, e2 = v2 - v0, Ng = cross(e1, e2)
         // (thirdparty/embree/kernels/geometry/triangle.h:53-54, triangle_intersector_moeller.h:118-120)
@@ -295,12 +309,28 @@ void oracle_ctx::buildBvh()
         tris[i].e1 = p0 - p1;
         tris[i].e2 = p2 - p0;
         tris[i].Ng = tris[i].e1.cross(tris[i].e2);
+    }
+}
+
+void oracle_ctx::buildBvh(uint32_t firstTri, uint32_t n, TriBvh &out) const
+{
+    std::vector<BvhNode> &nodes = out.nodes;
+    std::vector<uint32_t> &triOrder = out.triOrder;
+    triOrder.resize(n);
+    // per-triangle boxes, indexed by id - firstTri
+    std::vector<float> cminL(size_t(n)*3), cmaxL(size_t(n)*3), cenL(size_t(n)*3);
+    for (uint32_t i = 0; i < n; ++i) {
+        triOrder[i] = firstTri + i;
+        const float *tp = sc.tri_pos + size_t(firstTri + i)*9;
+        V3 p0(tp), p1(tp + 3), p2(tp + 6);
         for (int k = 0; k < 3; ++k) {
-            cmin[size_t(i)*3 + k] = std::min(p0[k], std::min(p1[k], p2[k]));
-            cmax[size_t(i)*3 + k] = std::max(p0[k], std::max(p1[k], p2[k]));
-            cen[size_t(i)*3 + k] = 0.5f*(cmin[size_t(i)*3 + k] + cmax[size_t(i)*3 + k]);
+            cminL[size_t(i)*3 + k] = std::min(p0[k], std::min(p1[k], p2[k]));
+            cmaxL[size_t(i)*3 + k] = std::max(p0[k], std::max(p1[k], p2[k]));
+            cenL[size_t(i)*3 + k] = 0.5f*(cminL[size_t(i)*3 + k] + cmaxL[size_t(i)*3 + k]);
         }
     }
+    // views addressed by global id
+    const float *cmin = cminL.data() - size_t(firstTri)*3, *cmax = cmaxL.data() - size_t(firstTri)*3, *cen = cenL.data() - size_t(firstTri)*3;
     nodes.clear();
     if (n == 0) return;
     nodes.reserve(size_t(n));
@@ -450,8 +480,10 @@ static inline TriHit triTest(const TriIsect &tri, const Ray &ray, float tfar0, i
 }
 
 // nearest hit = lexicographic minimum of (t, triangle id) over all valid triangles
-void oracle_ctx::intersectTris(const Ray &ray, float &bestT, float &bestU, float &bestV, uint32_t &bestPrim, Counters &c) const
+void oracle_ctx::intersectTris(const TriBvh &bvh, const Ray &ray, float &bestT, float &bestU, float &bestV, uint32_t &bestPrim, Counters &c) const
 {
+    const std::vector<BvhNode> &nodes = bvh.nodes;
+    const std::vector<uint32_t> &triOrder = bvh.triOrder;
     if (nodes.empty()) return;
     const float tfar0 = bestT;
     V3 inv(1.0f/ray.dir.x, 1.0f/ray.dir.y, 1.0f/ray.dir.z);
@@ -479,8 +511,10 @@ void oracle_ctx::intersectTris(const Ray &ray, float &bestT, float &bestU, float
     }
 }
 
-bool oracle_ctx::occludedTris(const Ray &ray, Counters &c) const
+bool oracle_ctx::occludedTris(const TriBvh &bvh, const Ray &ray, Counters &c) const
 {
+    const std::vector<BvhNode> &nodes = bvh.nodes;
+    const std::vector<uint32_t> &triOrder = bvh.triOrder;
     if (nodes.empty()) return false;
     V3 inv(1.0f/ray.dir.x, 1.0f/ray.dir.y, 1.0f/ray.dir.z);
     int stack[128];
@@ -668,18 +702,446 @@ void oracle_ctx::intersectionInfo(const Temp &data, Info &info) const
     }
     default: break;
     }
+    if (data.inst >= 0) { // Instance::intersectionInfo (:335-344) on top of the master's
+        const tgpu_instances &is = sc.instance_sets[data.instSet];
+        const float *rot = is.rot + size_t(data.inst)*4;
+        info.Ng = qrotate(rot, info.Ng);
+        info.Ns = qrotate(rot, info.Ns);
+        info.p = V3(is.pos + size_t(data.inst)*3) + qrotate(rot, info.p);
+        info.kind = PRIM_INSTANCE;
+        info.index = uint32_t(data.inst);
+    }
+}
+
+// ========================================================================================
+// "instances" primitives (primitives/Instance.cpp) -- restated WITH the reference's behaviour:
+//  * BVH2 over the instance boxes built exactly as Bvh::BvhBuilder(2) + BinaryBvh(prims, 2) do
+//    (bvh/BvhBuilder.cpp:99-185, FullSahSplitter.hpp, BinnedSahSplitter.hpp, BinaryBvh.hpp:120-146);
+//  * BinaryBvh::trace's ordered traversal (BinaryBvh.hpp:188-283);
+//  * Instance::intersect (:290-311): the local ray starts at the leaf's entry distance with farT = infinity, and
+//    whichever instance is hit LAST in traversal order wins -- the tree shape is therefore part of the result;
+//  * Instance::intersectionInfo (:335-344): the master sees the WORLD hit point, and info.p is transformed by the
+//    instance a second time (only Quad masters, which overwrite info.p with their local point, end up correct).
+// ========================================================================================
+namespace {
+const float BOX_MAX = std::numeric_limits<float>::max(), BOX_LOWEST = std::numeric_limits<float>::lowest();
+inline float sseMax(float a, float b) { return a > b ? a : b; } // _mm_max_ps / Tungsten::max
+inline float sseMin(float a, float b) { return a < b ? a : b; }
+struct IBox { // math/Box.hpp
+    V3 lo{BOX_MAX, BOX_MAX, BOX_MAX}, hi{BOX_LOWEST, BOX_LOWEST, BOX_LOWEST};
+    void grow(const V3 &p) { for (int k = 0; k < 3; ++k) { lo[k] = sseMin(lo[k], p[k]); hi[k] = sseMax(hi[k], p[k]); } }
+    void grow(const IBox &b) { for (int k = 0; k < 3; ++k) { lo[k] = sseMin(lo[k], b.lo[k]); hi[k] = sseMax(hi[k], b.hi[k]); } }
+    V3 diagonal() const { return V3(sseMax(hi.x - lo.x, 0.0f), sseMax(hi.y - lo.y, 0.0f), sseMax(hi.z - lo.z, 0.0f)); }
+    float area() const { V3 d = diagonal(); return (d.x*d.y + d.y*d.z + d.z*d.x)*2.0f; }
+    V3 center() const { return (lo + hi)/2.0f; }
+};
+inline int maxDim(const V3 &v) { int idx = 0; float m = v.x; for (int i = 1; i < 3; ++i) if (v[i] > m) { m = v[i]; idx = i; } return idx; }
+struct IPrim { IBox box; V3 centroid; uint32_t id; float area; }; // bvh/Primitive.hpp
+struct ISplit { IBox lBox, rBox, lCentroidBox, rCentroidBox; int dim; uint32_t idx; float cost; };
+typedef std::vector<IPrim> IPrims;
+
+inline int cvttss2si(float f) // int(float) as x86 does it, NaN/overflow -> INT_MIN
+{
+    if (!(f > -2147483904.0f && f < 2147483648.0f)) return std::numeric_limits<int>::min();
+    return int(f);
+}
+
+struct FullSahSplitter { // bvh/FullSahSplitter.hpp
+    static void sortDim(uint32_t start, uint32_t end, int dim, IPrims &prims)
+    {
+        std::sort(prims.begin() + start, prims.begin() + end + 1, [&](const IPrim &a, const IPrim &b) {
+            if (a.centroid[dim] == b.centroid[dim]) return a.id < b.id;
+            return a.centroid[dim] < b.centroid[dim];
+        });
+    }
+    static void findSahSplit(uint32_t start, uint32_t end, int dim, IPrims &prims, ISplit &split)
+    {
+        sortDim(start, end, dim, prims);
+        IBox rBox; // computeAreas
+        for (uint32_t i = end; i > start; --i) { rBox.grow(prims[i].box); prims[i].area = rBox.area(); }
+        rBox.grow(prims[start].box);
+        prims[start].area = rBox.area();
+        IBox lBox = prims[start].box;
+        for (uint32_t i = start + 1; i <= end; ++i) {
+            float cost = 1.0f*(lBox.area()*float(i - start) + prims[i].area*float(end - i + 1));
+            if (cost < split.cost) { split.dim = dim; split.idx = i; split.lBox = lBox; split.cost = cost; }
+            lBox.grow(prims[i].box);
+        }
+        if (split.dim == dim) {
+            IBox r;
+            for (uint32_t i = split.idx; i <= end; ++i) r.grow(prims[i].box);
+            split.rBox = r;
+        }
+    }
+    static void twoWaySahSplit(uint32_t start, uint32_t end, IPrims &prims, const IBox &geomBox, ISplit &split)
+    {
+        split.dim = -1;
+        split.cost = geomBox.area()*(float(end - start + 1)*1.0f - 1.0f);
+        findSahSplit(start, end, 0, prims, split);
+        findSahSplit(start, end, 1, prims, split);
+        findSahSplit(start, end, 2, prims, split);
+        if (split.dim == -1) {
+            split.dim = maxDim(geomBox.diagonal());
+            split.idx = (end - start + 1)/2 + start;
+            sortDim(start, end, split.dim, prims);
+            for (uint32_t i = start; i <= end; ++i) (i < split.idx ? split.lBox : split.rBox).grow(prims[i].box);
+        } else if (split.dim != 2) {
+            sortDim(start, end, split.dim, prims);
+        }
+    }
+};
+
+struct BinnedSahSplitter { // bvh/BinnedSahSplitter.hpp
+    static const int BinCount = 32;
+    IBox geomBounds[3][BinCount], centroidBounds[3][BinCount];
+    V3 centroidMin, centroidSpan;
+    int counts[3][BinCount];
+    BinnedSahSplitter() { std::memset(counts, 0, sizeof(counts)); }
+    int primitiveBin(const IPrim &p, int dim) const
+    {
+        int b = cvttss2si(float(BinCount)*((p.centroid[dim] - centroidMin[dim])/centroidSpan[dim]));
+        return b < 0 ? 0 : (b > BinCount - 1 ? BinCount - 1 : b); // clamp = min(max(val, lo), hi)
+    }
+    void findSahSplit(int dim, ISplit &split)
+    {
+        int rCount = 0, rCounts[BinCount];
+        IBox rBox, rBoxes[BinCount];
+        for (int i = BinCount - 1; i > 0; --i) {
+            rCount += counts[dim][i];
+            rBox.grow(geomBounds[dim][i]);
+            rCounts[i] = rCount;
+            rBoxes[i] = rBox;
+        }
+        int lCount = counts[dim][0];
+        IBox lBox = geomBounds[dim][0];
+        for (int i = 1; i < BinCount; ++i) {
+            float cost = 1.0f*(lBox.area()*float(lCount) + rBoxes[i].area()*float(rCounts[i]));
+            if (cost < split.cost) { split.dim = dim; split.idx = uint32_t(i); split.cost = cost; }
+            lCount += counts[dim][i];
+            lBox.grow(geomBounds[dim][i]);
+        }
+    }
+    uint32_t sortByBin(uint32_t start, uint32_t end, IPrims &prims, int dim, int bin)
+    {
+        uint32_t left = start, right = end;
+        while (left < right) {
+            while (left < right && primitiveBin(prims[left], dim) < bin) left++;
+            while (right > left && primitiveBin(prims[right], dim) >= bin) right--;
+            if (left != right) std::swap(prims[left], prims[right]);
+        }
+        if (left == end || right == start) return end + 1;
+        return left;
+    }
+    void fullSplit(uint32_t start, uint32_t end, IPrims &prims, const IBox &box, const IBox &centroidBox, ISplit &split)
+    {
+        centroidMin = centroidBox.lo; // partialBin
+        centroidSpan = centroidBox.diagonal();
+        for (int d = 0; d < 3; ++d)
+            if (centroidSpan[d] > 0.0f)
+                for (uint32_t i = start; i <= end; ++i) {
+                    int idx = primitiveBin(prims[i], d);
+                    geomBounds[d][idx].grow(prims[i].box);
+                    centroidBounds[d][idx].grow(prims[i].centroid);
+                    counts[d][idx]++;
+                }
+        split.dim = -1; // twoWaySahSplit
+        split.cost = box.area()*(float(end - start + 1)*1.0f - 1.0f);
+        for (int d = 0; d < 3; ++d)
+            if (centroidSpan[d] > 0.0f) findSahSplit(d, split);
+        if (split.dim == -1) { split.dim = maxDim(box.diagonal()); split.idx = BinCount/2; }
+        int bin = int(split.idx);
+        split.idx = sortByBin(start, end, prims, split.dim, bin);
+        if (split.idx > end || centroidSpan == 0.0f) {
+            split.idx = start + (end - start + 1)/2;
+            split.lBox = prims[start].box;
+            split.rBox = prims[end].box;
+            split.lCentroidBox = IBox(); split.lCentroidBox.lo = split.lCentroidBox.hi = prims[start].centroid;
+            split.rCentroidBox = IBox(); split.rCentroidBox.lo = split.rCentroidBox.hi = prims[end].centroid;
+            for (uint32_t i = start + 1; i < end; ++i) {
+                if (i < split.idx) { split.lBox.grow(prims[i].box); split.lCentroidBox.grow(prims[i].centroid); }
+                else { split.rBox.grow(prims[i].box); split.rCentroidBox.grow(prims[i].centroid); }
+            }
+        } else {
+            split.lBox = geomBounds[split.dim][0];
+            split.rBox = geomBounds[split.dim][BinCount - 1];
+            split.lCentroidBox = centroidBounds[split.dim][0];
+            split.rCentroidBox = centroidBounds[split.dim][BinCount - 1];
+            for (int i = 1; i < BinCount - 1; ++i) {
+                if (i < bin) { split.lBox.grow(geomBounds[split.dim][i]); split.lCentroidBox.grow(centroidBounds[split.dim][i]); }
+                else { split.rBox.grow(geomBounds[split.dim][i]); split.rCentroidBox.grow(centroidBounds[split.dim][i]); }
+            }
+        }
+    }
+};
+
+struct NaiveNode { // bvh/NaiveBvhNode.hpp
+    std::unique_ptr<NaiveNode> child[2];
+    IBox box;
+    uint32_t id = 0;
+    bool isLeaf() const { return !child[0]; }
+};
+
+// BvhBuilder.cpp:99-185 with branchFactor 2 (single-threaded paths; > 1M instances are refused at load)
+void naiveBuild(NaiveNode &dst, uint32_t start, uint32_t end, IPrims &prims, const IBox &geomBox, const IBox &centroidBox, int &depth)
+{
+    depth = 1;
+    dst.box = geomBox;
+    uint32_t numPrims = end - start + 1;
+    if (numPrims == 1) {
+        dst.id = prims[start].id;
+    } else if (numPrims <= 2) {
+        for (uint32_t i = start; i <= end; ++i) {
+            dst.child[i - start].reset(new NaiveNode());
+            dst.child[i - start]->box = prims[i].box;
+            dst.child[i - start]->id = prims[i].id;
+        }
+    } else {
+        ISplit split;
+        if (numPrims <= 64) FullSahSplitter::twoWaySahSplit(start, end, prims, geomBox, split);
+        else { std::unique_ptr<BinnedSahSplitter> b(new BinnedSahSplitter()); b->fullSplit(start, end, prims, geomBox, centroidBox, split); }
+        uint32_t starts[2] = {start, split.idx}, ends[2] = {split.idx - 1, end};
+        IBox geomBoxes[2] = {split.lBox, split.rBox}, centroidBoxes[2] = {split.lCentroidBox, split.rCentroidBox};
+        for (int i = 0; i < 2; ++i) dst.child[i].reset(new NaiveNode());
+        for (int i = 0; i < 2; ++i) {
+            int d;
+            naiveBuild(*dst.child[i], starts[i], ends[i], prims, geomBoxes[i], centroidBoxes[i], d);
+            depth = std::max(depth, d + 1);
+        }
+    }
+}
+
+struct TinyNode { float box[3][4]; int32_t l = -1, r = -1; uint32_t primIndex = 0, count = 0; bool isNode() const { return r >= 0; } };
+struct InstSet {
+    std::vector<TinyNode> nodes;
+    std::vector<uint32_t> primIndices;
+    IBox bounds;
+    int depth = 0;
+    std::vector<TriBvh> masterBvh; // per master; empty unless the master is a mesh
+};
+
+void setJointBbox(TinyNode &n, const IBox &l, const IBox &r)
+{
+    for (int k = 0; k < 3; ++k) { n.box[k][0] = l.lo[k]; n.box[k][1] = r.lo[k]; n.box[k][2] = l.hi[k]; n.box[k][3] = r.hi[k]; }
+}
+
+uint32_t tinyBuild(InstSet &s, const NaiveNode *node, uint32_t head, uint32_t &tail, uint32_t &primIndex, uint32_t maxPrimsPerLeaf)
+{ // BinaryBvh.hpp:120-146
+    if (node->isLeaf()) {
+        setJointBbox(s.nodes[head], node->box, node->box);
+        s.nodes[head].count = 1; s.nodes[head].primIndex = primIndex;
+        s.nodes[head].r = -1;
+        s.primIndices[primIndex++] = node->id;
+        return 1;
+    }
+    uint32_t childIdx = tail;
+    setJointBbox(s.nodes[head], node->child[0]->box, node->child[1]->box);
+    s.nodes[head].l = int32_t(childIdx);
+    s.nodes[head].r = int32_t(childIdx + 1);
+    tail += 2;
+    uint32_t lPrims = tinyBuild(s, node->child[0].get(), childIdx, tail, primIndex, maxPrimsPerLeaf);
+    uint32_t rPrims = tinyBuild(s, node->child[1].get(), childIdx + 1, tail, primIndex, maxPrimsPerLeaf);
+    if (lPrims + rPrims <= maxPrimsPerLeaf) {
+        s.nodes[head].count = lPrims + rPrims; s.nodes[head].primIndex = s.nodes[childIdx].primIndex;
+        s.nodes[head].r = -1;
+        tail = childIdx;
+    }
+    return lPrims + rPrims;
+}
+
+inline V3 qrot(const float *q, const V3 &o) { return qrotate(q, o); }
+
+inline bool bboxIntersection(const IBox &box, const V3 &o, const V3 &d, float &tMin, float &tMax) // BinaryBvh.hpp:148-171
+{
+    V3 invD(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    V3 relMin = box.lo - o, relMax = box.hi - o;
+    float ttMin = tMin, ttMax = tMax;
+    for (int i = 0; i < 3; ++i) {
+        if (invD[i] >= 0.0f) {
+            ttMin = fmax2(ttMin, relMin[i]*invD[i]);
+            ttMax = fmin2(ttMax, relMax[i]*invD[i]);
+        } else {
+            ttMax = fmin2(ttMax, relMin[i]*invD[i]);
+            ttMin = fmax2(ttMin, relMax[i]*invD[i]);
+        }
+    }
+    if (ttMin <= ttMax) { tMin = ttMin; tMax = ttMax; return true; }
+    return false;
+}
+} // namespace
+
+struct oracle_instances { std::vector<InstSet> sets; };
+
+void oracle_ctx::buildInstances()
+{
+    inst.reset(new oracle_instances());
+    for (uint32_t si = 0; si < sc.n_instance_sets; ++si) {
+        const tgpu_instances &is = sc.instance_sets[si];
+        inst->sets.emplace_back();
+        InstSet &s = inst->sets.back();
+        s.masterBvh.resize(is.n_masters);
+        for (uint32_t m = 0; m < is.n_masters; ++m)
+            if (is.masters[m].kind == TGPU_MASTER_MESH) buildBvh(is.masters[m].first, is.masters[m].count, s.masterBvh[m]);
+        // Instance::prepareForRender :405-424
+        IPrims prims;
+        prims.reserve(is.n_instances);
+        for (uint32_t i = 0; i < is.n_instances; ++i) {
+            const tgpu_master &mm = is.masters[is.master_id[i]];
+            V3 bmin(mm.bounds_min), bmax(mm.bounds_max), pos(is.pos + size_t(i)*3);
+            IBox bGlobal;
+            for (int xi = 0; xi < 2; ++xi)
+                for (int yi = 0; yi < 2; ++yi)
+                    for (int zi = 0; zi < 2; ++zi) {
+                        V3 t{float(xi), float(yi), float(zi)};
+                        V3 corner = bmin*(V3(1.0f, 1.0f, 1.0f) - t) + bmax*t; // lerp(a, b, ratio) = a*(1 - ratio) + b*ratio
+                        bGlobal.grow(pos + qrot(is.rot + size_t(i)*4, corner));
+                    }
+            IPrim p;
+            p.box = bGlobal; p.centroid = bGlobal.center(); p.id = i; p.area = bGlobal.area();
+            prims.push_back(p);
+        }
+        // BinaryBvh(prims, 2) :174-195
+        s.nodes.clear();
+        if (prims.empty()) {
+            s.depth = 0;
+            s.nodes.emplace_back();
+            setJointBbox(s.nodes[0], IBox(), IBox());
+            s.nodes[0].l = 0; s.nodes[0].r = 0; // rChild = itself: an inner node that never passes the box test
+            continue;
+        }
+        IBox geomBounds, centroidBounds;
+        for (const IPrim &p : prims) { geomBounds.grow(p.box); centroidBounds.grow(p.centroid); }
+        NaiveNode root;
+        size_t count = prims.size();
+        naiveBuild(root, 0, uint32_t(count - 1), prims, geomBounds, centroidBounds, s.depth);
+        s.bounds = root.box;
+        s.primIndices.resize(count);
+        s.nodes.resize(2*count);
+        uint32_t tail = 1, primIndex = 0;
+        tinyBuild(s, &root, 0, tail, primIndex, 2);
+        s.nodes.resize(tail);
+    }
+}
+
+// A master primitive's intersect() on the instance-local ray (mesh: TriangleMesh.cpp:317-335 on the master's own
+// Embree scene; quad / cube: the scene primitives' code)
+bool oracle_ctx::masterIntersect(uint32_t setIndex, uint32_t master, Ray &ray, Temp &data, Counters &c) const
+{
+    const InstSet &s = inst->sets[setIndex];
+    const tgpu_master &mm = sc.instance_sets[setIndex].masters[master];
+    if (mm.kind == TGPU_MASTER_QUAD) return quadIntersect(sc.quads[mm.first], mm.first, ray, data);
+    if (mm.kind == TGPU_MASTER_CUBE) return cubeIntersect(sc.cubes[mm.first], mm.first, ray, data);
+    float t = ray.farT, u = 0, v = 0;
+    uint32_t prim = 0xFFFFFFFFu;
+    intersectTris(s.masterBvh[master], ray, t, u, v, prim, c);
+    if (prim == 0xFFFFFFFFu) return false;
+    ray.farT = t;
+    data.kind = PRIM_TRI;
+    data.index = prim;
+    data.u = u;
+    data.v = v;
+    const float *p = sc.tri_pos + size_t(prim)*9;
+    V3 p0(p), p1(p + 3), p2(p + 6);
+    data.Ng = (p1 - p0).cross(p2 - p0);
+    data.backSide = data.Ng.dot(ray.dir) > 0.0f; // with the LOCAL direction
+    return true;
+}
+
+bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Counters &c) const // Instance.cpp:290-311
+{
+    const InstSet &s = inst->sets[setIndex];
+    const tgpu_instances &is = sc.instance_sets[setIndex];
+    bool hit = false;
+    uint32_t prim = 0;
+    auto intersector = [&](uint32_t id, float tMin) {
+        float invRot[4] = {is.rot[size_t(id)*4], -is.rot[size_t(id)*4 + 1], -is.rot[size_t(id)*4 + 2], -is.rot[size_t(id)*4 + 3]};
+        Ray localRay{qrot(invRot, ray.pos - V3(is.pos + size_t(id)*3)), qrot(invRot, ray.dir), tMin, INF}; // Ray::scatter: farT = infinity
+        if (masterIntersect(setIndex, is.master_id[id], localRay, data, c)) {
+            hit = true;
+            prim = id;
+            ray.farT = localRay.farT;
+        }
+    };
+    // ---- BinaryBvh::trace (:188-283), the SSE lanes written out per child
+    float tMin = ray.nearT, tMax = ray.farT;
+    if (!bboxIntersection(s.bounds, ray.pos, ray.dir, tMin, tMax)) return false;
+    struct StackNode { int32_t node; float tMin; };
+    std::vector<StackNode> stack(size_t(s.depth) + 2);
+    size_t sp = 0;
+    const V3 o = ray.pos, d = ray.dir;
+    const V3 invDir(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    const float nearLane = ray.nearT;
+    float negFarLane = -ray.farT;
+    int32_t node = 0;
+    while (true) {
+        bool skipLeaf = false;
+        while (s.nodes[size_t(node)].isNode()) {
+            const TinyNode &n = s.nodes[size_t(node)];
+            c.nodes++;
+            float mn[2], mx[2];
+            for (int ch = 0; ch < 2; ++ch) {
+                float tn[3], tfNeg[3];
+                for (int k = 0; k < 3; ++k) {
+                    float lo = n.box[k][ch], hi = n.box[k][2 + ch];
+                    float nearPlane = d[k] >= 0.0f ? lo : hi, farPlane = d[k] >= 0.0f ? hi : lo;
+                    tn[k] = (nearPlane - o[k])*invDir[k];
+                    tfNeg[k] = (farPlane - o[k])*(-invDir[k]);
+                }
+                mn[ch] = sseMax(sseMax(sseMax(tn[0], tn[1]), tn[2]), nearLane);
+                mx[ch] = -sseMax(sseMax(sseMax(tfNeg[0], tfNeg[1]), tfNeg[2]), negFarLane);
+            }
+            bool intersectsL = mn[0] <= mx[0], intersectsR = mn[1] <= mx[1];
+            if (intersectsL && intersectsR) {
+                if (mn[0] < mn[1]) { stack[sp++] = StackNode{n.r, mn[1]}; node = n.l; tMin = mn[0]; }
+                else { stack[sp++] = StackNode{n.l, mn[0]}; node = n.r; tMin = mn[1]; }
+            } else if (intersectsL) { node = n.l; tMin = mn[0]; }
+            else if (intersectsR) { node = n.r; tMin = mn[1]; }
+            else { skipLeaf = true; break; }
+        }
+        if (!skipLeaf) {
+            const TinyNode &leaf = s.nodes[size_t(node)];
+            for (uint32_t i = leaf.primIndex; i < leaf.primIndex + leaf.count; ++i) intersector(s.primIndices[i], tMin);
+            tMax = fmin2(tMax, ray.farT);
+            negFarLane = -tMax;
+        }
+        bool done = false;
+        while (true) { // pop
+            if (sp == 0) { done = true; break; }
+            --sp;
+            node = stack[sp].node;
+            tMin = stack[sp].tMin;
+            if (tMax < tMin) continue;
+            break;
+        }
+        if (done) break;
+    }
+    if (hit) {
+        data.inst = int32_t(prim);
+        data.instSet = int32_t(setIndex);
+    }
+    return hit;
 }
 
 bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const // renderer/TraceableScene.hpp:170-192
 {
     info.kind = PRIM_NONE;
     data.kind = PRIM_NONE;
-    for (uint32_t i = 0; i < sc.n_quads; ++i) quadIntersect(sc.quads[i], i, ray, data);
-    for (uint32_t i = 0; i < sc.n_cubes; ++i) cubeIntersect(sc.cubes[i], i, ray, data);
+    data.inst = data.instSet = -1;
+    // Order of the finites: "instances" primitives first, then everything else.  Embree visits its user geometries
+    // front to back by box entry; an Instance is the only primitive whose result depends on what was found before
+    // it (it ignores the incoming farT for its local rays), and its box is normally entered first.
+    for (uint32_t i = 0; i < sc.n_instance_sets; ++i) instanceIntersect(i, ray, data, c);
+    for (uint32_t i = 0; i < sc.n_quads; ++i)
+        if (quadIntersect(sc.quads[i], i, ray, data)) data.inst = data.instSet = -1;
+    for (uint32_t i = 0; i < sc.n_cubes; ++i) {
+        float before = ray.farT;
+        cubeIntersect(sc.cubes[i], i, ray, data);
+        if (ray.farT != before) data.inst = data.instSet = -1;
+    }
     float t = ray.farT, u = 0, v = 0;
     uint32_t prim = 0xFFFFFFFFu;
-    intersectTris(ray, t, u, v, prim, c);
+    intersectTris(sceneBvh, ray, t, u, v, prim, c);
     if (prim != 0xFFFFFFFFu) { // primitives/TriangleMesh.cpp:317-335
+        data.inst = data.instSet = -1;
         ray.farT = t;
         data.kind = PRIM_TRI;
         data.index = prim;
@@ -1448,7 +1910,9 @@ oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_m
     ctx->rngMode = rng_mode;
     ctx->mathMode = math_mode;
     ctx->rcpMode = rcp_mode;
-    ctx->buildBvh();
+    ctx->prepareTris();
+    ctx->buildBvh(0, ctx->sc.n_tris, ctx->sceneBvh);
+    ctx->buildInstances();
     return ctx;
 }
 

@@ -30,6 +30,9 @@ FIXTURES = [
     ("c1_128x72_32spp", "materialtest/c1_noadapt.json", (128, 72), 32),
     ("cornell_96x54_8spp", "cornell-box/scene_sobol.json", (96, 54), 8),
     # the stock scene WITH its adaptive sampling (4 passes of 16 spp: 1 uniform + 3 redistributed)
+    # "instances" primitive: cube + quad masters, overlapping rotated instances (Instance.cpp's last-hit-wins traversal)
+    ("inst_cubes_128x72_8spp", "instances/inst_cubes.json", (128, 72), 8),
+    ("inst_many_96x54_4spp", "instances/inst_many.json", (96, 54), 4),    # 294 instances: binned-SAH levels of the BVH2
     ("c1_adaptive_128x72_64spp", "materialtest/materialtest.json", (128, 72), 64, True),
 ]
 

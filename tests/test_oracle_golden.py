@@ -16,6 +16,9 @@ CASES = [
     ("c1_128x72_4spp", "materialtest/c1_noadapt.json", (128, 72), 4),  # stock scene: SmoothCoat over Cu
     ("c1_128x72_32spp", "materialtest/c1_noadapt.json", (128, 72), 32),
     ("cornell_96x54_8spp", "cornell-box/scene_sobol.json", (96, 54), 8),  # quads, cubes, quad light
+    # "instances" primitives: BVH2 build + ordered traversal + last-hit-wins + the double-transformed hit point
+    ("inst_cubes_128x72_8spp", "instances/inst_cubes.json", (128, 72), 8),   # 16 instances (full-sweep SAH only)
+    ("inst_many_96x54_4spp", "instances/inst_many.json", (96, 54), 4),       # 294 instances (binned SAH levels)
 ]
 
 

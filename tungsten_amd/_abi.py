@@ -1,7 +1,7 @@
 """ctypes mirror of include/tungsten_amd.h (keep in sync; tests/test_abi.py checks sizes)."""
 import ctypes as C
 
-TGPU_ABI_VERSION = 1
+TGPU_ABI_VERSION = 2
 
 f32 = C.c_float
 i32 = C.c_int32
@@ -60,6 +60,15 @@ class Light(C.Structure):
     _fields_ = [("kind", i32), ("index", i32)]
 
 
+class Master(C.Structure):
+    _fields_ = [("kind", i32), ("first", u32), ("count", u32), ("bounds_min", f32*3), ("bounds_max", f32*3)]
+
+
+class Instances(C.Structure):
+    _fields_ = [("n_masters", u32), ("masters", C.POINTER(Master)), ("n_instances", u32), ("pos", pf32), ("rot", pf32),
+                ("master_id", pu8)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", u32), ("camera", Camera), ("settings", Settings),
                 ("n_tris", u32), ("tri_pos", pf32), ("tri_normal", pf32), ("tri_uv", pf32), ("tri_bsdf", pi32),
@@ -71,6 +80,8 @@ class SceneDesc(C.Structure):
                 ("n_bitmaps", u32), ("bitmaps", C.POINTER(Bitmap)),
                 ("n_lights", u32), ("lights", C.POINTER(Light)),
                 ("env", Env),
+                ("n_master_tris", u32), ("n_master_quads", u32), ("n_master_cubes", u32),
+                ("n_instance_sets", u32), ("instance_sets", C.POINTER(Instances)),
                 ("sobol_matrices", pu32)]
 
 

@@ -545,6 +545,115 @@ int Scene::fetchBsdf(const Json &v) // Scene.cpp:83-93,120-125
     throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
 }
 
+MeshData Scene::parseMesh(const Json &v, const Mat4 &transform, int emissionTex)
+{
+    if (emissionTex >= 0) throw std::runtime_error("emissive meshes are outside the hot-path scope");
+    MeshData m;
+    v.getField("name", m.name);
+    m.transform = transform;
+    v.getField("smooth", m.smooth);
+    bool recompute = false;
+    v.getField("recompute_normals", recompute);
+    if (recompute) throw std::runtime_error("recompute_normals is outside the hot-path scope");
+    const Json &bsdf = v["bsdf"];
+    if (bsdf.isArray())
+        for (size_t i = 0; i < bsdf.size(); ++i) m.bsdfs.push_back(fetchBsdf(bsdf[i]));
+    else if (bsdf)
+        m.bsdfs.push_back(fetchBsdf(bsdf));
+    else {
+        Json d = Json::parse("{\"type\":\"lambert\",\"albedo\":1}"); // Primitive::_defaultBsdf
+        m.bsdfs.push_back(parseBsdf(d));
+    }
+    std::string file;
+    if (v.getField("file", file)) {
+        std::string full = file.size() && file[0] == '/' ? file : sceneDir + "/" + file;
+        if (!endsWith(full, ".wo3") || !loadWo3(full, m.verts, m.tris))
+            throw std::runtime_error("Unable to load triangle mesh at " + full);
+    }
+    return m;
+}
+
+// ---- QuaternionF (math/Quaternion.hpp), stored w x y z ----
+namespace {
+struct Quat {
+    float v[4];
+    static Quat fromMatrix(const Mat4 &a) // Quaternion.hpp:113-151
+    {
+        float trace = a(0, 0) + a(1, 1) + a(2, 2);
+        if (trace > 0.0f) {
+            float s = 0.5f/std::sqrt(trace + 1.0f);
+            return Quat{{0.25f/s, (a(2, 1) - a(1, 2))*s, (a(0, 2) - a(2, 0))*s, (a(1, 0) - a(0, 1))*s}};
+        } else if (a(0, 0) > a(1, 1) && a(0, 0) > a(2, 2)) {
+            float s = 2.0f*std::sqrt(1.0f + a(0, 0) - a(1, 1) - a(2, 2));
+            return Quat{{(a(2, 1) - a(1, 2))/s, 0.25f*s, (a(0, 1) + a(1, 0))/s, (a(0, 2) + a(2, 0))/s}};
+        } else if (a(1, 1) > a(2, 2)) {
+            float s = 2.0f*std::sqrt(1.0f + a(1, 1) - a(0, 0) - a(2, 2));
+            return Quat{{(a(0, 2) - a(2, 0))/s, (a(0, 1) + a(1, 0))/s, 0.25f*s, (a(1, 2) + a(2, 1))/s}};
+        } else {
+            float s = 2.0f*std::sqrt(1.0f + a(2, 2) - a(0, 0) - a(1, 1));
+            return Quat{{(a(1, 0) - a(0, 1))/s, (a(0, 2) + a(2, 0))/s, (a(1, 2) + a(2, 1))/s, 0.25f*s}};
+        }
+    }
+    static Quat fromAxisAngle(float theta, const Vec3 &u) // Quaternion.hpp:32-40
+    {
+        float cosTheta = std::cos(theta/2.0f), sinTheta = std::sin(theta/2.0f);
+        return Quat{{cosTheta, u.x*sinTheta, u.y*sinTheta, u.z*sinTheta}};
+    }
+    Quat operator*(const Quat &o) const // :66-73
+    {
+        return Quat{{v[0]*o.v[0] - v[1]*o.v[1] - v[2]*o.v[2] - v[3]*o.v[3],
+                     v[0]*o.v[1] + v[1]*o.v[0] + v[2]*o.v[3] - v[3]*o.v[2],
+                     v[0]*o.v[2] - v[1]*o.v[3] + v[2]*o.v[0] + v[3]*o.v[1],
+                     v[0]*o.v[3] + v[1]*o.v[2] - v[2]*o.v[1] + v[3]*o.v[0]}};
+    }
+};
+
+// Instance files (Instance.cpp:129-232): u32 count, u32 compression flags, Box3f position bounds, per-instance
+// records (lossless: pos3 + rotation vector3; lossy: 3 x u32), then count master ids (u8)
+bool loadInstanceFile(const std::string &path, std::vector<float> &pos, std::vector<Quat> &rot, std::vector<uint8_t> &id)
+{
+    std::string data = readFile(path);
+    if (data.size() < 32) return false;
+    const char *p = data.data(), *end = p + data.size();
+    auto rd = [&](void *dst, size_t n) { if (p + n > end) return false; std::memcpy(dst, p, n); p += n; return true; };
+    uint32_t count, compressed;
+    float bounds[6];
+    if (!rd(&count, 4) || !rd(&compressed, 4) || !rd(bounds, 24)) return false;
+    pos.resize(size_t(count)*3);
+    rot.resize(count);
+    id.resize(count);
+    const float TWO_PI_ = 6.283185307f; // Angle.hpp
+    for (uint32_t i = 0; i < count; ++i) {
+        if (compressed & 1u) { // loadLossyInstance :131-160
+            uint32_t a, b, c;
+            if (!rd(&a, 4) || !rd(&b, 4) || !rd(&c, 4)) return false;
+            uint32_t mask = (1u << 21) - 1u;
+            uint32_t xyz[3] = {a >> 11, ((a << 10) | (b >> 22)) & mask, (b >> 1) & mask};
+            uint32_t r = c & 255u, axisX = (c >> 8) & 4095u, axisY = (c >> 20) & 4095u;
+            float axisXf = (axisX/float(1 << 12))*2.0f - 1.0f;
+            float axisYf = (axisY/float(1 << 12))*2.0f - 1.0f;
+            float rotW = TWO_PI_*r/(1 << 8);
+            float zz = 1 - axisXf*axisXf - axisYf*axisYf;
+            Vec3 w(axisXf, axisYf, std::sqrt(zz > 0.0f ? zz : 0.0f));
+            for (int k = 0; k < 3; ++k) {
+                float t = float(xyz[k])/float(1 << 21);
+                pos[size_t(i)*3 + k] = bounds[k]*(1.0f - t) + bounds[3 + k]*t;
+            }
+            rot[i] = Quat::fromAxisAngle(rotW, w);
+        } else { // loadLosslessInstance :161-170
+            float rec[6];
+            if (!rd(rec, 24)) return false;
+            for (int k = 0; k < 3; ++k) pos[size_t(i)*3 + k] = rec[k];
+            Vec3 w(rec[3], rec[4], rec[5]);
+            float angle = w.length();
+            w = angle > 0 ? w/angle : Vec3(0.0f, 1.0f, 0.0f);
+            rot[i] = Quat::fromAxisAngle(angle, w);
+        }
+    }
+    return rd(id.data(), count);
+}
+} // namespace
+
 void Scene::parsePrimitive(const Json &v)
 {
     std::string type = v["type"].asString();
@@ -556,30 +665,7 @@ void Scene::parsePrimitive(const Json &v)
     if (v["emission"]) emissionTex = fetchTexture(v["emission"], false);
 
     if (type == "mesh") {
-        if (emissionTex >= 0) throw std::runtime_error("emissive meshes are outside the hot-path scope");
-        MeshData m;
-        v.getField("name", m.name);
-        m.transform = transform;
-        v.getField("smooth", m.smooth);
-        bool recompute = false;
-        v.getField("recompute_normals", recompute);
-        if (recompute) throw std::runtime_error("recompute_normals is outside the hot-path scope");
-        const Json &bsdf = v["bsdf"];
-        if (bsdf.isArray())
-            for (size_t i = 0; i < bsdf.size(); ++i) m.bsdfs.push_back(fetchBsdf(bsdf[i]));
-        else if (bsdf)
-            m.bsdfs.push_back(fetchBsdf(bsdf));
-        else {
-            Json d = Json::parse("{\"type\":\"lambert\",\"albedo\":1}"); // Primitive::_defaultBsdf
-            m.bsdfs.push_back(parseBsdf(d));
-        }
-        std::string file;
-        if (v.getField("file", file)) {
-            std::string full = file.size() && file[0] == '/' ? file : sceneDir + "/" + file;
-            if (!endsWith(full, ".wo3") || !loadWo3(full, m.verts, m.tris))
-                throw std::runtime_error("Unable to load triangle mesh at " + full);
-        }
-        meshes.push_back(std::move(m));
+        meshes.push_back(parseMesh(v, transform, emissionTex));
         _primOrder.push_back({PrimMesh, int(meshes.size()) - 1});
     } else if (type == "quad") {
         QuadSrc q{transform, fetchBsdf(v["bsdf"]), emissionTex};
@@ -589,6 +675,48 @@ void Scene::parsePrimitive(const Json &v)
         CubeSrc c{transform, fetchBsdf(v["bsdf"]), emissionTex};
         _cubeSrc.push_back(c);
         _primOrder.push_back({PrimCube, int(_cubeSrc.size()) - 1});
+    } else if (type == "instances") { // Instance::fromJson (Instance.cpp:60-93)
+        if (emissionTex >= 0) throw std::runtime_error("emissive 'instances' primitives are outside the hot-path scope");
+        if (v["instancesB"]) throw std::runtime_error("'instancesB'/'ratio' blending is outside the hot-path scope");
+        InstanceSrc src;
+        src.transform = transform;
+        const Json &masters = v["masters"];
+        for (size_t i = 0; masters && i < masters.size(); ++i) {
+            const Json &m = masters[i];
+            std::string mt = m["type"].asString();
+            Mat4 mtf;
+            if (m["transform"]) mtf = parseTransform(m["transform"]);
+            if (m["int_medium"] || m["ext_medium"]) throw std::runtime_error("participating media are outside the round-1 scope");
+            MasterSrc ms{};
+            if (mt == "mesh") { ms.kind = TGPU_MASTER_MESH; ms.mesh = parseMesh(m, mtf, -1); }
+            else if (mt == "quad") { ms.kind = TGPU_MASTER_QUAD; ms.quad = QuadSrc{mtf, fetchBsdf(m["bsdf"]), -1}; }
+            else if (mt == "cube") { ms.kind = TGPU_MASTER_CUBE; ms.cube = CubeSrc{mtf, fetchBsdf(m["bsdf"]), -1}; }
+            else throw std::runtime_error("instance master of type '" + mt + "' is outside the hot-path scope");
+            src.masters.push_back(std::move(ms));
+        }
+        if (src.masters.empty() || src.masters.size() > 256) throw std::runtime_error("'instances' needs 1..256 masters");
+        std::vector<Quat> rot;
+        const Json &inst = v["instances"] ? v["instances"] : v["instancesA"];
+        if (inst.isString()) {
+            std::string file = inst.asString();
+            std::string full = file.size() && file[0] == '/' ? file : sceneDir + "/" + file;
+            if (!loadInstanceFile(full, src.pos, rot, src.id)) throw std::runtime_error("Unable to load instances at " + full);
+        } else if (inst) {
+            for (size_t i = 0; i < inst.size(); ++i) {
+                int id = 0;
+                inst[i].getField("id", id);
+                Mat4 tf;
+                if (inst[i]["transform"]) tf = parseTransform(inst[i]["transform"]);
+                Vec3 t = tf.translation();
+                src.pos.push_back(t.x); src.pos.push_back(t.y); src.pos.push_back(t.z);
+                rot.push_back(Quat::fromMatrix(tf.extractRotation()));
+                src.id.push_back(uint8_t(id));
+            }
+        }
+        for (uint8_t id : src.id)
+            if (id >= src.masters.size()) throw std::runtime_error("'instances': master id out of range");
+        for (const Quat &q : rot) for (int k = 0; k < 4; ++k) src.rot.push_back(q.v[k]);
+        _instanceSrc.push_back(std::move(src));
     } else if (type == "infinite_sphere") {
         if (_envSrc.present) throw std::runtime_error("more than one infinite_sphere is outside the hot-path scope");
         _envSrc.present = true;
@@ -719,6 +847,74 @@ static float filterEval(const std::string &name, float x) // ReconstructionFilte
     throw JsonLoadException("Unknown reconstruction filter '" + name + "'");
 }
 
+void Scene::bakeMesh(const MeshData &m, float *boundsMin, float *boundsMax)
+{
+    size_t nv = m.verts.size()/8, nt = m.tris.size()/4;
+    Mat4 normalTform = m.transform.toNormalMatrix();
+    std::vector<Vec3> p(nv), n(nv);
+    if (boundsMin) for (int k = 0; k < 3; ++k) { boundsMin[k] = std::numeric_limits<float>::max(); boundsMax[k] = std::numeric_limits<float>::lowest(); }
+    for (size_t i = 0; i < nv; ++i) {
+        const float *v = &m.verts[i*8];
+        p[i] = m.transform*Vec3(v[0], v[1], v[2]);
+        n[i] = normalTform.transformVector(Vec3(v[3], v[4], v[5]));
+        if (boundsMin) // TriangleMesh::computeBounds :233-239 (every vertex, referenced or not)
+            for (int k = 0; k < 3; ++k) { boundsMin[k] = std::min(boundsMin[k], p[i][k]); boundsMax[k] = std::max(boundsMax[k], p[i][k]); }
+    }
+    for (size_t i = 0; i < nt; ++i) {
+        const uint32_t *tri = &m.tris[i*4];
+        int material = int(int32_t(tri[3]));
+        material = std::min(std::max(material, 0), int(m.bsdfs.size()) - 1);
+        for (int k = 0; k < 3; ++k) {
+            uint32_t vi = tri[k];
+            if (vi >= nv) throw std::runtime_error("mesh '" + m.name + "' has an out-of-range vertex index");
+            _triPos.push_back(p[vi].x); _triPos.push_back(p[vi].y); _triPos.push_back(p[vi].z);
+            _triNormal.push_back(n[vi].x); _triNormal.push_back(n[vi].y); _triNormal.push_back(n[vi].z);
+            _triUv.push_back(m.verts[size_t(vi)*8 + 6]); _triUv.push_back(m.verts[size_t(vi)*8 + 7]);
+        }
+        _triBsdf.push_back(m.bsdfs[size_t(material)]);
+        _triSmooth.push_back(m.smooth ? 1 : 0);
+    }
+}
+
+tgpu_quad Scene::bakeQuad(const QuadSrc &q) const
+{
+    tgpu_quad o{};
+    Vec3 base = q.transform*Vec3(0.0f);
+    Vec3 edge0 = q.transform.transformVector(Vec3(1.0f, 0.0f, 0.0f));
+    Vec3 edge1 = q.transform.transformVector(Vec3(0.0f, 0.0f, 1.0f));
+    base -= edge0*0.5f;
+    base -= edge1*0.5f;
+    Vec3 n = edge1.cross(edge0);
+    float area = n.length();
+    n /= area;
+    Vec3 tg = edge0.normalized(), bt = edge1.normalized();
+    for (int i = 0; i < 3; ++i) {
+        o.base[i] = base[i]; o.edge0[i] = edge0[i]; o.edge1[i] = edge1[i];
+        o.normal[i] = n[i]; o.tangent[i] = tg[i]; o.bitangent[i] = bt[i];
+    }
+    o.area = area;
+    o.inv_uv_sq[0] = 1.0f/edge0.lengthSq();
+    o.inv_uv_sq[1] = 1.0f/edge1.lengthSq();
+    o.bsdf = q.bsdf;
+    o.emission_tex = q.emissionTex;
+    return o;
+}
+
+tgpu_cube Scene::bakeCube(const CubeSrc &c) const
+{
+    tgpu_cube o{};
+    Vec3 p = c.transform*Vec3(0.0f);
+    Vec3 sc = c.transform.extractScale()*Vec3(0.5f);
+    Mat4 rot = c.transform.extractRotation();
+    Mat4 inv = rot.transpose();
+    storeMat3(rot, o.rot);
+    storeMat3(inv, o.inv_rot);
+    for (int i = 0; i < 3; ++i) { o.pos[i] = p[i]; o.scale[i] = sc[i]; }
+    o.bsdf = c.bsdf;
+    o.emission_tex = c.emissionTex;
+    return o;
+}
+
 void Scene::flatten()
 {
     const int RFILTER_RESOLUTION = 31;
@@ -763,80 +959,91 @@ void Scene::flatten()
 
     // ---- meshes: world-space bake (TriangleMesh.cpp:524-552) ----
     _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear();
-    for (const MeshData &m : meshes) {
-        size_t nv = m.verts.size()/8, nt = m.tris.size()/4;
-        Mat4 normalTform = m.transform.toNormalMatrix();
-        std::vector<Vec3> p(nv), n(nv);
-        for (size_t i = 0; i < nv; ++i) {
-            const float *v = &m.verts[i*8];
-            p[i] = m.transform*Vec3(v[0], v[1], v[2]);
-            n[i] = normalTform.transformVector(Vec3(v[3], v[4], v[5]));
-        }
-        for (size_t i = 0; i < nt; ++i) {
-            const uint32_t *tri = &m.tris[i*4];
-            int material = int(int32_t(tri[3]));
-            material = std::min(std::max(material, 0), int(m.bsdfs.size()) - 1);
-            for (int k = 0; k < 3; ++k) {
-                uint32_t vi = tri[k];
-                if (vi >= nv) throw std::runtime_error("mesh '" + m.name + "' has an out-of-range vertex index");
-                _triPos.push_back(p[vi].x); _triPos.push_back(p[vi].y); _triPos.push_back(p[vi].z);
-                _triNormal.push_back(n[vi].x); _triNormal.push_back(n[vi].y); _triNormal.push_back(n[vi].z);
-                _triUv.push_back(m.verts[size_t(vi)*8 + 6]); _triUv.push_back(m.verts[size_t(vi)*8 + 7]);
+    for (const MeshData &m : meshes) bakeMesh(m, nullptr, nullptr);
+    _desc.n_tris = uint32_t(_triBsdf.size());
+
+    // ---- quads (Quad.cpp:298-316), cubes (Cube.cpp:353-370) ----
+    _quads.clear();
+    for (const QuadSrc &q : _quadSrc) _quads.push_back(bakeQuad(q));
+    _desc.n_quads = uint32_t(_quads.size());
+    _cubes.clear();
+    for (const CubeSrc &c : _cubeSrc) _cubes.push_back(bakeCube(c));
+    _desc.n_cubes = uint32_t(_cubes.size());
+
+    // ---- "instances": masters go to the tail of the geometry arrays; Instance::prepareForRender :392-403 ----
+    _instanceFlat.clear();
+    _instanceSets.clear();
+    for (const InstanceSrc &src : _instanceSrc) {
+        _instanceFlat.emplace_back();
+        InstanceFlat &f = _instanceFlat.back();
+        for (const MasterSrc &ms : src.masters) {
+            tgpu_master m{};
+            m.kind = ms.kind;
+            if (ms.kind == TGPU_MASTER_MESH) {
+                m.first = uint32_t(_triBsdf.size());
+                bakeMesh(ms.mesh, m.bounds_min, m.bounds_max);
+                m.count = uint32_t(_triBsdf.size()) - m.first;
+                if (m.count == 0) throw std::runtime_error("instance master mesh has no triangles");
+            } else if (ms.kind == TGPU_MASTER_QUAD) {
+                m.first = uint32_t(_quads.size());
+                m.count = 1;
+                tgpu_quad q = bakeQuad(ms.quad);
+                _quads.push_back(q);
+                Vec3 base(q.base[0], q.base[1], q.base[2]), e0(q.edge0[0], q.edge0[1], q.edge0[2]), e1(q.edge1[0], q.edge1[1], q.edge1[2]);
+                Vec3 corners[4] = {base, base + e0, base + e1, base + e0 + e1}; // Quad::bounds :281-289
+                for (int k = 0; k < 3; ++k) { m.bounds_min[k] = std::numeric_limits<float>::max(); m.bounds_max[k] = std::numeric_limits<float>::lowest(); }
+                for (const Vec3 &c : corners)
+                    for (int k = 0; k < 3; ++k) { m.bounds_min[k] = std::min(m.bounds_min[k], c[k]); m.bounds_max[k] = std::max(m.bounds_max[k], c[k]); }
+            } else {
+                m.first = uint32_t(_cubes.size());
+                m.count = 1;
+                tgpu_cube c = bakeCube(ms.cube);
+                _cubes.push_back(c);
+                for (int k = 0; k < 3; ++k) { m.bounds_min[k] = std::numeric_limits<float>::max(); m.bounds_max[k] = std::numeric_limits<float>::lowest(); }
+                for (int i = 0; i < 8; ++i) { // Cube::bounds :333-344 (_rot*v is the point transform of a rotation matrix)
+                    Vec3 v((i & 1 ? c.scale[0] : -c.scale[0]), (i & 2 ? c.scale[1] : -c.scale[1]), (i & 4 ? c.scale[2] : -c.scale[2]));
+                    Vec3 r(c.rot[0]*v.x + c.rot[1]*v.y + c.rot[2]*v.z + 0.0f, c.rot[3]*v.x + c.rot[4]*v.y + c.rot[5]*v.z + 0.0f,
+                           c.rot[6]*v.x + c.rot[7]*v.y + c.rot[8]*v.z + 0.0f);
+                    for (int k = 0; k < 3; ++k) {
+                        float w = c.pos[k] + r[k];
+                        m.bounds_min[k] = std::min(m.bounds_min[k], w);
+                        m.bounds_max[k] = std::max(m.bounds_max[k], w);
+                    }
+                }
             }
-            _triBsdf.push_back(m.bsdfs[size_t(material)]);
-            _triSmooth.push_back(m.smooth ? 1 : 0);
+            f.masters.push_back(m);
+        }
+        Quat own = Quat::fromMatrix(src.transform.extractRotation());
+        size_t n = src.id.size();
+        f.pos.resize(n*3); f.rot.resize(n*4); f.id = src.id;
+        for (size_t i = 0; i < n; ++i) {
+            Vec3 p = src.transform*Vec3(src.pos[i*3], src.pos[i*3 + 1], src.pos[i*3 + 2]);
+            Quat q = own*Quat{{src.rot[i*4], src.rot[i*4 + 1], src.rot[i*4 + 2], src.rot[i*4 + 3]}};
+            for (int k = 0; k < 3; ++k) f.pos[i*3 + k] = p[k];
+            for (int k = 0; k < 4; ++k) f.rot[i*4 + k] = q.v[k];
         }
     }
-    _desc.n_tris = uint32_t(_triBsdf.size());
+    for (InstanceFlat &f : _instanceFlat) {
+        tgpu_instances is{};
+        is.n_masters = uint32_t(f.masters.size());
+        is.masters = f.masters.data();
+        is.n_instances = uint32_t(f.id.size());
+        is.pos = f.pos.data();
+        is.rot = f.rot.data();
+        is.master_id = f.id.data();
+        _instanceSets.push_back(is);
+    }
+    _desc.n_instance_sets = uint32_t(_instanceSets.size());
+    _desc.instance_sets = _instanceSets.data();
+    _desc.n_master_tris = uint32_t(_triBsdf.size()) - _desc.n_tris;
+    _desc.n_master_quads = uint32_t(_quads.size()) - _desc.n_quads;
+    _desc.n_master_cubes = uint32_t(_cubes.size()) - _desc.n_cubes;
     _desc.tri_pos = _triPos.data();
     _desc.tri_normal = _triNormal.data();
     _desc.tri_uv = _triUv.data();
     _desc.tri_bsdf = _triBsdf.data();
     _desc.tri_smooth = _triSmooth.data();
-
-    // ---- quads (Quad.cpp:298-316) ----
-    _quads.clear();
-    for (const QuadSrc &q : _quadSrc) {
-        tgpu_quad o{};
-        Vec3 base = q.transform*Vec3(0.0f);
-        Vec3 edge0 = q.transform.transformVector(Vec3(1.0f, 0.0f, 0.0f));
-        Vec3 edge1 = q.transform.transformVector(Vec3(0.0f, 0.0f, 1.0f));
-        base -= edge0*0.5f;
-        base -= edge1*0.5f;
-        Vec3 n = edge1.cross(edge0);
-        float area = n.length();
-        n /= area;
-        Vec3 tg = edge0.normalized(), bt = edge1.normalized();
-        for (int i = 0; i < 3; ++i) {
-            o.base[i] = base[i]; o.edge0[i] = edge0[i]; o.edge1[i] = edge1[i];
-            o.normal[i] = n[i]; o.tangent[i] = tg[i]; o.bitangent[i] = bt[i];
-        }
-        o.area = area;
-        o.inv_uv_sq[0] = 1.0f/edge0.lengthSq();
-        o.inv_uv_sq[1] = 1.0f/edge1.lengthSq();
-        o.bsdf = q.bsdf;
-        o.emission_tex = q.emissionTex;
-        _quads.push_back(o);
-    }
-    _desc.n_quads = uint32_t(_quads.size());
     _desc.quads = _quads.data();
-
-    // ---- cubes (Cube.cpp:353-370) ----
-    _cubes.clear();
-    for (const CubeSrc &c : _cubeSrc) {
-        tgpu_cube o{};
-        Vec3 p = c.transform*Vec3(0.0f);
-        Vec3 sc = c.transform.extractScale()*Vec3(0.5f);
-        Mat4 rot = c.transform.extractRotation();
-        Mat4 inv = rot.transpose();
-        storeMat3(rot, o.rot);
-        storeMat3(inv, o.inv_rot);
-        for (int i = 0; i < 3; ++i) { o.pos[i] = p[i]; o.scale[i] = sc[i]; }
-        o.bsdf = c.bsdf;
-        o.emission_tex = c.emissionTex;
-        _cubes.push_back(o);
-    }
-    _desc.n_cubes = uint32_t(_cubes.size());
     _desc.cubes = _cubes.data();
 
     // ---- lights in primitive order (TraceableScene.hpp:86-102) ----

@@ -79,6 +79,9 @@ private:
 
     struct QuadSrc { Mat4 transform; int bsdf; int emissionTex; };
     struct CubeSrc { Mat4 transform; int bsdf; int emissionTex; };
+    // "instances" primitive (primitives/Instance.cpp:60-93): masters are private primitives of the set
+    struct MasterSrc { int kind; MeshData mesh; QuadSrc quad; CubeSrc cube; };
+    struct InstanceSrc { Mat4 transform; std::vector<MasterSrc> masters; std::vector<float> pos, rot; std::vector<uint8_t> id; };
     struct EnvSrc { bool present = false; Mat4 transform; int emissionTex = -1; bool sample = true; };
     enum PrimKind { PrimMesh, PrimQuad, PrimCube, PrimEnv };
     struct PrimRef { PrimKind kind; int index; };
@@ -91,6 +94,15 @@ private:
     std::vector<std::string> _bitmapPaths;
     std::vector<QuadSrc> _quadSrc;
     std::vector<CubeSrc> _cubeSrc;
+    std::vector<InstanceSrc> _instanceSrc;
+    // flattened instance sets (pointers into these go into _desc)
+    struct InstanceFlat { std::vector<tgpu_master> masters; std::vector<float> pos, rot; std::vector<uint8_t> id; };
+    std::vector<InstanceFlat> _instanceFlat;
+    std::vector<tgpu_instances> _instanceSets;
+    void bakeMesh(const MeshData &m, float *boundsMin, float *boundsMax);
+    tgpu_quad bakeQuad(const QuadSrc &q) const;
+    tgpu_cube bakeCube(const CubeSrc &c) const;
+    MeshData parseMesh(const Json &v, const Mat4 &transform, int emissionTex);
     EnvSrc _envSrc;
     std::vector<PrimRef> _primOrder;
     Json _bsdfArray;

@@ -2045,6 +2045,7 @@ int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *
             uint32_t kind = data.kind == PRIM_TRI ? 0u : data.kind == PRIM_QUAD ? 1u : 2u;
             prim = (kind << 30) | data.index;
             if (data.kind != PRIM_CUBE) { u = data.u; v = data.v; }
+            if (data.inst >= 0) prim = (3u << 30) | uint32_t(data.inst); // same convention as tgpu_trace_closest
         }
         float *h = hits + size_t(i)*4;
         h[0] = hit ? ray.farT : r[7];

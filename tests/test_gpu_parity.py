@@ -32,6 +32,10 @@ def assert_bit_exact(got, ref, what):
     ("materialtest/c1_noadapt.json", (128, 72), 16, 8),   # stock scene: SmoothCoat (supplemental-stream lobe picks)
     ("cornell-box/scene_sobol.json", (96, 54), 16, 16),   # quads + cubes + quad light + Null BSDF
     ("materialtest/c2.json", (1, 1), 4, 4),               # minimal image
+    # "instances" primitives (a25), reference semantics: BVH2 order, last hit wins, double-transformed hit point
+    ("instances/inst_cubes.json", (128, 72), 8, 8),       # cube + quad masters, 16 instances, env light
+    ("instances/inst_many.json", (96, 54), 4, 4),         # 294 instances: binned-SAH levels
+    ("instances/inst_mesh.json", (96, 54), 8, 8),         # mesh masters (own BVH4 each) + quad light (finite end cap)
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)
@@ -39,6 +43,27 @@ def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     got = render_gpu(ta, gpu_ctx, hs, shard, spp, step)
     ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, spp, spp_step=step)
     assert_bit_exact(got, ref, f"{scene} {res} {spp}spp")
+
+
+def test_instance_rays_bit_exact(ta, oracle_py, gpu_ctx):
+    """Ray level: closest hits (t, u, v; instance hits report kind 3 << 30 | instance) and any-hit against the oracle."""
+    hs = ta.HostScene(scene_path("instances/inst_mesh.json"), resolution=(64, 36))
+    gpu_ctx.upload(hs, ta.Shard(hs.res_x, hs.res_y))
+    o = oracle_py.Oracle(hs, **oracle_py.GPU)
+    rng = np.random.default_rng(3)
+    n = 20000
+    org = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    org[:, 1] = np.abs(org[:, 1]) + 0.2
+    tgt = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d.astype(np.float32), np.full((n, 1), np.inf, np.float32)], axis=1)
+    got, ref = gpu_ctx.trace_closest(rays), o.trace_closest(rays)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    kinds = got[:, 3].view(np.uint32) >> 30
+    assert (kinds == 3).sum() > 1000 and (got[:, 3].view(np.uint32) == 0xFFFFFFFF).sum() > 100
+    rays[:, 7] = rng.uniform(0.5, 6.0, n).astype(np.float32)
+    assert np.array_equal(gpu_ctx.trace_occluded(rays), o.trace_occluded(rays))
 
 
 def test_settings_variants(ta, oracle_py, gpu_ctx):

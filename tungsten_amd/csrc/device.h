@@ -85,6 +85,21 @@ enum : uint32_t {
 // ---- device scene -----------------------------------------------------------------------------
 struct DBitmap { int32_t w, h, clamp, linear; float scale; const float4 *texels; }; // RGB padded to 16 B: one load per texel
 
+// "instances" primitives (primitives/Instance.cpp; host build in instance_bvh.h).
+// BVH2 node = 4 x float4: x-, y-, z-boxes of both children as (lMin, rMin, lMax, rMax) -- the lanes of
+// BinaryBvh's TinyBvhNode -- then bits(left, right, first, count); right == 0xFFFFFFFF marks a leaf.
+struct DMaster { int32_t kind; uint32_t ref; }; // mesh: root child reference of its BVH4; quad / cube: index into quads / cubes
+struct DInstSet {
+    const float4 *nodes;
+    const uint32_t *order;   // BinaryBvh::_primIndices
+    const float4 *pos;       // xyz = _instancePos, w = bits(master id)
+    const float4 *rot;       // _instanceRot as (w, x, y, z)
+    const DMaster *masters;
+    float boundsMin[3], boundsMax[3];
+    uint32_t rootIsLeaf;
+};
+constexpr int TG_TOP_STACK = 48; // BinaryBvh::trace needs depth + 1 entries; checked at upload
+
 struct DScene {
     tgpu_camera cam;
     tgpu_settings settings;
@@ -113,11 +128,13 @@ struct DScene {
     // std::upper_bound of Distribution2D::warp becomes one table read + a short forward scan
     const uint16_t *envGuideMarginal;    // dist_h entries
     const uint16_t *envGuideConditional; // dist_h x dist_w entries
+    const DInstSet *instSets; uint32_t nInstSets;
 };
 
 // prim id encoding shared with the C ABI: kind << 30 | index; 0xFFFFFFFF = miss
 constexpr uint32_t PRIM_MISS = 0xFFFFFFFFu;
 constexpr uint32_t KIND_TRI = 0u, KIND_QUAD = 1u, KIND_CUBE = 2u, KIND_ENV = 3u;
+constexpr uint32_t INST_NONE = 0xFFFFFFFFu; // hitInst: set << 24 | instance, or none
 TG_DEV uint32_t primKind(uint32_t p) { return p >> 30; }
 TG_DEV uint32_t primIndex(uint32_t p) { return p & 0x3FFFFFFFu; }
 

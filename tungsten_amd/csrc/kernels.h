@@ -60,7 +60,8 @@ TG_DEV int flagsEnd(uint32_t f) { return int((f >> 24) & 0xFu); }
 struct DState {
     float4 *rayO;   // origin.xyz, tnear
     float4 *rayD;   // dir.xyz, tfar
-    float4 *hit;    // t, u, v, bits(prim)
+    float4 *hit;                // t, u, v, bits(prim)
+    uint32_t *hitInst;          // instance of the hit (set << 24 | index) or INST_NONE; only with "instances" in the scene
     float4 *tp;     // throughput.xyz, bits(flags)
     float4 *em;     // emission (radiance so far).xyz, bits(Sobol scramble)
     uint4 *samp;    // sobol dimension, pcg lo, pcg hi, sample index
@@ -366,7 +367,7 @@ TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, const 
 // Closest (ANY = false): lexicographic minimum of (t, soup triangle id) over all valid triangles.
 // Any-hit (ANY = true): returns true at the first valid triangle.
 template <bool ANY, bool COUNT>
-TG_DEV bool traverse(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D, float tnear, float &bestT, float &bestU, float &bestV,
+TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 &O, const V3 &D, float tnear, float &bestT, float &bestU, float &bestV,
                      uint32_t &bestPrim, TraceCounters &tc)
 {
     const float tfar0 = bestT;
@@ -378,7 +379,7 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
     V3 noi(-O.x*inv.x, -O.y*inv.y, -O.z*inv.z);
     const int maxSp = sc.stackEntries;
     int sp = 0;
-    uint32_t node = sc.rootChild;
+    uint32_t node = root;
     // per-axis choice of the near/far byte plane (bvh_build.h, Bvh4): for a negative direction the near
     // plane of the box is HI
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
@@ -448,17 +449,186 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
     return false;
 }
 
+// =================================================================================================
+// "instances" primitives: Instance::intersect (primitives/Instance.cpp:290-311) on top of BinaryBvh::trace
+// (bvh/BinaryBvh.hpp:188-283), reference behaviour included -- the local ray of every candidate instance starts at
+// the leaf's entry distance with farT = infinity and the LAST instance hit in traversal order wins, so the BVH2 is
+// walked in exactly the reference's order (single ray, ordered, (node, tMin) stack; the SSE lanes written per child).
+// The master is intersected through the same code scene primitives use: the quantised BVH4 of its mesh
+// (closest: lexicographic (t, triangle id)), Quad.cpp:71-98, Cube.cpp:94-127.
+// ANY = true: stop at the first instance whose master is hit (shadow rays towards infinite lights: the set of
+// leaves reached before the first hit does not depend on the order).
+// =================================================================================================
+TG_DEV V3 quatRotate(const float4 &q, const V3 &o) // Quaternion::operator*(Vec3), q = (w, x, y, z) in .x .y .z .w
+{
+    float tx = 2.0f*(q.z*o.z - q.w*o.y);
+    float ty = 2.0f*(q.w*o.x - q.y*o.z);
+    float tz = 2.0f*(q.y*o.y - q.z*o.x);
+    return V3(o.x + q.x*tx + q.z*tz - q.w*ty,
+              o.y + q.x*ty + q.w*tx - q.y*tz,
+              o.z + q.x*tz + q.y*ty - q.z*tx);
+}
+TG_DEV float sseMax(float a, float b) { return a > b ? a : b; } // _mm_max_ps operand order
+
+// Cube::intersect as a master sees it: 0 = false, 1 = true without a recorded hit (the slab test passed but neither
+// face is inside (nearT, farT): Cube.cpp:113-124 still returns true), 2 = hit
+TG_DEV int cubeMasterIntersect(const tgpu_cube &cb, const V3 &pos, const V3 &dir, float nearT, float farT, float &tHit)
+{
+    V3 p = mulPoint0(cb.inv_rot, pos - V3(cb.pos));
+    V3 d = mulPoint0(cb.inv_rot, dir);
+    float ttMin = nearT, ttMax = farT;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float di = d.comp(i), pi = p.comp(i), sc = cb.scale[i];
+        float invD = 1.0f/di;
+        float relMin = -sc - pi, relMax = sc - pi;
+        if (invD >= 0.0f) {
+            ttMin = fmax2(ttMin, relMin*invD);
+            ttMax = fmin2(ttMax, relMax*invD);
+        } else {
+            ttMax = fmin2(ttMax, relMin*invD);
+            ttMin = fmax2(ttMin, relMax*invD);
+        }
+    }
+    if (!(ttMin <= ttMax)) return 0;
+    if (ttMin > nearT && ttMin < farT) { tHit = ttMin; return 2; }
+    if (ttMax > nearT && ttMax < farT) { tHit = ttMax; return 2; }
+    return 1;
+}
+
+template <bool ANY, bool COUNT>
+TG_DEV bool instanceIntersect(const DScene &sc, const DInstSet &is, uint32_t setIndex, uint32_t *stack, const V3 &O, const V3 &D,
+                              float tnear, float &rayFarT, uint32_t &prim, float &u, float &v, uint32_t &inst, TraceCounters &tc)
+{
+    // bboxIntersection(_bounds, ...) :148-171
+    float tMin = tnear, tMax = rayFarT;
+    {
+        float ttMin = tMin, ttMax = tMax;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float invD = 1.0f/D.comp(i);
+            float relMin = is.boundsMin[i] - O.comp(i), relMax = is.boundsMax[i] - O.comp(i);
+            if (invD >= 0.0f) {
+                ttMin = fmax2(ttMin, relMin*invD);
+                ttMax = fmin2(ttMax, relMax*invD);
+            } else {
+                ttMax = fmin2(ttMax, relMin*invD);
+                ttMin = fmax2(ttMin, relMax*invD);
+            }
+        }
+        if (!(ttMin <= ttMax)) return false;
+        tMin = ttMin; tMax = ttMax;
+    }
+    const V3 invDir(1.0f/D.x, 1.0f/D.y, 1.0f/D.z);
+    const bool px = D.x >= 0.0f, py = D.y >= 0.0f, pz = D.z >= 0.0f;
+    const float nearLane = tnear;
+    float negFarLane = -rayFarT;
+    uint32_t tsNode[TG_TOP_STACK];
+    float tsT[TG_TOP_STACK];
+    int sp = 0;
+    uint32_t node = 0;
+    bool hit = false;
+    while (true) {
+        float4 q3 = is.nodes[size_t(node)*4 + 3];
+        bool reachedLeaf = true;
+        while (__float_as_uint(q3.y) != 0xFFFFFFFFu) {
+            const float4 *n = is.nodes + size_t(node)*4;
+            float4 bx = n[0], by = n[1], bz = n[2];
+            if (COUNT) tc.nodes++;
+            // child 0 = lanes (x: min, z: max), child 1 = lanes (y: min, w: max)
+            float nx0 = px ? bx.x : bx.z, fx0 = px ? bx.z : bx.x, nx1 = px ? bx.y : bx.w, fx1 = px ? bx.w : bx.y;
+            float ny0 = py ? by.x : by.z, fy0 = py ? by.z : by.x, ny1 = py ? by.y : by.w, fy1 = py ? by.w : by.y;
+            float nz0 = pz ? bz.x : bz.z, fz0 = pz ? bz.z : bz.x, nz1 = pz ? bz.y : bz.w, fz1 = pz ? bz.w : bz.y;
+            float mn0 = sseMax(sseMax(sseMax((nx0 - O.x)*invDir.x, (ny0 - O.y)*invDir.y), (nz0 - O.z)*invDir.z), nearLane);
+            float mn1 = sseMax(sseMax(sseMax((nx1 - O.x)*invDir.x, (ny1 - O.y)*invDir.y), (nz1 - O.z)*invDir.z), nearLane);
+            float mx0 = -sseMax(sseMax(sseMax((fx0 - O.x)*(-invDir.x), (fy0 - O.y)*(-invDir.y)), (fz0 - O.z)*(-invDir.z)), negFarLane);
+            float mx1 = -sseMax(sseMax(sseMax((fx1 - O.x)*(-invDir.x), (fy1 - O.y)*(-invDir.y)), (fz1 - O.z)*(-invDir.z)), negFarLane);
+            const bool hitL = mn0 <= mx0, hitR = mn1 <= mx1;
+            const uint32_t l = __float_as_uint(q3.x), r = __float_as_uint(q3.y);
+            if (hitL && hitR) {
+                if (mn0 < mn1) { tsNode[sp] = r; tsT[sp] = mn1; ++sp; node = l; tMin = mn0; }
+                else { tsNode[sp] = l; tsT[sp] = mn0; ++sp; node = r; tMin = mn1; }
+            } else if (hitL) { node = l; tMin = mn0; }
+            else if (hitR) { node = r; tMin = mn1; }
+            else { reachedLeaf = false; break; }
+            q3 = is.nodes[size_t(node)*4 + 3];
+        }
+        if (reachedLeaf) {
+            const uint32_t first = __float_as_uint(q3.z), count = __float_as_uint(q3.w);
+            for (uint32_t i = first; i < first + count; ++i) {
+                const uint32_t id = is.order[i];
+                const float4 pq = is.pos[id], rq = is.rot[id];
+                const float4 inv = make_float4(rq.x, -rq.y, -rq.z, -rq.w); // conjugate
+                const V3 lo = quatRotate(inv, O - V3(pq.x, pq.y, pq.z)), ld = quatRotate(inv, D);
+                const DMaster m = is.masters[__float_as_uint(pq.w)];
+                bool hitI = false;
+                float localFarT = TG_INF; // Ray::scatter default (math/Ray.hpp:29)
+                if (m.kind == TGPU_MASTER_MESH) {
+                    float t = TG_INF, tu = 0.0f, tv = 0.0f;
+                    uint32_t tri = PRIM_MISS;
+                    bool any = traverse<ANY, COUNT>(sc, stack, m.ref, lo, ld, tMin, t, tu, tv, tri, tc);
+                    if (ANY) {
+                        hitI = any;
+                    } else if (tri != PRIM_MISS) {
+                        hitI = true; localFarT = t; prim = tri; u = tu; v = tv;
+                    }
+                } else if (m.kind == TGPU_MASTER_QUAD) {
+                    QuadHit h;
+                    if (quadIntersect(sc.quads[m.ref], lo, ld, tMin, TG_INF, h)) {
+                        hitI = true; localFarT = h.t; prim = (KIND_QUAD << 30) | m.ref; u = h.u; v = h.v;
+                    }
+                } else {
+                    float t = 0.0f;
+                    int r = cubeMasterIntersect(sc.cubes[m.ref], lo, ld, tMin, TG_INF, t);
+                    if (r == 2) { localFarT = t; prim = (KIND_CUBE << 30) | m.ref; u = 0.0f; v = 0.0f; }
+                    hitI = r != 0;
+                }
+                if (hitI) {
+                    if (ANY) return true;
+                    hit = true;
+                    inst = (setIndex << 24) | id;
+                    rayFarT = localFarT;
+                }
+            }
+            tMax = fmin2(tMax, rayFarT);
+            negFarLane = -tMax;
+        }
+        // pop
+        bool done = false;
+        while (true) {
+            if (sp == 0) { done = true; break; }
+            --sp;
+            node = tsNode[sp];
+            tMin = tsT[sp];
+            if (tMax < tMin) continue;
+            break;
+        }
+        if (done) break;
+    }
+    return hit;
+}
+
 // TraceableScene::intersect restated: analytic primitives first (each shrinking tfar, Quad.cpp:71-98,
 // Cube.cpp:94-127), then the triangle BVH.  Returns encoded prim or PRIM_MISS.
-template <bool COUNT>
-TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D, float tnear, float &tfar, float &u, float &v, TraceCounters &tc)
+template <bool COUNT, bool INST>
+TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D, float tnear, float &tfar, float &u, float &v, uint32_t &inst,
+                           TraceCounters &tc)
 {
     uint32_t prim = PRIM_MISS;
+    inst = INST_NONE;
+    // "instances" primitives come first: their result ignores what was found before them (see instanceIntersect),
+    // the primitives after them compare against whatever farT they leave behind
+    if (INST) {
+        for (uint32_t s = 0; s < sc.nInstSets; ++s)
+            instanceIntersect<false, COUNT>(sc, sc.instSets[s], s, stack, O, D, tnear, tfar, prim, u, v, inst, tc);
+        if (prim == PRIM_MISS) inst = INST_NONE;
+    }
     for (uint32_t i = 0; i < sc.nQuads; ++i) {
         QuadHit h;
         if (quadIntersect(sc.quads[i], O, D, tnear, tfar, h)) {
             tfar = h.t; u = h.u; v = h.v;
             prim = (KIND_QUAD << 30) | i;
+            inst = INST_NONE;
         }
     }
     for (uint32_t i = 0; i < sc.nCubes; ++i) {
@@ -467,15 +637,17 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
         if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, t, back)) {
             tfar = t; u = 0.0f; v = 0.0f;
             prim = (KIND_CUBE << 30) | i;
+            inst = INST_NONE;
         }
     }
     if (sc.nTris) {
         uint32_t tri = PRIM_MISS;
         float t = tfar, tu = 0.0f, tv = 0.0f;
-        traverse<false, COUNT>(sc, stack, O, D, tnear, t, tu, tv, tri, tc);
+        traverse<false, COUNT>(sc, stack, sc.rootChild, O, D, tnear, t, tu, tv, tri, tc);
         if (tri != PRIM_MISS) {
             tfar = t; u = tu; v = tv;
             prim = tri; // KIND_TRI == 0
+            inst = INST_NONE;
         }
     }
     return prim;
@@ -483,9 +655,25 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
 
 // generalizedShadowRay for scenes without forward-lobe BSDFs: blocked iff any primitive other than
 // the end cap is hit inside (tnear, tfar) (TraceBase.cpp:62-125)
-template <bool COUNT>
+template <bool COUNT, bool INST>
 TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D, float tnear, float tfar, uint32_t endCap, TraceCounters &tc)
 {
+    if (INST) {
+        if (primKind(endCap) == KIND_QUAD && endCap != PRIM_MISS) {
+            // finite end cap: an instance may leave farT BEYOND the light (its local rays run to infinity), in which case
+            // the light quad itself becomes the final hit and the ray counts as unblocked -- only the full
+            // closest-hit query of generalizedShadowRay (TraceBase.cpp:79) reproduces that
+            float t = tfar, u, v;
+            uint32_t inst;
+            uint32_t prim = closestHit<COUNT, true>(sc, stack, O, D, tnear, t, u, v, inst, tc);
+            return prim != PRIM_MISS && !(inst == INST_NONE && prim == endCap);
+        }
+        for (uint32_t s = 0; s < sc.nInstSets; ++s) {
+            float t = tfar, u, v;
+            uint32_t prim, inst;
+            if (instanceIntersect<true, COUNT>(sc, sc.instSets[s], s, stack, O, D, tnear, t, prim, u, v, inst, tc)) return true;
+        }
+    }
     for (uint32_t i = 0; i < sc.nQuads; ++i) {
         if (((KIND_QUAD << 30) | i) == endCap) continue;
         QuadHit h;
@@ -499,7 +687,7 @@ TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
     if (sc.nTris) {
         float t = tfar, u, v;
         uint32_t p = PRIM_MISS;
-        if (traverse<true, COUNT>(sc, stack, O, D, tnear, t, u, v, p, tc)) return true;
+        if (traverse<true, COUNT>(sc, stack, sc.rootChild, O, D, tnear, t, u, v, p, tc)) return true;
     }
     return false;
 }
@@ -534,7 +722,7 @@ TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
 // dropped onto the free list.  RAW = true: ray-level entry point (tgpu_trace_closest): identity queue,
 // no classification.
 // =================================================================================================
-template <bool COUNT, bool RAW>
+template <bool COUNT, bool RAW, bool INST>
 __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, uint32_t rawCount)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -572,7 +760,12 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, u
                     float4 ro = ldStream(&st.rayO[path]), rd = ldStream(&st.rayD[path]);
                     V3 O = xyz(ro), D = xyz(rd);
                     float tfar = rd.w, u = 0.0f, v = 0.0f;
-                    uint32_t prim = closestHit<COUNT>(sc, stack, O, D, ro.w, tfar, u, v, tc);
+                    uint32_t inst;
+                    uint32_t prim = closestHit<COUNT, INST>(sc, stack, O, D, ro.w, tfar, u, v, inst, tc);
+                    if (INST) {
+                        if (RAW) { if (inst != INST_NONE) prim = (3u << 30) | (inst & 0xFFFFFFu); } // ray-level ABI: kind 3 = instance index
+                        else stStream(&st.hitInst[path], inst);
+                    }
                     stStream(&st.hit[path], make_float4(tfar, u, v, __uint_as_float(prim)));
                     if (!RAW) cls = hitClass(sc, prim);
                 }
@@ -708,6 +901,28 @@ TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 
     }
 }
 
+// Instance::intersectionInfo (primitives/Instance.cpp:335-344) on top of the master's, as the reference does it: the
+// master was handed the WORLD hit point (TraceableScene.hpp:184-187), and info.p is then moved by the instance
+// transform once more.  Only a Quad master replaces info.p by its own (instance-local) hit point first
+// (Quad.cpp:123-131), so only quads end up where the ray actually hit.
+TG_DEV void applyInstance(const DScene &sc, uint32_t inst, uint32_t prim, const V3 &O, const V3 &D, float t, HitInfo &info)
+{
+    const DInstSet &is = sc.instSets[inst >> 24];
+    const uint32_t id = inst & 0xFFFFFFu;
+    const float4 pq = is.pos[id], rq = is.rot[id];
+    const V3 pos(pq.x, pq.y, pq.z);
+    if (primKind(prim) == KIND_QUAD) {
+        const float4 inv = make_float4(rq.x, -rq.y, -rq.z, -rq.w);
+        const V3 lo = quatRotate(inv, O - pos), ld = quatRotate(inv, D);
+        info.p = lo + t*ld;
+    }
+    info.Ng = quatRotate(rq, info.Ng);
+    info.Ns = quatRotate(rq, info.Ns);
+    info.p = pos + quatRotate(rq, info.p);
+    info.emissive = false; // the hit primitive is the Instance, whose masters' emission is never consulted
+    info.emissionTex = -1;
+}
+
 // light.directPdf for the BSDF-sampled NEE ray (InfiniteSphere.cpp:218-229, Quad.cpp:216-223)
 TG_DEV float envDirectPdf(const DScene &sc, const V3 &w, float &ux, float &uy)
 {
@@ -820,6 +1035,10 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
         uint32_t prim = __float_as_uint(hw.w);
         HitInfo info;
         fetchHitInfo(sc, prim, O, D, hw.x, hw.y, hw.z, info);
+        if (sc.nInstSets) {
+            const uint32_t inst = st.hitInst[path];
+            if (inst != INST_NONE) applyInstance(sc, inst, prim, O, D, hw.x, info);
+        }
         const tgpu_bsdf &bsdf = sc.bsdfs[info.bsdf];
         const uint32_t lobes = bsdfLobes(sc, bsdf);
 
@@ -1037,7 +1256,7 @@ __global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
 //   emission += ((0 + L*visL) + B*visB) * weight * throughput   (TraceBase.cpp:383-400,483-494,537-538)
 // =================================================================================================
 // Both NEE rays of the path's current vertex, then the resolve (body of the shadow kernel and of the tail kernel)
-template <bool COUNT>
+template <bool COUNT, bool INST>
 TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint32_t path, TraceCounters &tc, uint32_t &rays)
 {
     float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
@@ -1046,11 +1265,11 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
     V3 result(0.0f);
     if (a.w >= 0.0f) {
         rays++;
-        if (!occluded<COUNT>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
+        if (!occluded<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
     }
     if (b.w >= 0.0f) {
         rays++;
-        if (!occluded<COUNT>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
+        if (!occluded<COUNT, INST>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
     }
     float4 emw = ldStream(&st.em[path]);
     V3 em = xyz(emw);
@@ -1059,7 +1278,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
     stStream(&st.em[path], make_float4(em.x, em.y, em.z, emw.w));
 }
 
-template <bool COUNT>
+template <bool COUNT, bool INST>
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -1077,7 +1296,7 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
         uint32_t idx = base + lane;
         uint32_t path = 0;
         // no `continue` here: the dequeue above must be executed by the whole wave together
-        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) shadowPath<COUNT>(sc, st, stack, path, tc, rays);
+        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) shadowPath<COUNT, INST>(sc, st, stack, path, tc, rays);
     }
     if (COUNT) flushCounters(st.stats, 2, tc);
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
@@ -1085,6 +1304,7 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
 }
 
 // raw any-hit for tgpu_trace_occluded
+template <bool INST>
 __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint32_t count, uint8_t *out)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -1092,7 +1312,7 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
     TraceCounters tc{0, 0};
     for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < count; i += gridDim.x*blockDim.x) {
         float4 ro = st.rayO[i], rd = st.rayD[i];
-        out[i] = occluded<false>(sc, stack, xyz(ro), xyz(rd), ro.w, rd.w, PRIM_MISS, tc) ? 1 : 0;
+        out[i] = occluded<false, INST>(sc, stack, xyz(ro), xyz(rd), ro.w, rd.w, PRIM_MISS, tc) ? 1 : 0;
     }
 }
 
@@ -1103,7 +1323,7 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
 // ..., using exactly the per-path functions of the wavefront kernels (so the bits do not change), then
 // retires it.  Every slot of the lists ends on the free list.
 // =================================================================================================
-template <bool COUNT>
+template <bool COUNT, bool INST>
 __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -1122,7 +1342,9 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
             while (flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE) {
                 float4 ro = st.rayO[slot], rd = st.rayD[slot];
                 float tfar = rd.w, u = 0.0f, v = 0.0f;
-                uint32_t prim = closestHit<COUNT>(sc, stack, xyz(ro), xyz(rd), ro.w, tfar, u, v, tcE);
+                uint32_t inst;
+                uint32_t prim = closestHit<COUNT, INST>(sc, stack, xyz(ro), xyz(rd), ro.w, tfar, u, v, inst, tcE);
+                if (INST) st.hitInst[slot] = inst;
                 st.hit[slot] = make_float4(tfar, u, v, __uint_as_float(prim));
                 extRays++;
                 if (prim == PRIM_MISS) {
@@ -1130,7 +1352,7 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
                 } else {
                     shadePath(sc, st, slot);
                     events++;
-                    if (st.shFlag[slot]) shadowPath<COUNT>(sc, st, stack, slot, tcS, shRays);
+                    if (st.shFlag[slot]) shadowPath<COUNT, INST>(sc, st, stack, slot, tcS, shRays);
                 }
             }
             float4 tpw = st.tp[slot];

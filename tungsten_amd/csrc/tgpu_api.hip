@@ -3,6 +3,7 @@
 // kernels of kernels.h.  No CPU fallback exists: every entry point fails loudly without a GPU.
 #include "kernels.h"
 #include "bvh_build.h"
+#include "instance_bvh.h"
 
 #include <algorithm>
 #include <atomic>
@@ -156,7 +157,8 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
     if (!s || s->abi_version != TGPU_ABI_VERSION) { fail(ctx, "scene description has ABI version %u, expected %u", s ? s->abi_version : 0u, TGPU_ABI_VERSION); return TGPU_ERR_INVALID; }
     if (s->camera.res_x == 0 || s->camera.res_y == 0) { fail(ctx, "camera resolution is zero"); return TGPU_ERR_INVALID; }
     if (s->n_tris && (!s->tri_pos || !s->tri_normal || !s->tri_uv || !s->tri_bsdf || !s->tri_smooth)) { fail(ctx, "triangle arrays missing"); return TGPU_ERR_INVALID; }
-    if (s->n_tris >= (1u << 29)) { fail(ctx, "too many triangles (%u)", s->n_tris); return TGPU_ERR_UNSUPPORTED; }
+    if ((s->n_tris || s->n_master_tris) && (!s->tri_pos || !s->tri_normal || !s->tri_uv || !s->tri_bsdf || !s->tri_smooth)) { fail(ctx, "triangle arrays missing"); return TGPU_ERR_INVALID; }
+    if (uint64_t(s->n_tris) + s->n_master_tris >= (1u << 29)) { fail(ctx, "too many triangles (%u + %u)", s->n_tris, s->n_master_tris); return TGPU_ERR_UNSUPPORTED; }
     if (!s->sobol_matrices) { fail(ctx, "Sobol matrices missing"); return TGPU_ERR_INVALID; }
     if (s->n_lights > TG_MAX_LIGHTS) { fail(ctx, "more than %d samplable lights are not supported", TG_MAX_LIGHTS); return TGPU_ERR_UNSUPPORTED; }
     if (s->settings.max_bounces < 0 || s->settings.max_bounces > 0xFFFF) { fail(ctx, "max_bounces out of range"); return TGPU_ERR_INVALID; }
@@ -181,13 +183,13 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         }
     }
     auto bsdfOk = [&](int b) { return b >= 0 && uint32_t(b) < s->n_bsdfs; };
-    for (uint32_t i = 0; i < s->n_tris; ++i)
+    for (uint32_t i = 0; i < s->n_tris + s->n_master_tris; ++i)
         if (!bsdfOk(s->tri_bsdf[i])) { fail(ctx, "triangle %u references bsdf %d", i, s->tri_bsdf[i]); return TGPU_ERR_INVALID; }
-    for (uint32_t i = 0; i < s->n_quads; ++i) {
+    for (uint32_t i = 0; i < s->n_quads + s->n_master_quads; ++i) {
         if (!bsdfOk(s->quads[i].bsdf)) { fail(ctx, "quad %u references bsdf %d", i, s->quads[i].bsdf); return TGPU_ERR_INVALID; }
         if (s->quads[i].emission_tex >= 0 && !texOk(s->quads[i].emission_tex)) { fail(ctx, "quad %u: bad emission texture", i); return TGPU_ERR_INVALID; }
     }
-    for (uint32_t i = 0; i < s->n_cubes; ++i) {
+    for (uint32_t i = 0; i < s->n_cubes + s->n_master_cubes; ++i) {
         if (!bsdfOk(s->cubes[i].bsdf)) { fail(ctx, "cube %u references bsdf %d", i, s->cubes[i].bsdf); return TGPU_ERR_INVALID; }
         if (s->cubes[i].emission_tex >= 0) { fail(ctx, "emissive cubes are outside the hot-path scope"); return TGPU_ERR_UNSUPPORTED; }
     }
@@ -198,6 +200,27 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         } else if (l.kind == TGPU_LIGHT_QUAD) {
             if (l.index < 0 || uint32_t(l.index) >= s->n_quads || s->quads[l.index].emission_tex < 0) { fail(ctx, "light %u: bad quad", i); return TGPU_ERR_INVALID; }
         } else { fail(ctx, "light %u has unknown kind", i); return TGPU_ERR_INVALID; }
+    }
+    // "instances" primitives
+    if (s->n_instance_sets > 255) { fail(ctx, "more than 255 'instances' primitives"); return TGPU_ERR_UNSUPPORTED; }
+    if (s->n_instance_sets && !s->instance_sets) { fail(ctx, "instance_sets missing"); return TGPU_ERR_INVALID; }
+    for (uint32_t si = 0; si < s->n_instance_sets; ++si) {
+        const tgpu_instances &is = s->instance_sets[si];
+        if (is.n_masters == 0 || is.n_masters > 256 || !is.masters) { fail(ctx, "instance set %u: needs 1..256 masters", si); return TGPU_ERR_INVALID; }
+        if (is.n_instances && (!is.pos || !is.rot || !is.master_id)) { fail(ctx, "instance set %u: arrays missing", si); return TGPU_ERR_INVALID; }
+        // > 2^20 instances would take the reference's multi-threaded binning path (BvhBuilder.cpp:40-61), whose bin
+        // partition differs from the serial one restated in instance_bvh.h
+        if (is.n_instances > (1u << 20)) { fail(ctx, "instance set %u: more than 2^20 instances", si); return TGPU_ERR_UNSUPPORTED; }
+        for (uint32_t m = 0; m < is.n_masters; ++m) {
+            const tgpu_master &mm = is.masters[m];
+            bool ok = false;
+            if (mm.kind == TGPU_MASTER_MESH) ok = mm.count > 0 && mm.first >= s->n_tris && uint64_t(mm.first) + mm.count <= uint64_t(s->n_tris) + s->n_master_tris;
+            else if (mm.kind == TGPU_MASTER_QUAD) ok = mm.first >= s->n_quads && mm.first < s->n_quads + s->n_master_quads && s->quads[mm.first].emission_tex < 0;
+            else if (mm.kind == TGPU_MASTER_CUBE) ok = mm.first >= s->n_cubes && mm.first < s->n_cubes + s->n_master_cubes;
+            if (!ok) { fail(ctx, "instance set %u: master %u does not reference tail geometry of its kind", si, m); return TGPU_ERR_INVALID; }
+        }
+        for (uint32_t i = 0; i < is.n_instances; ++i)
+            if (is.master_id[i] >= is.n_masters) { fail(ctx, "instance set %u: instance %u references master %u", si, i, unsigned(is.master_id[i])); return TGPU_ERR_INVALID; }
     }
     if (s->env.present) {
         if (!texOk(s->env.emission_tex)) { fail(ctx, "environment: bad emission texture"); return TGPU_ERR_INVALID; }
@@ -303,32 +326,109 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.cam = s->camera;
     sc.settings = s->settings;
 
-    // ---- BVH ----
-    tgpu_bvh::Builder builder(s->tri_pos, s->n_tris);
-    tgpu_bvh::Bvh bvh = builder.build();
-    // collapse to the quantised BVH4 the kernels traverse (bvh_build.h)
-    tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run();
+    // ---- BVHs: the scene's triangles, then one per mesh master of the "instances" primitives ----
+    const uint32_t nAllTris = s->n_tris + s->n_master_tris;
+    std::vector<tgpu_bvh::Float4> allNodes, allTris;
+    std::vector<uint32_t> allTriId;
+    int maxDepth4 = 0;
+    // appends one BVH over triangles [first, first + count) and returns its root child reference
+    auto appendBvh = [&](uint32_t first, uint32_t count, const char *what) -> uint32_t {
+        tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count);
+        tgpu_bvh::Bvh bvh = builder.build();
+        tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run(); // the quantised BVH4 the kernels traverse (bvh_build.h)
+        const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/3);
+        auto rebase = [&](uint32_t ref) -> uint32_t {
+            if (ref == 0xFFFFFFFFu) return ref;                               // empty slot
+            if (ref & 0x80000000u) {                                          // leaf: first << 2 | count - 1
+                uint32_t payload = ref & 0x7FFFFFFFu;
+                return 0x80000000u | ((((payload >> 2) + triBase) << 2) | (payload & 3u));
+            }
+            return ref + nodeBase;
+        };
+        for (size_t i = 0; i < bvh4.nodes.size(); i += 4) {
+            tgpu_bvh::Float4 q3 = bvh4.nodes[i + 3];
+            float *c[4] = {&q3.x, &q3.y, &q3.z, &q3.w};
+            for (float *f : c) {
+                uint32_t bits;
+                std::memcpy(&bits, f, 4);
+                bits = rebase(bits);
+                std::memcpy(f, &bits, 4);
+            }
+            allNodes.push_back(bvh4.nodes[i]); allNodes.push_back(bvh4.nodes[i + 1]); allNodes.push_back(bvh4.nodes[i + 2]); allNodes.push_back(q3);
+        }
+        allTris.insert(allTris.end(), bvh.tris.begin(), bvh.tris.end());
+        for (uint32_t id : bvh.triId) allTriId.push_back(id + first);
+        maxDepth4 = std::max(maxDepth4, bvh4.maxDepth);
+        if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] %s: %u tris, bvh2 %u nodes depth %d -> bvh4 %u nodes depth %d\n", what, count, bvh.nodeCount, bvh.maxDepth, bvh4.nodeCount, bvh4.maxDepth);
+        return rebase(bvh4.rootChild);
+    };
     sc.nTris = s->n_tris;
-    sc.rootChild = bvh4.rootChild;
-    sc.stackEntries = 3*bvh4.maxDepth + 2; // at most 3 pushes per level
+    sc.rootChild = appendBvh(0, s->n_tris, "scene");
+    // ---- "instances" (Instance::prepareForRender: the BVH2 over instance boxes is built in instance_bvh.h) ----
+    auto bitsToFloat = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    std::vector<DInstSet> instSets(s->n_instance_sets);
+    for (uint32_t si = 0; si < s->n_instance_sets; ++si) {
+        const tgpu_instances &is = s->instance_sets[si];
+        std::vector<DMaster> masters(is.n_masters);
+        for (uint32_t m = 0; m < is.n_masters; ++m) {
+            const tgpu_master &mm = is.masters[m];
+            masters[m].kind = mm.kind;
+            masters[m].ref = mm.kind == TGPU_MASTER_MESH ? appendBvh(mm.first, mm.count, "instance master") : mm.first;
+        }
+        tgpu_inst::TreeBuilder tb;
+        tgpu_inst::Tree tree = tb.build(tgpu_inst::TreeBuilder::instanceItems(is));
+        if (tree.depth + 1 > TG_TOP_STACK) { fail(ctx, "instance BVH of depth %d exceeds the traversal stack (%d)", tree.depth, TG_TOP_STACK); return TGPU_ERR_UNSUPPORTED; }
+        std::vector<float4> nodes(tree.nodes.size()*4), pos(is.n_instances), rot(is.n_instances);
+        for (size_t i = 0; i < tree.nodes.size(); ++i) {
+            const tgpu_inst::Node &n = tree.nodes[i];
+            const bool leaf = n.right < 0;
+            nodes[i*4 + 0] = make_float4(n.bx[0], n.bx[1], n.bx[2], n.bx[3]);
+            nodes[i*4 + 1] = make_float4(n.by[0], n.by[1], n.by[2], n.by[3]);
+            nodes[i*4 + 2] = make_float4(n.bz[0], n.bz[1], n.bz[2], n.bz[3]);
+            nodes[i*4 + 3] = make_float4(bitsToFloat(uint32_t(n.left)), bitsToFloat(leaf ? 0xFFFFFFFFu : uint32_t(n.right)),
+                                         bitsToFloat(n.first), bitsToFloat(n.count));
+        }
+        for (uint32_t i = 0; i < is.n_instances; ++i) {
+            pos[i] = make_float4(is.pos[size_t(i)*3], is.pos[size_t(i)*3 + 1], is.pos[size_t(i)*3 + 2], bitsToFloat(uint32_t(is.master_id[i])));
+            rot[i] = make_float4(is.rot[size_t(i)*4], is.rot[size_t(i)*4 + 1], is.rot[size_t(i)*4 + 2], is.rot[size_t(i)*4 + 3]);
+        }
+        float4 *dN, *dP, *dR;
+        uint32_t *dO;
+        DMaster *dM;
+        if ((rc = upload(ctx, ctx->allocs, nodes.data(), nodes.size(), &dN))) return rc;
+        if ((rc = upload(ctx, ctx->allocs, tree.order.data(), tree.order.size(), &dO))) return rc;
+        if ((rc = upload(ctx, ctx->allocs, pos.data(), pos.size(), &dP))) return rc;
+        if ((rc = upload(ctx, ctx->allocs, rot.data(), rot.size(), &dR))) return rc;
+        if ((rc = upload(ctx, ctx->allocs, masters.data(), masters.size(), &dM))) return rc;
+        DInstSet &d = instSets[si];
+        d.nodes = dN; d.order = dO; d.pos = dP; d.rot = dR; d.masters = dM;
+        for (int k = 0; k < 3; ++k) { d.boundsMin[k] = tree.bounds.lo[k]; d.boundsMax[k] = tree.bounds.hi[k]; }
+        d.rootIsLeaf = tree.nodes[0].right < 0;
+        if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] instance set %u: %u instances, %zu bvh2 nodes, depth %d\n", si, is.n_instances, tree.nodes.size(), tree.depth);
+    }
+    DInstSet *dSets;
+    if ((rc = upload(ctx, ctx->allocs, instSets.data(), instSets.size(), &dSets))) return rc;
+    sc.instSets = dSets;
+    sc.nInstSets = s->n_instance_sets;
+
+    sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
     if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
-    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] bvh2: %u nodes depth %d -> bvh4: %u nodes depth %d, stack entries %d\n", bvh.nodeCount, bvh.maxDepth, bvh4.nodeCount, bvh4.maxDepth, sc.stackEntries);
     float4 *dNodes, *dTris;
     uint32_t *dTriId;
-    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh4.nodes.data()), bvh4.nodes.size(), &dNodes))) return rc;
-    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(bvh.tris.data()), bvh.tris.size(), &dTris))) return rc;
-    if ((rc = upload(ctx, ctx->allocs, bvh.triId.data(), bvh.triId.size(), &dTriId))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allNodes.data()), allNodes.size(), &dNodes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allTris.data()), allTris.size(), &dTris))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, allTriId.data(), allTriId.size(), &dTriId))) return rc;
     sc.nodes = dNodes;
     sc.tris = dTris;
     sc.triId = dTriId;
     ctx->ldsBytes = size_t(sc.stackEntries)*256*sizeof(uint32_t);
-    if (ctx->ldsBytes > 160*1024) { fail(ctx, "BVH depth %d needs more LDS than a CU has", bvh4.maxDepth); return TGPU_ERR_UNSUPPORTED; }
+    if (ctx->ldsBytes > 160*1024) { fail(ctx, "BVH depth %d needs more LDS than a CU has", maxDepth4); return TGPU_ERR_UNSUPPORTED; }
 
     // ---- shading records ----
-    std::vector<tgpu_bvh::Float4> shade(size_t(s->n_tris)*5);
-    std::vector<uint8_t> triClass(s->n_tris);
-    for (uint32_t i = 0; i < s->n_tris; ++i) {
+    std::vector<tgpu_bvh::Float4> shade(size_t(nAllTris)*5);
+    std::vector<uint8_t> triClass(nAllTris);
+    for (uint32_t i = 0; i < nAllTris; ++i) {
         const float *n = s->tri_normal + size_t(i)*9, *uv = s->tri_uv + size_t(i)*6, *p = s->tri_pos + size_t(i)*9;
         uint32_t bits = uint32_t(s->tri_bsdf[i]) | (s->tri_smooth[i] ? 0x80000000u : 0u);
         float fb;
@@ -353,8 +453,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
 
     // ---- analytic primitives, materials, textures ----
     tgpu_quad *dQuads; tgpu_cube *dCubes; tgpu_bsdf *dBsdfs; tgpu_texture *dTex; tgpu_light *dLights;
-    if ((rc = upload(ctx, ctx->allocs, s->quads, s->n_quads, &dQuads))) return rc;
-    if ((rc = upload(ctx, ctx->allocs, s->cubes, s->n_cubes, &dCubes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs, s->quads, s->n_quads + s->n_master_quads, &dQuads))) return rc; // masters at the tail
+    if ((rc = upload(ctx, ctx->allocs, s->cubes, s->n_cubes + s->n_master_cubes, &dCubes))) return rc;
     if ((rc = upload(ctx, ctx->allocs, s->bsdfs, s->n_bsdfs, &dBsdfs))) return rc;
     if ((rc = upload(ctx, ctx->allocs, s->textures, s->n_textures, &dTex))) return rc;
     if ((rc = upload(ctx, ctx->allocs, s->lights, s->n_lights, &dLights))) return rc;
@@ -477,6 +577,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (float4 **pp : f4)
         if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
+    if (sc.nInstSets && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.hitInst))) return rc;
     {
         std::vector<uint32_t> ident(cap);
         for (uint64_t i = 0; i < cap; ++i) ident[i] = uint32_t(i);
@@ -607,8 +708,13 @@ static int driveIteration(tgpu_ctx *ctx)
     if (tail) {
         Timer t(ctx, &ctx->stats.other_ms);
         int grid = gridFor(ctx, nCur);
-        if (count) hipLaunchKernelGGL(k_tail<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-        else hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+        if (sc.nInstSets) {
+            if (count) hipLaunchKernelGGL((k_tail<true, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+            else hipLaunchKernelGGL((k_tail<false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+        } else {
+            if (count) hipLaunchKernelGGL((k_tail<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+            else hipLaunchKernelGGL((k_tail<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+        }
         // every listed slot ends on the free list: both list sets are empty afterwards
         (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0), 0, 2*TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
         ctx->stats.tail_launches++;
@@ -616,8 +722,13 @@ static int driveIteration(tgpu_ctx *ctx)
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
-            if (count) hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
-            else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
+            if (sc.nInstSets) {
+                if (count) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
+                else hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
+            } else {
+                if (count) hipLaunchKernelGGL((k_extend<true, false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
+                else hipLaunchKernelGGL((k_extend<false, false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
+            }
         }
         ctx->stats.extend_launches++;
         {
@@ -630,8 +741,13 @@ static int driveIteration(tgpu_ctx *ctx)
         }
         {
             Timer t(ctx, &ctx->stats.shadow_ms);
-            if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+            if (sc.nInstSets) {
+                if (count) hipLaunchKernelGGL((k_shadow<true, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                else hipLaunchKernelGGL((k_shadow<false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+            } else {
+                if (count) hipLaunchKernelGGL((k_shadow<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                else hipLaunchKernelGGL((k_shadow<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+            }
         }
         ctx->stats.shadow_launches++;
         {
@@ -926,10 +1042,12 @@ static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, u
         if (e == hipSuccess) e = hipMemsetAsync(st.counters + CNT(CNT_HEAD_EXT), 0, 3*TG_CNT_STRIDE*sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) {
             if (hits) {
-                hipLaunchKernelGGL((k_extend<false, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
+                if (ctx->sc.nInstSets) hipLaunchKernelGGL((k_extend<false, true, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
+                else hipLaunchKernelGGL((k_extend<false, true, false>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
                 e = hipMemcpyAsync(hits + base*4, st.hit, size_t(m)*16, hipMemcpyDeviceToHost, ctx->stream);
             } else {
-                hipLaunchKernelGGL(k_occluded_raw, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
+                if (ctx->sc.nInstSets) hipLaunchKernelGGL(k_occluded_raw<true>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
+                else hipLaunchKernelGGL(k_occluded_raw<false>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
                 e = hipMemcpyAsync(occ + base, dOcc, m, hipMemcpyDeviceToHost, ctx->stream);
             }
         }

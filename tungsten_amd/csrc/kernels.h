@@ -1223,7 +1223,10 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
                 }
             }
         }
-        // NEE rays start at info.p, which for every primitive kind has the bits of the scatter origin
+        // NEE rays start at info.p.  For scene primitives that has the bits of the scatter origin (ray.hitpoint());
+        // for a hit on an "instances" primitive it does not (applyInstance), so the shadow kernel gets it through shF --
+        // free here, because an instance hit is never emissive
+        const bool neeOriginMoved = sc.nInstSets && st.hitInst[path] != INST_NONE;
         st.rayO[path] = mk4(hitpoint, eps);
         st.rayD[path] = mk4(wo, TG_INF);
         st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
@@ -1232,8 +1235,9 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
             st.shB[path] = mk4(dB, tfarB);
             st.shC[path] = mk4(L, pickWeight);
             st.shD[path] = mk4u(B, endCap);
-            st.shE[path] = mk4u(tpVertex, hasPostAdd ? 1u : 0u);
+            st.shE[path] = mk4u(tpVertex, (hasPostAdd ? 1u : 0u) | (neeOriginMoved ? 2u : 0u));
             if (hasPostAdd) st.shF[path] = mk4(postAdd, 0.0f);
+            else if (neeOriginMoved) st.shF[path] = mk4(info.p, 0.0f);
         }
         st.em[path] = mk4u(em, smp.scramble);
     }
@@ -1261,6 +1265,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
 {
     float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
     V3 O = xyz(ro);
+    if (INST && (__float_as_uint(e.w) & 2u)) O = xyz(ldStream(&st.shF[path])); // info.p of an instance hit (shadePath)
     uint32_t endCap = __float_as_uint(d.w);
     V3 result(0.0f);
     if (a.w >= 0.0f) {

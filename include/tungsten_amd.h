@@ -65,7 +65,8 @@ enum {
     TGPU_BSDF_ROUGH_CONDUCTOR = 1,  /* RoughConductorBsdf.cpp:60-143    */
     TGPU_BSDF_SMOOTH_COAT = 2,      /* SmoothCoatBsdf.cpp:41-223        */
     TGPU_BSDF_NULL = 3,             /* NullBsdf.cpp (light carriers)    */
-    TGPU_BSDF_NUM_CLASSES = 4
+    TGPU_BSDF_ROUGH_DIELECTRIC = 4, /* RoughDielectricBsdf.cpp:55-280   */
+    TGPU_BSDF_NUM_CLASSES = 5
 };
 enum { TGPU_DIST_BECKMANN = 0, TGPU_DIST_PHONG = 1, TGPU_DIST_GGX = 2 };
 
@@ -75,13 +76,25 @@ typedef struct tgpu_bsdf {
     int32_t roughness_tex; /* rough_conductor: scalar (x channel)           */
     int32_t distribution;  /* TGPU_DIST_*                                   */
     float   eta[3], k[3];  /* conductor complex IOR                         */
-    float   ior;           /* smooth_coat                                   */
+    float   ior;           /* smooth_coat, rough_dielectric                 */
     float   thickness;
     float   sigma_a[3];
     int32_t substrate;     /* smooth_coat: index of substrate bsdf          */
     float   scaled_sigma_a[3];   /* thickness*sigma_a   (SmoothCoatBsdf.cpp:217-223, */
     float   avg_transmittance;   /* exp(-2*avg(scaled)) baked at prepareForRender)   */
+    int32_t enable_refraction;   /* rough_dielectric "enable_refraction" (default 1)  */
 } tgpu_bsdf;
+
+/* ---- participating media (src/core/media) ------------------------------- */
+/* HomogeneousMedium after prepareForRender (HomogeneousMedium.cpp:42-48) with
+ * an isotropic phase function (IsotropicPhaseFunction.cpp:17-44) and the
+ * exponential transmittance (ExponentialTransmittance.cpp:26-55, evaluated
+ * with fmath::exp_ps, thirdparty/fmath/fmath.hpp:320-363).                    */
+typedef struct tgpu_medium {
+    float   sigma_a[3], sigma_s[3], sigma_t[3];
+    int32_t absorption_only;     /* sigma_s == 0                               */
+    int32_t max_bounce;          /* Medium::_maxBounce (default 1024)          */
+} tgpu_medium;
 
 /* ---- analytic primitives ------------------------------------------------ */
 /* Quad after prepareForRender (src/core/primitives/Quad.cpp:298-316).        */
@@ -92,6 +105,7 @@ typedef struct tgpu_quad {
     float   area;
     int32_t bsdf;
     int32_t emission_tex;  /* -1 = not emissive                             */
+    int32_t int_medium, ext_medium; /* Primitive::_intMedium/_extMedium, -1 = none (Primitive.hpp:172-183) */
 } tgpu_quad;
 
 /* Cube after prepareForRender (src/core/primitives/Cube.cpp:353-370).        */
@@ -102,6 +116,7 @@ typedef struct tgpu_cube {
     float   scale[3];
     int32_t bsdf;
     int32_t emission_tex;
+    int32_t int_medium, ext_medium;
 } tgpu_cube;
 
 /* Infinite sphere / environment light (InfiniteSphere.cpp:27-50,161-244) and
@@ -133,6 +148,7 @@ typedef struct tgpu_camera {
     int32_t  filter_type;
     float    filter_bin_size;
     float    filter_cdf[32];  /* RFILTER_RESOLUTION + 1                      */
+    int32_t  medium;          /* Camera::_medium, -1 = none (Camera.hpp)     */
 } tgpu_camera;
 
 /* ---- integrator settings (TraceSettings.hpp:23-29, PathTracerSettings) --- */
@@ -143,6 +159,7 @@ typedef struct tgpu_settings {
     int32_t enable_consistency_checks;
     int32_t use_sobol;        /* renderer "stratified_sampler"               */
     int32_t adaptive_sampling;/* renderer "adaptive_sampling": keep per-4x4-tile SampleRecords (SampleRecord.hpp) */
+    int32_t enable_volume_light_sampling; /* PathTracerSettings.hpp:14-27 (default 1) */
 } tgpu_settings;
 
 /* A light is an emissive, samplable primitive, in scene order
@@ -191,6 +208,7 @@ typedef struct tgpu_scene_desc {
     const float   *tri_uv;      /* n_tris*6                                   */
     const int32_t *tri_bsdf;    /* n_tris   : index into bsdfs                */
     const uint8_t *tri_smooth;  /* n_tris   : mesh "smooth" flag              */
+    const int16_t *tri_media;   /* n_tris*2 : int_medium, ext_medium of the mesh, -1 = none; NULL = no media */
 
     uint32_t         n_quads;   const tgpu_quad    *quads;
     uint32_t         n_cubes;   const tgpu_cube    *cubes;
@@ -198,6 +216,7 @@ typedef struct tgpu_scene_desc {
     uint32_t         n_textures;const tgpu_texture *textures;
     uint32_t         n_bitmaps; const tgpu_bitmap  *bitmaps;
     uint32_t         n_lights;  const tgpu_light   *lights;
+    uint32_t         n_media;   const tgpu_medium  *media;
     tgpu_env         env;
 
     /* instance masters: tri_* / quads / cubes hold n_tris + n_master_tris (etc.) entries; the tail

@@ -147,6 +147,7 @@ struct Sampler { // sampling/SobolPathSampler.hpp:20-84 and sampling/UniformPath
         dimension = 0;
     }
     bool nextBoolean(float pTrue) { return supplemental->next1D() < pTrue; }
+    int nextDiscrete(int numChoices) { return int(supplemental->next1D()*float(numChoices)); }
     float next1D()
     {
         if (!sobol || dimension >= 1024) return supplemental->next1D();
@@ -214,6 +215,11 @@ struct Event { // samplerecords/SurfaceScatterEvent.hpp:14-66
     bool flippedFrame;
 };
 struct LightSample { V3 d; float dist, pdf; };
+} // namespace
+// media/Medium.hpp:30-47, samplerecords/MediumSample.hpp
+struct MediumStateO { bool firstScatter; int bounce; void reset() { firstScatter = true; bounce = 0; } void advance() { firstScatter = false; bounce++; } };
+struct MediumSampleO { V3 p; float t; V3 weight, emission; float pdf; bool exited; };
+namespace {
 
 struct BvhNode { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; };
 struct TriIsect { V3 v0, e1, e2, Ng; };
@@ -282,13 +288,25 @@ struct oracle_ctx {
 
     // ---- integrator --------------------------------------------------------------------
     Event makeLocalScatterEvent(const Temp &data, const Info &info, const Ray &ray, Sampler *sampler) const;
-    V3 shadowRay(Ray &ray, int endKind, uint32_t endIndex, int bounce, Counters &c) const;
-    V3 attenuatedEmission(const tgpu_light &l, float expectedDist, Temp &data, Info &info, int bounce, Ray &ray, Counters &c) const;
-    V3 lightSample(const tgpu_light &l, Event &event, int bounce, const Ray &parent, Counters &c) const;
-    V3 bsdfSampleNee(const tgpu_light &l, Event &event, int bounce, const Ray &parent, Counters &c) const;
-    V3 estimateDirect(Event &event, int bounce, const Ray &parent, Counters &c) const;
-    bool handleSurface(Event &event, Temp &data, Info &info, int bounce, bool enableLightSampling, Ray &ray,
-                       V3 &throughput, V3 &emission, bool &wasSpecular, Counters &c) const;
+    V3 shadowRay(Ray &ray, int medium, int endKind, uint32_t endIndex, int bounce, bool startsOnSurface, bool endsOnSurface, Counters &c) const;
+    V3 attenuatedEmission(const tgpu_light &l, int medium, float expectedDist, Temp &data, Info &info, int bounce, bool startsOnSurface, Ray &ray, Counters &c) const;
+    V3 lightSample(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
+    V3 bsdfSampleNee(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
+    V3 estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
+    const tgpu_light *chooseLight(const V3 &p, Sampler &sampler, float &weight) const;
+    // media (media/HomogeneousMedium.cpp, transmittances/ExponentialTransmittance.cpp, phasefunctions/IsotropicPhaseFunction.cpp)
+    V3 fastExp(const V3 &x) const;
+    bool mediumSampleDistance(int medium, Sampler &sampler, const Ray &ray, struct MediumStateO &state, struct MediumSampleO &sample) const;
+    V3 mediumTransmittance(int medium, const Ray &ray, bool startOnSurface, bool endOnSurface) const;
+    int selectMedium(const Info &info, int current, bool geometricBackside) const;
+    V3 volumeEstimateDirect(Sampler &sampler, const struct MediumSampleO &ms, int medium, int bounce, const Ray &parent, Counters &c) const;
+    bool handleVolume(Sampler &sampler, const struct MediumSampleO &ms, int medium, int bounce, bool enableLightSampling, Ray &ray, V3 &throughput, V3 &emission,
+                      bool &wasSpecular, Counters &c) const;
+    uint32_t expTable[1024];
+    float expA, expB;
+    void buildExpTable();
+    bool handleSurface(Event &event, Temp &data, Info &info, int &medium, int bounce, bool enableLightSampling, Ray &ray,
+                       V3 &throughput, V3 &emission, bool &wasSpecular, struct MediumStateO &state, Counters &c) const;
     V3 traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c) const;
     void cameraRay(uint32_t px, uint32_t py, float xi0, float xi1, Ray &ray) const;
 };
@@ -1312,6 +1330,8 @@ uint32_t oracle_ctx::bsdfLobes(int b) const
     case TGPU_BSDF_LAMBERT: return DiffuseReflectionLobe;
     case TGPU_BSDF_ROUGH_CONDUCTOR: return GlossyReflectionLobe;
     case TGPU_BSDF_SMOOTH_COAT: return SpecularReflectionLobe | bsdfLobes(d.substrate);
+    case TGPU_BSDF_ROUGH_DIELECTRIC: // RoughDielectricBsdf.cpp:38-41
+        return d.enable_refraction ? (GlossyReflectionLobe | GlossyTransmissionLobe) : GlossyReflectionLobe;
     default: return 0;
     }
 }
@@ -1404,6 +1424,13 @@ inline float dielectricReflectance(float eta, float cosThetaI, float &cosThetaT)
     float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
     return (Rs*Rs + Rp*Rp)*0.5f;
 }
+inline float sgnE(float v) { return v < 0.0f ? -1.0f : 1.0f; } // RoughDielectricBsdf.cpp:13-17
+// Bsdf::eval/sample(event, adjoint = false) multiply by sqr(eta(event)) (Bsdf.hpp:71-97, RoughDielectricBsdf.cpp:266-272)
+inline float dielectricEtaSq(float ior, const V3 &wi, const V3 &wo)
+{
+    float eta = wi.z*wo.z >= 0.0f ? 1.0f : (wi.z < 0.0f ? ior : 1.0f/ior);
+    return eta*eta;
+}
 inline bool checkReflectionConstraint(const V3 &wi, const V3 &wo) // bsdfs/Bsdf.hpp:44-47
 {
     return std::abs(wi.z*wo.z - wi.x*wo.x - wi.y*wo.y - 1.0f) < 1e-3f;
@@ -1434,6 +1461,37 @@ V3 oracle_ctx::bsdfEval(int b, const Event &e) const
         float D = mf.D(alpha, hr);
         float fr = (G*D*0.25f)/e.wi.z;
         return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*fr);
+    }
+    case TGPU_BSDF_ROUGH_DIELECTRIC: { // bsdfs/RoughDielectricBsdf.cpp:133-164 (evalBase), :242-249
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float wiDotN = e.wi.z, woDotN = e.wo.z;
+        bool reflect = wiDotN*woDotN >= 0.0f;
+        if ((reflect && !sampleR) || (!reflect && !sampleT)) return V3(0.0f);
+        MF mf{this, d.distribution};
+        float alpha = roughnessToAlpha(roughness);
+        float eta = wiDotN < 0.0f ? d.ior : 1.0f/d.ior;
+        V3 m;
+        if (reflect) m = sgnE(wiDotN)*(e.wi + e.wo).normalized();
+        else m = -(e.wi*eta + e.wo).normalized();
+        float wiDotM = e.wi.dot(m), woDotM = e.wo.dot(m);
+        float cosThetaT;
+        float F = dielectricReflectance(1.0f/d.ior, wiDotM, cosThetaT);
+        float G = mf.G(alpha, e.wi, e.wo, m);
+        float D = mf.D(alpha, m);
+        V3 f;
+        if (reflect) {
+            float fr = (F*G*D*0.25f)/std::abs(wiDotN);
+            f = V3(fr);
+        } else {
+            float q = eta*wiDotM + woDotM;
+            float fs = std::abs(wiDotM*woDotM)*(1.0f - F)*G*D/((q*q)*std::abs(wiDotN));
+            f = V3(fs);
+        }
+        f = f*texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        f *= dielectricEtaSq(d.ior, e.wi, e.wo);
+        return f;
     }
     case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:146-178
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
@@ -1506,6 +1564,62 @@ bool oracle_ctx::bsdfSample(int b, Event &e) const
         e.sampledLobe = GlossyReflectionLobe;
         return true;
     }
+    case TGPU_BSDF_ROUGH_DIELECTRIC: { // bsdfs/RoughDielectricBsdf.cpp:55-131 (sampleBase), :232-240
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        const float ior = d.ior;
+        MF mf{this, d.distribution};
+        float wiDotN = e.wi.z;
+        float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+        float sampleRoughness = (1.2f - 0.2f*std::sqrt(std::abs(wiDotN)))*roughness;
+        float alpha = roughnessToAlpha(roughness);
+        float sampleAlpha = roughnessToAlpha(sampleRoughness);
+        float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+        V3 m = mf.sample(sampleAlpha, xix, xiy);
+        float pm = mf.pdf(sampleAlpha, m);
+        if (pm < 1e-10f) return false;
+        float wiDotM = e.wi.dot(m);
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+        float etaM = wiDotM < 0.0f ? ior : 1.0f/ior;
+        bool reflect;
+        if (sampleR && sampleT) {
+            reflect = e.sampler->nextBoolean(F);
+        } else if (sampleT) {
+            if (F == 1.0f) return false;
+            reflect = false;
+        } else if (sampleR) {
+            reflect = true;
+        } else {
+            return false;
+        }
+        if (reflect) e.wo = 2.0f*wiDotM*m - e.wi;
+        else e.wo = (etaM*wiDotM - sgnE(wiDotM)*cosThetaT)*m - etaM*e.wi;
+        float woDotN = e.wo.z;
+        bool reflected = wiDotN*woDotN > 0.0f;
+        if (reflected != reflect) return false;
+        float woDotM = e.wo.dot(m);
+        float G = mf.G(alpha, e.wi, e.wo, m);
+        float D = mf.D(alpha, m);
+        e.weight = V3(std::abs(wiDotM)*G*D/(std::abs(wiDotN)*pm));
+        if (reflect) {
+            e.pdf = pm*0.25f/std::abs(wiDotM);
+            e.sampledLobe = GlossyReflectionLobe;
+        } else {
+            float q = eta*wiDotM + woDotM;
+            e.pdf = pm*std::abs(woDotM)/(q*q);
+            e.sampledLobe = GlossyTransmissionLobe;
+        }
+        if (sampleR && sampleT) {
+            if (reflect) e.pdf *= F; else e.pdf *= 1.0f - F;
+        } else {
+            if (reflect) e.weight *= F; else e.weight *= 1.0f - F;
+        }
+        e.weight *= texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        e.weight *= dielectricEtaSq(d.ior, e.wi, e.wo);
+        return true;
+    }
     case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:41-100
         if (e.wi.z <= 0.0f) return false;
         uint32_t subLobes = bsdfLobes(d.substrate);
@@ -1576,6 +1690,36 @@ float oracle_ctx::bsdfPdf(int b, const Event &e) const
         V3 hr = (e.wi + e.wo).normalized();
         return mf.pdf(sampleAlpha, hr)*0.25f/e.wi.dot(hr);
     }
+    case TGPU_BSDF_ROUGH_DIELECTRIC: { // bsdfs/RoughDielectricBsdf.cpp:198-234 (pdfBase)
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float wiDotN = e.wi.z, woDotN = e.wo.z;
+        bool reflect = wiDotN*woDotN >= 0.0f;
+        if ((reflect && !sampleR) || (!reflect && !sampleT)) return 0.0f;
+        MF mf{this, d.distribution};
+        float sampleRoughness = (1.2f - 0.2f*std::sqrt(std::abs(wiDotN)))*roughness;
+        float sampleAlpha = roughnessToAlpha(sampleRoughness);
+        float eta = wiDotN < 0.0f ? d.ior : 1.0f/d.ior;
+        V3 m;
+        if (reflect) m = sgnE(wiDotN)*(e.wi + e.wo).normalized();
+        else m = -(e.wi*eta + e.wo).normalized();
+        float wiDotM = e.wi.dot(m), woDotM = e.wo.dot(m);
+        float cosThetaT;
+        float F = dielectricReflectance(1.0f/d.ior, wiDotM, cosThetaT);
+        float pm = mf.pdf(sampleAlpha, m);
+        float pdf;
+        if (reflect) {
+            pdf = pm*0.25f/std::abs(wiDotM);
+        } else {
+            float q = eta*wiDotM + woDotM;
+            pdf = pm*std::abs(woDotM)/(q*q);
+        }
+        if (sampleR && sampleT) {
+            if (reflect) pdf *= F; else pdf *= 1.0f - F;
+        }
+        return pdf;
+    }
     case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:180-215
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
         uint32_t subLobes = bsdfLobes(d.substrate);
@@ -1634,20 +1778,23 @@ Event oracle_ctx::makeLocalScatterEvent(const Temp & /*data*/, const Info &info,
     return e;
 }
 
-V3 oracle_ctx::shadowRay(Ray &ray, int endKind, uint32_t endIndex, int bounce, Counters &c) const
-{   // TraceBase.cpp:62-125 (generalizedShadowRayImpl<false>) without media; none of the BSDFs in
-    // scope has a ForwardLobe, so the first non-end-cap hit blocks.
+V3 oracle_ctx::shadowRay(Ray &ray, int medium, int endKind, uint32_t endIndex, int bounce, bool startsOnSurface, bool endsOnSurface, Counters &c) const
+{   // TraceBase.cpp:62-125 (generalizedShadowRayImpl<false>).  None of the BSDFs in scope has a ForwardLobe, so the
+    // first non-end-cap hit blocks and the loop body runs once; the medium attenuates the unoccluded segment.
     c.shadow++;
     Temp data;
     Info info;
+    V3 throughput(1.0f);
     bool didHit = intersect(ray, data, info, c) && !(info.kind == endKind && info.index == endIndex);
     if (didHit) {
         if (!(bsdfLobes(info.bsdf) & ForwardLobe)) return V3(0.0f);
     }
-    return bounce >= sc.settings.min_bounces ? V3(1.0f) : V3(0.0f);
+    if (medium >= 0) throughput *= mediumTransmittance(medium, ray, startsOnSurface, endsOnSurface);
+    return bounce >= sc.settings.min_bounces ? throughput : V3(0.0f);
 }
 
-V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, float expectedDist, Temp &data, Info &info, int bounce, Ray &ray, Counters &c) const
+V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, int medium, float expectedDist, Temp &data, Info &info, int bounce, bool startsOnSurface,
+                                  Ray &ray, Counters &c) const
 {   // TraceBase.cpp:144-174
     constexpr float fudgeFactor = 1.0f + 1e-3f;
     if (!lightIntersect(l, ray, data) || ray.farT*fudgeFactor < expectedDist) return V3(0.0f);
@@ -1655,12 +1802,12 @@ V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, float expectedDist, Temp 
     info.w = ray.dir;
     intersectionInfo(data, info);
     int endKind = l.kind == TGPU_LIGHT_ENV ? PRIM_ENV : PRIM_QUAD;
-    V3 shadow = shadowRay(ray, endKind, uint32_t(l.index), bounce, c);
+    V3 shadow = shadowRay(ray, medium, endKind, uint32_t(l.index), bounce, startsOnSurface, true, c);
     if (shadow == 0.0f) return V3(0.0f);
     return shadow*primEvalDirect(data, info);
 }
 
-V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int bounce, const Ray &parent, Counters &c) const
+V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const
 {   // TraceBase.cpp:246-285
     LightSample sample;
     if (!lightSampleDirect(l, event.info->p, *event.sampler, sample)) return V3(0.0f);
@@ -1670,14 +1817,15 @@ V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int bounce, const 
         bool shadingBackside = (event.wo.z < 0.0f) ^ event.flippedFrame;
         if (geometricBackside != shadingBackside) return V3(0.0f);
     }
+    medium = selectMedium(*event.info, medium, sample.d.dot(event.info->Ng) < 0.0f); // the medium on the light's side (:261-262)
     event.requestedLobe = AllButSpecular;
-    V3 f = bsdfEval(event.info->bsdf, event); // eval(event, false): *= sqr(eta) == 1
+    V3 f = bsdfEval(event.info->bsdf, event); // eval(event, false)
     if (f == 0.0f) return V3(0.0f);
     Ray ray{event.info->p, sample.d, event.info->epsilon, INF};
     (void)parent;
     Temp data;
     Info info;
-    V3 e = attenuatedEmission(l, sample.dist, data, info, bounce, ray, c);
+    V3 e = attenuatedEmission(l, medium, sample.dist, data, info, bounce, true, ray, c);
     if (e == 0.0f) return V3(0.0f);
     V3 lightF = f*e/sample.pdf;
     float bp = bsdfPdf(event.info->bsdf, event);
@@ -1685,7 +1833,7 @@ V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int bounce, const 
     return lightF;
 }
 
-V3 oracle_ctx::bsdfSampleNee(const tgpu_light &l, Event &event, int bounce, const Ray & /*parent*/, Counters &c) const
+V3 oracle_ctx::bsdfSampleNee(const tgpu_light &l, Event &event, int medium, int bounce, const Ray & /*parent*/, Counters &c) const
 {   // TraceBase.cpp:287-321
     event.requestedLobe = AllButSpecular;
     if (!bsdfSample(event.info->bsdf, event)) return V3(0.0f);
@@ -1696,10 +1844,11 @@ V3 oracle_ctx::bsdfSampleNee(const tgpu_light &l, Event &event, int bounce, cons
         bool shadingBackside = (event.wo.z < 0.0f) ^ event.flippedFrame;
         if (geometricBackside != shadingBackside) return V3(0.0f);
     }
+    medium = selectMedium(*event.info, medium, wo.dot(event.info->Ng) < 0.0f); // :301-302
     Ray ray{event.info->p, wo, event.info->epsilon, INF};
     Temp data;
     Info info;
-    V3 e = attenuatedEmission(l, -1.0f, data, info, bounce, ray, c);
+    V3 e = attenuatedEmission(l, medium, -1.0f, data, info, bounce, true, ray, c);
     if (e == 0.0f) return V3(0.0f);
     V3 bsdfF = e*event.weight;
     float lp = lightDirectPdf(l, data, info, event.info->p);
@@ -1707,10 +1856,9 @@ V3 oracle_ctx::bsdfSampleNee(const tgpu_light &l, Event &event, int bounce, cons
     return bsdfF;
 }
 
-V3 oracle_ctx::estimateDirect(Event &event, int bounce, const Ray &parent, Counters &c) const
-{   // TraceBase.cpp:483-494 -> chooseLight :416-459 -> sampleDirect :383-400
-    if (sc.n_lights == 0) return V3(0.0f);
-    float weight;
+const tgpu_light *oracle_ctx::chooseLight(const V3 &p, Sampler &sampler, float &weight) const
+{   // TraceBase.cpp:416-459
+    if (sc.n_lights == 0) return nullptr;
     const tgpu_light *light;
     if (sc.n_lights == 1) {
         weight = 1.0f;
@@ -1721,7 +1869,7 @@ V3 oracle_ctx::estimateDirect(Event &event, int bounce, const Ray &parent, Count
         float total = 0.0f;
         unsigned numNonNegative = 0;
         for (uint32_t i = 0; i < n; ++i) {
-            lightPdf[i] = lightApproximateRadiance(sc.lights[i], event.info->p);
+            lightPdf[i] = lightApproximateRadiance(sc.lights[i], p);
             if (lightPdf[i] >= 0.0f) {
                 total += lightPdf[i];
                 numNonNegative++;
@@ -1739,8 +1887,8 @@ V3 oracle_ctx::estimateDirect(Event &event, int bounce, const Ray &parent, Count
                 }
             }
         }
-        if (total == 0.0f) return V3(0.0f);
-        float t = event.sampler->next1D()*total;
+        if (total == 0.0f) return nullptr;
+        float t = sampler.next1D()*total;
         light = nullptr;
         for (uint32_t i = 0; i < n; ++i) {
             if (t < lightPdf[i] || i == n - 1) {
@@ -1751,21 +1899,27 @@ V3 oracle_ctx::estimateDirect(Event &event, int bounce, const Ray &parent, Count
                 t -= lightPdf[i];
             }
         }
-        if (!light) return V3(0.0f);
     }
-    // sampleDirect
+    return light;
+}
+
+V3 oracle_ctx::estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c) const
+{   // TraceBase.cpp:483-494 -> sampleDirect :383-400
+    float weight;
+    const tgpu_light *light = chooseLight(event.info->p, *event.sampler, weight);
+    if (!light) return V3(0.0f);
     V3 result(0.0f);
     uint32_t lobes = bsdfLobes(event.info->bsdf);
     bool pureSpecular = lobes != 0 && (lobes & ~uint32_t(SpecularLobe)) == 0;
     if (pureSpecular || lobes == ForwardLobe) return V3(0.0f);
-    result += lightSample(*light, event, bounce, parent, c);
-    result += bsdfSampleNee(*light, event, bounce, parent, c); // lights in scope are never Dirac
+    result += lightSample(*light, event, medium, bounce, parent, c);
+    result += bsdfSampleNee(*light, event, medium, bounce, parent, c); // lights in scope are never Dirac
     return result*weight;
 }
 
-bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int bounce, bool enableLightSampling, Ray &ray,
-                               V3 &throughput, V3 &emission, bool &wasSpecular, Counters &c) const
-{   // TraceBase.cpp:516-568 (adjoint = false, no media)
+bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int &medium, int bounce, bool enableLightSampling, Ray &ray,
+                               V3 &throughput, V3 &emission, bool &wasSpecular, MediumStateO &state, Counters &c) const
+{   // TraceBase.cpp:516-568 (adjoint = false)
     c.surface++;
     Event fwd = event; // makeForwardEvent
     fwd.wo = -fwd.wi;
@@ -1782,7 +1936,7 @@ bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int bounce,
         throughput *= event.weight;
     } else {
         if (enableLightSampling && bounce < sc.settings.max_bounces - 1)
-            emission += estimateDirect(event, bounce + 1, ray, c)*throughput;
+            emission += estimateDirect(event, medium, bounce + 1, ray, c)*throughput;
         if (primEmissive(info.kind, info.index) && bounce >= sc.settings.min_bounces) {
             if (!enableLightSampling || wasSpecular || !primSamplable(info.kind, info.index))
                 emission += primEvalDirect(data, info)*throughput;
@@ -1798,8 +1952,157 @@ bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int bounce,
         throughput *= event.weight;
         wasSpecular = (event.sampledLobe & SpecularLobe) != 0;
     }
+    bool geometricBackside = wo.dot(info.Ng) < 0.0f;
+    medium = selectMedium(info, medium, geometricBackside);
+    state.reset();
     V3 hitpoint = ray.pos + ray.dir*ray.farT;
     ray = Ray{hitpoint, wo, info.epsilon, INF};
+    return true;
+}
+
+// ---- media ------------------------------------------------------------------------------
+void oracle_ctx::buildExpTable()
+{   // fmath::ExpVar<10> (thirdparty/fmath/fmath.hpp:90-127)
+    float log_2 = ::logf(2.0f);
+    expA = 1024/log_2;
+    expB = log_2/1024;
+    for (int i = 0; i < 1024; ++i) {
+        float y = std::pow(2.0f, (float)i/1024);
+        expTable[i] = tgpu_float_to_bits(y) & 0x7FFFFFu;
+    }
+}
+
+V3 oracle_ctx::fastExp(const V3 &v) const
+{   // FastMath::exp(Vec3f) = fmath::exp_ps on (x, y, z, 0) (math/FastMath.hpp:23-27, fmath.hpp:320-363)
+    float x[3] = {v.x, v.y, v.z};
+    bool over = false;
+    for (int i = 0; i < 3; ++i)
+        if (int32_t(tgpu_float_to_bits(x[i]) & 0x7FFFFFFFu) > int32_t(0x42B00000)) over = true;
+    float out[3];
+    for (int i = 0; i < 3; ++i) {
+        float xi = x[i];
+        if (over) {
+            xi = xi < 88.0f ? xi : 88.0f;   // _mm_min_ps(x, maxX)
+            xi = xi > -88.0f ? xi : -88.0f; // _mm_max_ps(x, minX)
+        }
+        int32_t r = _mm_cvtss_si32(_mm_set_ss(xi*expA)); // cvtps_epi32: round to nearest even
+        float t = xi - float(r)*expB;
+        t = t + 1.0f;
+        uint32_t vIdx = uint32_t(r) & 1023u;
+        uint32_t u = ((uint32_t(r) + (127u << 10)) >> 10) << 23;
+        out[i] = t*tgpu_bits_to_float(expTable[vIdx] | u);
+    }
+    return V3(out[0], out[1], out[2]);
+}
+
+bool oracle_ctx::mediumSampleDistance(int medium, Sampler &sampler, const Ray &ray, MediumStateO &state, MediumSampleO &sample) const
+{   // HomogeneousMedium.cpp:65-108 ; ExponentialTransmittance: every surface/medium variant is exp(-tau), sigmaBar = 1
+    const tgpu_medium &m = sc.media[medium];
+    const V3 sigmaT(m.sigma_t), sigmaS(m.sigma_s);
+    sample.emission = V3(0.0f);
+    if (state.bounce > m.max_bounce) return false;
+    float maxT = ray.farT;
+    if (m.absorption_only) {
+        if (maxT == INF) return false;
+        sample.t = maxT;
+        sample.weight = fastExp(-(sample.t*sigmaT));
+        sample.pdf = 1.0f;
+        sample.exited = true;
+    } else {
+        int component = sampler.nextDiscrete(3);
+        float sigmaTc = sigmaT[component];
+        float t = -mlog(1.0f - sampler.next1D())/sigmaTc; // ExponentialTransmittance::sampleSurface/sampleMedium :46-53
+        sample.t = fmin2(t, maxT);
+        sample.exited = t >= maxT;
+        V3 tau = sample.t*sigmaT;
+        sample.weight = fastExp(-tau); // eval(tau, firstScatter, exited): mediumMedium(tau)/sigmaBar() == exp(-tau)/1
+        if (sample.exited) {
+            sample.pdf = fastExp(-tau).avg();
+        } else {
+            sample.pdf = (sigmaT*fastExp(-tau)).avg();
+            sample.weight *= sigmaS*1.0f;
+        }
+        sample.weight /= sample.pdf;
+        state.advance();
+    }
+    sample.p = ray.pos + sample.t*ray.dir;
+    return true;
+}
+
+V3 oracle_ctx::mediumTransmittance(int medium, const Ray &ray, bool /*startOnSurface*/, bool /*endOnSurface*/) const
+{   // HomogeneousMedium.cpp:110-117
+    if (ray.farT == INF) return V3(0.0f);
+    return fastExp(-(V3(sc.media[medium].sigma_t)*ray.farT));
+}
+
+int oracle_ctx::selectMedium(const Info &info, int current, bool geometricBackside) const
+{   // Primitive::selectMedium (primitives/Primitive.hpp:172-183)
+    int im = -1, em = -1;
+    if (info.kind == PRIM_TRI && sc.tri_media) { im = sc.tri_media[size_t(info.index)*2]; em = sc.tri_media[size_t(info.index)*2 + 1]; }
+    else if (info.kind == PRIM_QUAD) { im = sc.quads[info.index].int_medium; em = sc.quads[info.index].ext_medium; }
+    else if (info.kind == PRIM_CUBE) { im = sc.cubes[info.index].int_medium; em = sc.cubes[info.index].ext_medium; }
+    if (im >= 0 || em >= 0) return geometricBackside ? im : em;
+    return current;
+}
+
+V3 oracle_ctx::volumeEstimateDirect(Sampler &sampler, const MediumSampleO &ms, int medium, int bounce, const Ray &parent, Counters &c) const
+{   // TraceBase.cpp:470-481 -> volumeSampleDirect :402-414 -> volumeLightSample :323-354, volumePhaseSample :356-381
+    float weight;
+    const tgpu_light *light = chooseLight(ms.p, sampler, weight);
+    if (!light) return V3(0.0f);
+    V3 result(0.0f);
+    { // volumeLightSample
+        LightSample ls;
+        V3 lightF(0.0f);
+        if (lightSampleDirect(*light, ms.p, sampler, ls)) {
+            V3 f(INV_FOUR_PI); // IsotropicPhaseFunction::eval
+            Ray ray{ms.p, ls.d, 0.0f, INF};
+            Temp data;
+            Info info;
+            V3 e = attenuatedEmission(*light, medium, ls.dist, data, info, bounce, false, ray, c);
+            if (!(e == 0.0f)) {
+                lightF = f*e/ls.pdf;
+                float pp = INV_FOUR_PI; // phase->pdf
+                lightF *= (ls.pdf*ls.pdf)/(ls.pdf*ls.pdf + pp*pp);
+            }
+        }
+        result = lightF;
+    }
+    { // volumePhaseSample (lights in scope are never Dirac)
+        float xi0 = sampler.next1D(), xi1 = sampler.next1D();
+        float phi = xi0*TWO_PI; // SampleWarp::uniformSphere (SampleWarp.hpp:96-107)
+        float z = xi1*2.0f - 1.0f;
+        float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
+        V3 w(mcos(phi)*r, msin(phi)*r, z);
+        Ray ray{ms.p, w, 0.0f, INF};
+        Temp data;
+        Info info;
+        V3 e = attenuatedEmission(*light, medium, -1.0f, data, info, bounce, false, ray, c);
+        if (!(e == 0.0f)) {
+            V3 phaseF = e*V3(1.0f); // phaseSample.weight
+            float lp = lightDirectPdf(*light, data, info, ms.p);
+            float pp = INV_FOUR_PI;
+            phaseF *= (pp*pp)/(pp*pp + lp*lp);
+            result += phaseF;
+        }
+    }
+    (void)parent;
+    return result*weight;
+}
+
+bool oracle_ctx::handleVolume(Sampler &sampler, const MediumSampleO &ms, int medium, int bounce, bool enableLightSampling, Ray &ray, V3 &throughput,
+                              V3 &emission, bool &wasSpecular, Counters &c) const
+{   // TraceBase.cpp:496-514
+    wasSpecular = !enableLightSampling;
+    if (enableLightSampling && bounce < sc.settings.max_bounces - 1)
+        emission += throughput*volumeEstimateDirect(sampler, ms, medium, bounce + 1, ray, c);
+    float xi0 = sampler.next1D(), xi1 = sampler.next1D(); // IsotropicPhaseFunction::sample
+    float phi = xi0*TWO_PI;
+    float z = xi1*2.0f - 1.0f;
+    float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
+    V3 w(mcos(phi)*r, msin(phi)*r, z);
+    ray = Ray{ms.p, w, 0.0f, INF};
+    throughput *= V3(1.0f);
     return true;
 }
 
@@ -1842,7 +2145,7 @@ void oracle_ctx::cameraRay(uint32_t px, uint32_t py, float xi0, float xi1, Ray &
 }
 
 V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c) const
-{   // integrators/path_tracer/PathTracer.cpp:14-149 (no media, no AOV buffers)
+{   // integrators/path_tracer/PathTracer.cpp:14-149 (no AOV buffers; low_order_scattering = include_surfaces = true)
     c.samples++;
     float xi0 = sampler.next1D(), xi1 = sampler.next1D();
     Ray ray;
@@ -1852,16 +2155,34 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
     Info info;
     V3 emission(0.0f);
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
-    const bool nee = sc.settings.enable_light_sampling != 0;
+    const bool nee = sc.settings.enable_light_sampling != 0, volumeNee = sc.settings.enable_volume_light_sampling != 0;
+    MediumSampleO mediumSample;
+    MediumStateO state;
+    state.reset();
+    int medium = sc.n_media ? sc.camera.medium : -1;
 
+    int mediumBounces = 0;
     int bounce = 0;
     c.extend++;
     bool didHit = intersect(ray, data, info, c);
     bool wasSpecular = true;
-    while (didHit && bounce < maxBounces) {
-        Event surfaceEvent = makeLocalScatterEvent(data, info, ray, &sampler);
-        bool terminate = !handleSurface(surfaceEvent, data, info, bounce, nee, ray, throughput, emission, wasSpecular, c);
-        if (terminate) return emission;
+    while ((didHit || medium >= 0) && bounce < maxBounces) {
+        bool hitSurface = true;
+        if (medium >= 0) {
+            if (!mediumSampleDistance(medium, sampler, ray, state, mediumSample)) return emission;
+            emission += throughput*mediumSample.emission;
+            throughput *= mediumSample.weight;
+            hitSurface = mediumSample.exited;
+            if (hitSurface && !didHit) break;
+        }
+        if (hitSurface) {
+            Event surfaceEvent = makeLocalScatterEvent(data, info, ray, &sampler);
+            bool terminate = !handleSurface(surfaceEvent, data, info, medium, bounce, nee, ray, throughput, emission, wasSpecular, state, c);
+            if (terminate) return emission;
+        } else {
+            mediumBounces++;
+            if (!handleVolume(sampler, mediumSample, medium, bounce, volumeNee, ray, throughput, emission, wasSpecular, c)) return emission;
+        }
 
         if (throughput.max() == 0.0f) break;
 
@@ -1881,6 +2202,7 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
             didHit = intersect(ray, data, info, c);
         }
     }
+    (void)mediumBounces;
     if (bounce >= minBounces && bounce < maxBounces) {
         // TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) / TraceableScene::intersectInfinites (:194-209)
         if (sc.env.present) {
@@ -1913,6 +2235,7 @@ oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_m
     ctx->prepareTris();
     ctx->buildBvh(0, ctx->sc.n_tris, ctx->sceneBvh);
     ctx->buildInstances();
+    ctx->buildExpTable();
     return ctx;
 }
 
@@ -2072,6 +2395,14 @@ int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_
 }
 
 uint32_t oracle_hash32(uint32_t x) { return hash32(x); }
+
+void oracle_fast_exp(const oracle_ctx *ctx, const float *x3, float *out3)
+{
+    V3 e = ctx->fastExp(V3(x3[0], x3[1], x3[2]));
+    out3[0] = e.x; out3[1] = e.y; out3[2] = e.z;
+}
+void oracle_exp_table(const oracle_ctx *ctx, uint32_t *out1024) { std::memcpy(out1024, ctx->expTable, sizeof(ctx->expTable)); }
+
 
 uint32_t oracle_sobol(const oracle_ctx *ctx, uint32_t index, uint32_t dim, uint32_t scramble)
 {

@@ -68,6 +68,8 @@ int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_
 
 /* Leaf functions exposed for known-answer tests. */
 uint32_t oracle_hash32(uint32_t x);
+void oracle_fast_exp(const oracle_ctx *ctx, const float *x3, float *out3); /* FastMath::exp(Vec3f) */
+void oracle_exp_table(const oracle_ctx *ctx, uint32_t *out1024);
 uint32_t oracle_sobol(const oracle_ctx *ctx, uint32_t index, uint32_t dim, uint32_t scramble);
 void oracle_pcg_stream(uint64_t state, uint64_t seq, uint32_t n, uint32_t *out);
 void oracle_camera_ray(const oracle_ctx *ctx, uint32_t px, uint32_t py, float xi0, float xi1, float *origin_dir6);

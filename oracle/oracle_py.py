@@ -33,6 +33,8 @@ def lib():
                                               C.c_void_p, C.c_int]
         L.oracle_render_shard_adaptive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_int]
+        L.oracle_exp_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_fast_exp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_trace_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.oracle_hash32.restype = C.c_uint32

@@ -10,6 +10,7 @@
 #include <bsdfs/Microfacet.hpp>
 #include <bsdfs/Fresnel.hpp>
 #include <sobol/sobol.h>
+#include <math/FastMath.hpp>
 #include <cstdio>
 #include <cstring>
 
@@ -69,6 +70,16 @@ int main()
         TangentFrame f(n);
         std::printf("%s[%u, %u, %u, %u, %u, %u, %u, %u, %u]", i ? ", " : "", bits(n.x()), bits(n.y()), bits(n.z()), bits(f.tangent.x()), bits(f.tangent.y()),
                     bits(f.tangent.z()), bits(f.bitangent.x()), bits(f.bitangent.y()), bits(f.bitangent.z()));
+    }
+    // fmath::exp_ps as used by ExponentialTransmittance (math/FastMath.hpp:23-27): the 1024-entry mantissa table and
+    // known answers (inputs include the clamped range and values next to table boundaries)
+    std::printf("],\n\"fmath_exp_table\": [");
+    for (int i = 0; i < 1024; ++i) std::printf("%s%u", i ? ", " : "", fmath::local::C<>::expVar.tbl[i]);
+    std::printf("],\n\"fmath_exp\": [");
+    for (int i = 0; i < 96; ++i) {
+        float x = i < 64 ? -12.0f*gen.next1D() : (i < 80 ? -100.0f*gen.next1D() : 3.0f*gen.next1D());
+        Vec3f e = FastMath::exp(Vec3f(x, x*0.5f, -x*0.25f));
+        std::printf("%s[%u, %u, %u, %u]", i ? ", " : "", bits(x), bits(e.x()), bits(e.y()), bits(e.z()));
     }
     std::printf("]\n}\n");
     return 0;

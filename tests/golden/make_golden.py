@@ -33,6 +33,9 @@ FIXTURES = [
     # "instances" primitive: cube + quad masters, overlapping rotated instances (Instance.cpp's last-hit-wins traversal)
     ("inst_cubes_128x72_8spp", "instances/inst_cubes.json", (128, 72), 8),
     ("inst_many_96x54_4spp", "instances/inst_many.json", (96, 54), 4),    # 294 instances: binned-SAH levels of the BVH2
+    # config 5: rough_dielectric boundary + homogeneous medium inside (volume scattering / absorption only)
+    ("c5_128x72_16spp", "materialtest/c5.json", (128, 72), 16),
+    ("c5_absorb_128x72_8spp", "materialtest/c5_absorb.json", (128, 72), 8),
     ("c1_adaptive_128x72_64spp", "materialtest/materialtest.json", (128, 72), 64, True),
 ]
 

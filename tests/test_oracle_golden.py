@@ -19,6 +19,9 @@ CASES = [
     # "instances" primitives: BVH2 build + ordered traversal + last-hit-wins + the double-transformed hit point
     ("inst_cubes_128x72_8spp", "instances/inst_cubes.json", (128, 72), 8),   # 16 instances (full-sweep SAH only)
     ("inst_many_96x54_4spp", "instances/inst_many.json", (96, 54), 4),       # 294 instances (binned SAH levels)
+    # config 5 (a26): rough_dielectric boundary, homogeneous medium inside (distance sampling, volume NEE, fmath exp)
+    ("c5_128x72_16spp", "materialtest/c5.json", (128, 72), 16),
+    ("c5_absorb_128x72_8spp", "materialtest/c5_absorb.json", (128, 72), 8),  # absorption only + beckmann glass
 ]
 
 

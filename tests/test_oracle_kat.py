@@ -95,3 +95,20 @@ def test_tangent_frame(kat, L):
         n = np.array([f32(b) for b in row[:3]], np.float32)
         L.oracle_tangent_frame(n.ctypes.data, out.ctypes.data)
         assert [bits(t) for t in out] == row[3:]
+
+
+def test_fmath_exp(kat, ta, oracle_py):
+    """ExponentialTransmittance evaluates fmath::exp_ps (1024-entry table + first-order term): the oracle's table
+    and 96 x 3 results, incl. the clamped range, against the reference's own."""
+    hs = ta.HostScene(scene_path("materialtest/c5.json"), resolution=(16, 9))
+    o = oracle_py.Oracle(hs, **oracle_py.REF)
+    lib = oracle_py.lib()
+    tbl = np.zeros(1024, np.uint32)
+    lib.oracle_exp_table(C.c_void_p(o._h), tbl.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(tbl, np.array(kat["fmath_exp_table"], np.uint32))
+    for x, ex, ey, ez in kat["fmath_exp"]:
+        xf = f32(x)
+        inp = np.array([xf, xf*np.float32(0.5), -xf*np.float32(0.25)], np.float32)
+        out = np.zeros(3, np.float32)
+        lib.oracle_fast_exp(C.c_void_p(o._h), inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert [int(v) for v in out.view(np.uint32)] == [ex, ey, ez]

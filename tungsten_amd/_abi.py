@@ -25,17 +25,22 @@ class Bitmap(C.Structure):
 class Bsdf(C.Structure):
     _fields_ = [("type", i32), ("albedo_tex", i32), ("roughness_tex", i32), ("distribution", i32),
                 ("eta", f32*3), ("k", f32*3), ("ior", f32), ("thickness", f32), ("sigma_a", f32*3),
-                ("substrate", i32), ("scaled_sigma_a", f32*3), ("avg_transmittance", f32)]
+                ("substrate", i32), ("scaled_sigma_a", f32*3), ("avg_transmittance", f32), ("enable_refraction", i32)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("sigma_a", f32*3), ("sigma_s", f32*3), ("sigma_t", f32*3), ("absorption_only", i32), ("max_bounce", i32)]
 
 
 class Quad(C.Structure):
     _fields_ = [("base", f32*3), ("edge0", f32*3), ("edge1", f32*3), ("normal", f32*3), ("tangent", f32*3),
-                ("bitangent", f32*3), ("inv_uv_sq", f32*2), ("area", f32), ("bsdf", i32), ("emission_tex", i32)]
+                ("bitangent", f32*3), ("inv_uv_sq", f32*2), ("area", f32), ("bsdf", i32), ("emission_tex", i32),
+                ("int_medium", i32), ("ext_medium", i32)]
 
 
 class Cube(C.Structure):
     _fields_ = [("rot", f32*9), ("inv_rot", f32*9), ("pos", f32*3), ("scale", f32*3), ("bsdf", i32),
-                ("emission_tex", i32)]
+                ("emission_tex", i32), ("int_medium", i32), ("ext_medium", i32)]
 
 
 class Env(C.Structure):
@@ -47,13 +52,13 @@ class Env(C.Structure):
 class Camera(C.Structure):
     _fields_ = [("pos", f32*3), ("rot", f32*9), ("res_x", u32), ("res_y", u32), ("plane_dist", f32),
                 ("ratio", f32), ("pixel_size_x", f32), ("filter_type", i32), ("filter_bin_size", f32),
-                ("filter_cdf", f32*32)]
+                ("filter_cdf", f32*32), ("medium", i32)]
 
 
 class Settings(C.Structure):
     _fields_ = [("min_bounces", i32), ("max_bounces", i32), ("enable_light_sampling", i32),
                 ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("use_sobol", i32),
-                ("adaptive_sampling", i32)]
+                ("adaptive_sampling", i32), ("enable_volume_light_sampling", i32)]
 
 
 class Light(C.Structure):
@@ -72,13 +77,14 @@ class Instances(C.Structure):
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", u32), ("camera", Camera), ("settings", Settings),
                 ("n_tris", u32), ("tri_pos", pf32), ("tri_normal", pf32), ("tri_uv", pf32), ("tri_bsdf", pi32),
-                ("tri_smooth", pu8),
+                ("tri_smooth", pu8), ("tri_media", C.POINTER(C.c_int16)),
                 ("n_quads", u32), ("quads", C.POINTER(Quad)),
                 ("n_cubes", u32), ("cubes", C.POINTER(Cube)),
                 ("n_bsdfs", u32), ("bsdfs", C.POINTER(Bsdf)),
                 ("n_textures", u32), ("textures", C.POINTER(Texture)),
                 ("n_bitmaps", u32), ("bitmaps", C.POINTER(Bitmap)),
                 ("n_lights", u32), ("lights", C.POINTER(Light)),
+                ("n_media", u32), ("media", C.POINTER(Medium)),
                 ("env", Env),
                 ("n_master_tris", u32), ("n_master_quads", u32), ("n_master_cubes", u32),
                 ("n_instance_sets", u32), ("instance_sets", C.POINTER(Instances)),

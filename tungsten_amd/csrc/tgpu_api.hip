@@ -201,6 +201,8 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
             if (l.index < 0 || uint32_t(l.index) >= s->n_quads || s->quads[l.index].emission_tex < 0) { fail(ctx, "light %u: bad quad", i); return TGPU_ERR_INVALID; }
         } else { fail(ctx, "light %u has unknown kind", i); return TGPU_ERR_INVALID; }
     }
+    if (s->n_media) { fail(ctx, "participating media: GPU path not built yet"); return TGPU_ERR_UNSUPPORTED; } // TEMP(a26)
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type == TGPU_BSDF_ROUGH_DIELECTRIC) { fail(ctx, "rough_dielectric: GPU path not built yet"); return TGPU_ERR_UNSUPPORTED; } // TEMP(a26)
     // "instances" primitives
     if (s->n_instance_sets > 255) { fail(ctx, "more than 255 'instances' primitives"); return TGPU_ERR_UNSUPPORTED; }
     if (s->n_instance_sets && !s->instance_sets) { fail(ctx, "instance_sets missing"); return TGPU_ERR_INVALID; }

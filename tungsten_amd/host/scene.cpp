@@ -526,11 +526,71 @@ int Scene::parseBsdf(const Json &v)
             float avg = sum*(1.0f/3.0f);
             b.avg_transmittance = std::exp(-2.0f*avg);
         }
+    } else if (type == "rough_dielectric") { // RoughDielectricBsdf.cpp:19-42
+        b.type = TGPU_BSDF_ROUGH_DIELECTRIC;
+        b.ior = 1.5f;
+        v.getField("ior", b.ior);
+        std::string dist = "ggx";
+        v.getField("distribution", dist);
+        if (dist == "beckmann") b.distribution = TGPU_DIST_BECKMANN;
+        else if (dist == "phong") b.distribution = TGPU_DIST_PHONG;
+        else if (dist == "ggx") b.distribution = TGPU_DIST_GGX;
+        else throw JsonLoadException("Unknown microfacet distribution '" + dist + "'");
+        bool enableT = true;
+        v.getField("enable_refraction", enableT);
+        b.enable_refraction = enableT ? 1 : 0;
+        if (v["roughness"])
+            b.roughness_tex = fetchTexture(v["roughness"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 0.1;
+            b.roughness_tex = fetchTexture(r, true);
+        }
     } else {
         throw std::runtime_error("BSDF type '" + type + "' is outside the hot-path scope (SURVEY.md section 2 row 8)");
     }
     _bsdfs.push_back(b);
     return int(_bsdfs.size()) - 1;
+}
+
+int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp:19-29
+{
+    std::string type = v["type"].asString();
+    if (type != "homogeneous") throw std::runtime_error("Medium type '" + type + "' is outside the hot-path scope (SURVEY.md section 8 a26: homogeneous only)");
+    if (const Json &ph = v["phase_function"]) {
+        std::string pt = ph.isObject() ? ph["type"].asString() : ph.asString();
+        if (pt != "isotropic") throw std::runtime_error("phase function '" + pt + "' is outside the hot-path scope");
+    }
+    if (const Json &tr = v["transmittance"]) {
+        std::string tt = tr.isObject() ? tr["type"].asString() : tr.asString();
+        if (tt != "exponential") throw std::runtime_error("transmittance '" + tt + "' is outside the hot-path scope");
+    }
+    float sa[3] = {0, 0, 0}, ss[3] = {0, 0, 0}, density = 1.0f;
+    v.getVec("sigma_a", sa, 3);
+    v.getVec("sigma_s", ss, 3);
+    v.getField("density", density);
+    tgpu_medium m{};
+    m.max_bounce = 1024;
+    v.getField("max_bounces", m.max_bounce);
+    for (int i = 0; i < 3; ++i) {
+        m.sigma_a[i] = sa[i]*density;
+        m.sigma_s[i] = ss[i]*density;
+        m.sigma_t[i] = m.sigma_a[i] + m.sigma_s[i];
+    }
+    m.absorption_only = m.sigma_s[0] == 0.0f && m.sigma_s[1] == 0.0f && m.sigma_s[2] == 0.0f;
+    _media.push_back(m);
+    return int(_media.size()) - 1;
+}
+
+int Scene::fetchMedium(const Json &v) // Scene.cpp:105-108
+{
+    if (v.isString()) {
+        for (auto &kv : _namedMedia)
+            if (kv.first == v.asString()) return kv.second;
+        throw JsonLoadException("Unable to find an object with name '" + v.asString() + "'");
+    } else if (v.isObject()) {
+        return parseMedium(v);
+    }
+    throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
 }
 
 int Scene::fetchBsdf(const Json &v) // Scene.cpp:83-93,120-125
@@ -660,23 +720,28 @@ void Scene::parsePrimitive(const Json &v)
     Mat4 transform;
     if (v["transform"]) transform = parseTransform(v["transform"]);
     if (v["power"]) throw std::runtime_error("'power' emitters are outside the hot-path scope");
-    if (v["int_medium"] || v["ext_medium"]) throw std::runtime_error("participating media are outside the round-1 scope");
+    int intMedium = -1, extMedium = -1;
+    if (v["int_medium"]) intMedium = fetchMedium(v["int_medium"]);
+    if (v["ext_medium"]) extMedium = fetchMedium(v["ext_medium"]);
     int emissionTex = -1;
     if (v["emission"]) emissionTex = fetchTexture(v["emission"], false);
 
     if (type == "mesh") {
         meshes.push_back(parseMesh(v, transform, emissionTex));
+        meshes.back().intMedium = intMedium;
+        meshes.back().extMedium = extMedium;
         _primOrder.push_back({PrimMesh, int(meshes.size()) - 1});
     } else if (type == "quad") {
-        QuadSrc q{transform, fetchBsdf(v["bsdf"]), emissionTex};
+        QuadSrc q{transform, fetchBsdf(v["bsdf"]), emissionTex, intMedium, extMedium};
         _quadSrc.push_back(q);
         _primOrder.push_back({PrimQuad, int(_quadSrc.size()) - 1});
     } else if (type == "cube") {
-        CubeSrc c{transform, fetchBsdf(v["bsdf"]), emissionTex};
+        CubeSrc c{transform, fetchBsdf(v["bsdf"]), emissionTex, intMedium, extMedium};
         _cubeSrc.push_back(c);
         _primOrder.push_back({PrimCube, int(_cubeSrc.size()) - 1});
     } else if (type == "instances") { // Instance::fromJson (Instance.cpp:60-93)
         if (emissionTex >= 0) throw std::runtime_error("emissive 'instances' primitives are outside the hot-path scope");
+        if (intMedium >= 0 || extMedium >= 0) throw std::runtime_error("media on 'instances' primitives are outside the hot-path scope");
         if (v["instancesB"]) throw std::runtime_error("'instancesB'/'ratio' blending is outside the hot-path scope");
         InstanceSrc src;
         src.transform = transform;
@@ -686,11 +751,11 @@ void Scene::parsePrimitive(const Json &v)
             std::string mt = m["type"].asString();
             Mat4 mtf;
             if (m["transform"]) mtf = parseTransform(m["transform"]);
-            if (m["int_medium"] || m["ext_medium"]) throw std::runtime_error("participating media are outside the round-1 scope");
+            if (m["int_medium"] || m["ext_medium"]) throw std::runtime_error("media on instance masters are outside the hot-path scope");
             MasterSrc ms{};
             if (mt == "mesh") { ms.kind = TGPU_MASTER_MESH; ms.mesh = parseMesh(m, mtf, -1); }
-            else if (mt == "quad") { ms.kind = TGPU_MASTER_QUAD; ms.quad = QuadSrc{mtf, fetchBsdf(m["bsdf"]), -1}; }
-            else if (mt == "cube") { ms.kind = TGPU_MASTER_CUBE; ms.cube = CubeSrc{mtf, fetchBsdf(m["bsdf"]), -1}; }
+            else if (mt == "quad") { ms.kind = TGPU_MASTER_QUAD; ms.quad = QuadSrc{mtf, fetchBsdf(m["bsdf"]), -1, -1, -1}; }
+            else if (mt == "cube") { ms.kind = TGPU_MASTER_CUBE; ms.cube = CubeSrc{mtf, fetchBsdf(m["bsdf"]), -1, -1, -1}; }
             else throw std::runtime_error("instance master of type '" + mt + "' is outside the hot-path scope");
             src.masters.push_back(std::move(ms));
         }
@@ -719,6 +784,7 @@ void Scene::parsePrimitive(const Json &v)
         _instanceSrc.push_back(std::move(src));
     } else if (type == "infinite_sphere") {
         if (_envSrc.present) throw std::runtime_error("more than one infinite_sphere is outside the hot-path scope");
+        if (intMedium >= 0 || extMedium >= 0) throw std::runtime_error("media on infinite_sphere are outside the hot-path scope");
         _envSrc.present = true;
         _envSrc.transform = transform;
         _envSrc.emissionTex = emissionTex;
@@ -741,7 +807,7 @@ void Scene::parseCamera(const Json &v)
         resX = uint32_t(res[0]);
         resY = uint32_t(res[1]);
     }
-    if (v["medium"]) throw std::runtime_error("camera media are outside the round-1 scope");
+    if (v["medium"]) _cameraMedium = fetchMedium(v["medium"]);
     v.getField("reconstruction_filter", filterName);
     if (v["transform"]) camTransform = parseTransform(v["transform"]);
     v.getField("fov", fovDeg);
@@ -754,7 +820,12 @@ Scene Scene::load(const std::string &jsonPath)
     s.sceneJsonText = readFile(jsonPath);
     Json root = Json::parse(s.sceneJsonText);
 
-    if (root["media"] && root["media"].size() > 0) throw std::runtime_error("participating media are outside the round-1 scope");
+    const Json &media = root["media"];
+    for (size_t i = 0; media && i < media.size(); ++i) {
+        int id = s.parseMedium(media[i]);
+        std::string name;
+        if (media[i].getField("name", name)) s._namedMedia.emplace_back(name, id);
+    }
     const Json &bsdfs = root["bsdfs"];
     for (size_t i = 0; bsdfs && i < bsdfs.size(); ++i) {
         int id = s.parseBsdf(bsdfs[i]);
@@ -771,6 +842,7 @@ Scene Scene::load(const std::string &jsonPath)
     s.settings.enable_light_sampling = 1;
     s.settings.enable_two_sided_shading = 1;
     s.settings.enable_consistency_checks = 0;
+    s.settings.enable_volume_light_sampling = 1;
     if (const Json &it = root["integrator"]) {
         std::string type = "path_tracer";
         it.getField("type", type);
@@ -782,8 +854,12 @@ Scene Scene::load(const std::string &jsonPath)
         if (it.getField("enable_light_sampling", b)) s.settings.enable_light_sampling = b;
         if (it.getField("enable_two_sided_shading", b)) s.settings.enable_two_sided_shading = b;
         if (it.getField("enable_consistency_checks", b)) s.settings.enable_consistency_checks = b;
+        s.settings.enable_volume_light_sampling = 1;
+        if (it.getField("enable_volume_light_sampling", b)) s.settings.enable_volume_light_sampling = b;
         bool flag = true;
         if (it.getField("include_surfaces", flag) && !flag) throw std::runtime_error("include_surfaces=false is outside the hot-path scope");
+        flag = true;
+        if (it.getField("low_order_scattering", flag) && !flag) throw std::runtime_error("low_order_scattering=false is outside the hot-path scope");
     }
     if (const Json &r = root["renderer"]) {
         r.getField("output_file", s.renderer.outputFile);
@@ -873,6 +949,8 @@ void Scene::bakeMesh(const MeshData &m, float *boundsMin, float *boundsMax)
         }
         _triBsdf.push_back(m.bsdfs[size_t(material)]);
         _triSmooth.push_back(m.smooth ? 1 : 0);
+        _triMedia.push_back(int16_t(m.intMedium));
+        _triMedia.push_back(int16_t(m.extMedium));
     }
 }
 
@@ -897,6 +975,8 @@ tgpu_quad Scene::bakeQuad(const QuadSrc &q) const
     o.inv_uv_sq[1] = 1.0f/edge1.lengthSq();
     o.bsdf = q.bsdf;
     o.emission_tex = q.emissionTex;
+    o.int_medium = q.intMedium;
+    o.ext_medium = q.extMedium;
     return o;
 }
 
@@ -912,6 +992,8 @@ tgpu_cube Scene::bakeCube(const CubeSrc &c) const
     for (int i = 0; i < 3; ++i) { o.pos[i] = p[i]; o.scale[i] = sc[i]; }
     o.bsdf = c.bsdf;
     o.emission_tex = c.emissionTex;
+    o.int_medium = c.intMedium;
+    o.ext_medium = c.extMedium;
     return o;
 }
 
@@ -958,7 +1040,7 @@ void Scene::flatten()
     _desc.settings.adaptive_sampling = renderer.useAdaptiveSampling ? 1 : 0;
 
     // ---- meshes: world-space bake (TriangleMesh.cpp:524-552) ----
-    _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear();
+    _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear(); _triMedia.clear();
     for (const MeshData &m : meshes) bakeMesh(m, nullptr, nullptr);
     _desc.n_tris = uint32_t(_triBsdf.size());
 
@@ -1043,6 +1125,10 @@ void Scene::flatten()
     _desc.tri_uv = _triUv.data();
     _desc.tri_bsdf = _triBsdf.data();
     _desc.tri_smooth = _triSmooth.data();
+    _desc.n_media = uint32_t(_media.size());
+    _desc.media = _media.data();
+    _desc.tri_media = _media.empty() ? nullptr : _triMedia.data();
+    cam.medium = _cameraMedium;
     _desc.quads = _quads.data();
     _desc.cubes = _cubes.data();
 

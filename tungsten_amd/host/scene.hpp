@@ -37,6 +37,7 @@ struct MeshData {
     Mat4 transform;
     bool smooth = false;
     std::vector<int> bsdfs;
+    int intMedium = -1, extMedium = -1; // Primitive::_intMedium / _extMedium
 };
 
 class Scene {
@@ -77,8 +78,14 @@ private:
     void parsePrimitive(const Json &v);
     void parseCamera(const Json &v);
 
-    struct QuadSrc { Mat4 transform; int bsdf; int emissionTex; };
-    struct CubeSrc { Mat4 transform; int bsdf; int emissionTex; };
+    struct QuadSrc { Mat4 transform; int bsdf; int emissionTex; int intMedium = -1, extMedium = -1; };
+    struct CubeSrc { Mat4 transform; int bsdf; int emissionTex; int intMedium = -1, extMedium = -1; };
+    int fetchMedium(const Json &v);
+    int parseMedium(const Json &v);
+    std::vector<std::pair<std::string, int>> _namedMedia;
+    std::vector<tgpu_medium> _media;
+    std::vector<int16_t> _triMedia;
+    int _cameraMedium = -1;
     // "instances" primitive (primitives/Instance.cpp:60-93): masters are private primitives of the set
     struct MasterSrc { int kind; MeshData mesh; QuadSrc quad; CubeSrc cube; };
     struct InstanceSrc { Mat4 transform; std::vector<MasterSrc> masters; std::vector<float> pos, rot; std::vector<uint8_t> id; };

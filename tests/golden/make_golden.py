@@ -36,6 +36,7 @@ FIXTURES = [
     # config 5: rough_dielectric boundary + homogeneous medium inside (volume scattering / absorption only)
     ("c5_128x72_16spp", "materialtest/c5.json", (128, 72), 16),
     ("c5_absorb_128x72_8spp", "materialtest/c5_absorb.json", (128, 72), 8),
+    ("cornell_fog_96x54_8spp", "cornell-box/scene_fog.json", (96, 54), 8),   # camera medium + quad light: finite-segment transmittance
     ("c1_adaptive_128x72_64spp", "materialtest/materialtest.json", (128, 72), 64, True),
 ]
 

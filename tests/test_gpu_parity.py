@@ -36,6 +36,10 @@ def assert_bit_exact(got, ref, what):
     ("instances/inst_cubes.json", (128, 72), 8, 8),       # cube + quad masters, 16 instances, env light
     ("instances/inst_many.json", (96, 54), 4, 4),         # 294 instances: binned-SAH levels
     ("instances/inst_mesh.json", (96, 54), 8, 8),         # mesh masters (own BVH4 each) + quad light (finite end cap)
+    # config 5 (a26): rough_dielectric + homogeneous media (volume list, fmath exp, volume NEE)
+    ("materialtest/c5.json", (128, 72), 16, 8),
+    ("materialtest/c5_absorb.json", (128, 72), 8, 8),
+    ("cornell-box/scene_fog.json", (96, 54), 16, 16),      # camera medium + quad light
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)

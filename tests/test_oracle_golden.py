@@ -22,6 +22,7 @@ CASES = [
     # config 5 (a26): rough_dielectric boundary, homogeneous medium inside (distance sampling, volume NEE, fmath exp)
     ("c5_128x72_16spp", "materialtest/c5.json", (128, 72), 16),
     ("c5_absorb_128x72_8spp", "materialtest/c5_absorb.json", (128, 72), 8),  # absorption only + beckmann glass
+    ("cornell_fog_96x54_8spp", "cornell-box/scene_fog.json", (96, 54), 8),   # camera medium, quad light: finite transmittance
 ]
 
 

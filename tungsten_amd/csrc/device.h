@@ -129,6 +129,10 @@ struct DScene {
     const uint16_t *envGuideMarginal;    // dist_h entries
     const uint16_t *envGuideConditional; // dist_h x dist_w entries
     const DInstSet *instSets; uint32_t nInstSets;
+    // participating media (media/HomogeneousMedium.cpp) and the table of fmath::exp_ps (thirdparty/fmath/fmath.hpp:90-127)
+    const tgpu_medium *media; uint32_t nMedia;
+    const uint32_t *expTable; // 1024 mantissas of 2^(i/1024)
+    float expA, expB;         // 1024/logf(2), logf(2)/1024
 };
 
 // prim id encoding shared with the C ABI: kind << 30 | index; 0xFFFFFFFF = miss
@@ -176,6 +180,7 @@ struct Sampler {
         pcgNext();
     }
     TG_DEV bool nextBoolean(float pTrue) { return pcg1D() < pTrue; }
+    TG_DEV int nextDiscrete(int numChoices) { return int(pcg1D()*float(numChoices)); } // SobolPathSampler.hpp:62-65
     TG_DEV float next1D()
     {
         if (!sobol || dimension >= 1024u) return pcg1D();
@@ -521,7 +526,79 @@ TG_DEV uint32_t baseLobes(int type)
 TG_DEV uint32_t bsdfLobes(const DScene &sc, const tgpu_bsdf &d)
 {
     if (d.type == TGPU_BSDF_SMOOTH_COAT) return SpecularReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);
+    if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) // RoughDielectricBsdf.cpp:38-41
+        return d.enable_refraction ? uint32_t(GlossyReflectionLobe | GlossyTransmissionLobe) : uint32_t(GlossyReflectionLobe);
     return baseLobes(d.type);
+}
+
+// ---- RoughDielectricBsdf (bsdfs/RoughDielectricBsdf.cpp:55-280) --------------------------------------
+TG_DEV float sgnE(float v) { return v < 0.0f ? -1.0f : 1.0f; } // :13-17
+// Bsdf::eval/sample(event, adjoint = false) scale by sqr(eta(event)) (Bsdf.hpp:71-97, RoughDielectricBsdf.cpp:266-272)
+TG_DEV float dielectricEtaSq(float ior, const V3 &wi, const V3 &wo)
+{
+    float eta = wi.z*wo.z >= 0.0f ? 1.0f : (wi.z < 0.0f ? ior : 1.0f/ior);
+    return eta*eta;
+}
+TG_DEV V3 dielectricEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{   // evalBase :133-164, eval :242-249
+    bool sampleR = (requested & GlossyReflectionLobe) != 0;
+    bool sampleT = (requested & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+    float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+    float wiDotN = wi.z, woDotN = wo.z;
+    bool reflect = wiDotN*woDotN >= 0.0f;
+    if ((reflect && !sampleR) || (!reflect && !sampleT)) return V3(0.0f);
+    float alpha = roughnessToAlpha(roughness);
+    float eta = wiDotN < 0.0f ? d.ior : 1.0f/d.ior;
+    V3 m;
+    if (reflect) m = sgnE(wiDotN)*(wi + wo).normalized();
+    else m = -(wi*eta + wo).normalized();
+    float wiDotM = wi.dot(m), woDotM = wo.dot(m);
+    float cosThetaT;
+    float F = dielectricReflectance(1.0f/d.ior, wiDotM, cosThetaT);
+    float G = mfG(d.distribution, alpha, wi, wo, m);
+    float D = mfD(d.distribution, alpha, m);
+    V3 f;
+    if (reflect) {
+        float fr = (F*G*D*0.25f)/__builtin_fabsf(wiDotN);
+        f = V3(fr);
+    } else {
+        float q = eta*wiDotM + woDotM;
+        float fs = __builtin_fabsf(wiDotM*woDotM)*(1.0f - F)*G*D/((q*q)*__builtin_fabsf(wiDotN));
+        f = V3(fs);
+    }
+    f = f*texEval(sc, d.albedo_tex, uvx, uvy);
+    f *= dielectricEtaSq(d.ior, wi, wo);
+    return f;
+}
+TG_DEV float dielectricPdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{   // pdfBase :198-234
+    bool sampleR = (requested & GlossyReflectionLobe) != 0;
+    bool sampleT = (requested & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+    float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+    float wiDotN = wi.z, woDotN = wo.z;
+    bool reflect = wiDotN*woDotN >= 0.0f;
+    if ((reflect && !sampleR) || (!reflect && !sampleT)) return 0.0f;
+    float sampleRoughness = (1.2f - 0.2f*__builtin_sqrtf(__builtin_fabsf(wiDotN)))*roughness;
+    float sampleAlpha = roughnessToAlpha(sampleRoughness);
+    float eta = wiDotN < 0.0f ? d.ior : 1.0f/d.ior;
+    V3 m;
+    if (reflect) m = sgnE(wiDotN)*(wi + wo).normalized();
+    else m = -(wi*eta + wo).normalized();
+    float wiDotM = wi.dot(m), woDotM = wo.dot(m);
+    float cosThetaT;
+    float F = dielectricReflectance(1.0f/d.ior, wiDotM, cosThetaT);
+    float pm = mfPdf(d.distribution, sampleAlpha, m);
+    float pdf;
+    if (reflect) {
+        pdf = pm*0.25f/__builtin_fabsf(wiDotM);
+    } else {
+        float q = eta*wiDotM + woDotM;
+        pdf = pm*__builtin_fabsf(woDotM)/(q*q);
+    }
+    if (sampleR && sampleT) {
+        if (reflect) pdf *= F; else pdf *= 1.0f - F;
+    }
+    return pdf;
 }
 
 // Lambert (bsdfs/LambertBsdf.cpp:27-68) and RoughConductor (bsdfs/RoughConductorBsdf.cpp:60-143):
@@ -609,10 +686,68 @@ TG_DEV bool baseSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &
     return false;
 }
 
+TG_DEV bool dielectricSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{   // sampleBase :55-131, sample :232-240
+    bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+    bool sampleT = (e.requestedLobe & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+    float roughness = texEval(sc, d.roughness_tex, e.uvx, e.uvy).x;
+    const float ior = d.ior;
+    float wiDotN = e.wi.z;
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    float sampleRoughness = (1.2f - 0.2f*__builtin_sqrtf(__builtin_fabsf(wiDotN)))*roughness;
+    float alpha = roughnessToAlpha(roughness);
+    float sampleAlpha = roughnessToAlpha(sampleRoughness);
+    float xix = s.next1D(), xiy = s.next1D();
+    V3 m = mfSample(d.distribution, sampleAlpha, xix, xiy);
+    float pm = mfPdf(d.distribution, sampleAlpha, m);
+    if (pm < 1e-10f) return false;
+    float wiDotM = e.wi.dot(m);
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+    float etaM = wiDotM < 0.0f ? ior : 1.0f/ior;
+    bool reflect;
+    if (sampleR && sampleT) {
+        reflect = s.nextBoolean(F);
+    } else if (sampleT) {
+        if (F == 1.0f) return false;
+        reflect = false;
+    } else if (sampleR) {
+        reflect = true;
+    } else {
+        return false;
+    }
+    if (reflect) e.wo = 2.0f*wiDotM*m - e.wi;
+    else e.wo = (etaM*wiDotM - sgnE(wiDotM)*cosThetaT)*m - etaM*e.wi;
+    float woDotN = e.wo.z;
+    bool reflected = wiDotN*woDotN > 0.0f;
+    if (reflected != reflect) return false;
+    float woDotM = e.wo.dot(m);
+    float G = mfG(d.distribution, alpha, e.wi, e.wo, m);
+    float D = mfD(d.distribution, alpha, m);
+    e.weight = V3(__builtin_fabsf(wiDotM)*G*D/(__builtin_fabsf(wiDotN)*pm));
+    if (reflect) {
+        e.pdf = pm*0.25f/__builtin_fabsf(wiDotM);
+        e.sampledLobe = GlossyReflectionLobe;
+    } else {
+        float q = eta*wiDotM + woDotM;
+        e.pdf = pm*__builtin_fabsf(woDotM)/(q*q);
+        e.sampledLobe = GlossyTransmissionLobe;
+    }
+    if (sampleR && sampleT) {
+        if (reflect) e.pdf *= F; else e.pdf *= 1.0f - F;
+    } else {
+        if (reflect) e.weight *= F; else e.weight *= 1.0f - F;
+    }
+    e.weight *= texEval(sc, d.albedo_tex, e.uvx, e.uvy);
+    e.weight *= dielectricEtaSq(ior, e.wi, e.wo);
+    return true;
+}
+
 TG_DEV V3 expV3(const V3 &a) { return V3(tgpu_expf(a.x), tgpu_expf(a.y), tgpu_expf(a.z)); }
 
 TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
+    if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:146-178
     if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
@@ -640,6 +775,7 @@ TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 
 TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
+    if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return basePdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:180-215
     if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
@@ -671,6 +807,7 @@ TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 
 TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
+    if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricSample(sc, d, e, s);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseSample(sc, d, e, s);
     // bsdfs/SmoothCoatBsdf.cpp:41-100
     if (e.wi.z <= 0.0f) return false;

@@ -19,16 +19,18 @@
 namespace tg {
 
 // ---- path-state streams ---------------------------------------------------------------------
-// Slot lists: two sets (ping-pong) of 1 + TGPU_BSDF_NUM_CLASSES lists.  List 0 holds the slots whose ray
-// escaped (and freshly started / just-died slots), list 1 + c the slots whose hit has BSDF class c.
+// Slot lists: two sets (ping-pong) of 2 + TGPU_BSDF_NUM_CLASSES lists.  List 0 holds the slots whose ray
+// escaped (and freshly started / just-died slots), list 1 + c the slots whose hit has BSDF class c, the last
+// list the slots whose ray runs inside a participating medium (distance sampling comes before the surface).
 // The extend kernel reads the concatenation of the current set and writes the other set; every other
 // kernel works in place on the set extend just wrote, so a slot keeps its list entry while its path is
 // retired and the next sample is started in it.
-#define TG_LISTS (1 + TGPU_BSDF_NUM_CLASSES)
+#define TG_LISTS (2 + TGPU_BSDF_NUM_CLASSES)
+#define TG_CLASS_VOLUME TGPU_BSDF_NUM_CLASSES /* paths whose ray travels inside a participating medium (hit or miss) */
 enum { CNT_LIST0 = 0 /* 2 x TG_LISTS list lengths */, CNT_HEAD_EXT = 2*TG_LISTS, CNT_HEAD_SHADOW = CNT_HEAD_EXT + 1,
        CNT_REGEN = CNT_HEAD_EXT + 2 /* samples claimed this iteration */,
        CNT_FREE = CNT_HEAD_EXT + 3 /* persistent: length of the free-slot list */,
-       CNT_JOB_DONE0 = CNT_HEAD_EXT + 4 /* TG_RING persistent per-job retire counters */, CNT_TOTAL = 32 };
+       CNT_JOB_DONE0 = CNT_HEAD_EXT + 4 /* TG_RING persistent per-job retire counters */, CNT_TOTAL = 40 };
 // Result-ring slices (= jobs that may be in flight).  A job can only be folded into the framebuffer
 // once its slowest path has ended (~max_bounces iterations after its last sample started), and during
 // that time the pool keeps starting samples of later jobs: the ring must hold ~26 x pool size samples.
@@ -61,6 +63,7 @@ struct DState {
     float4 *rayO;   // origin.xyz, tnear
     float4 *rayD;   // dir.xyz, tfar
     float4 *hit;                // t, u, v, bits(prim)
+    uint32_t *med;              // medium state: [7:0] medium + 1, [8] MediumState::firstScatter, [31:9] MediumState::bounce; only with media
     uint32_t *hitInst;          // instance of the hit (set << 24 | index) or INST_NONE; only with "instances" in the scene
     float4 *tp;     // throughput.xyz, bits(flags)
     float4 *em;     // emission (radiance so far).xyz, bits(Sobol scramble)
@@ -245,6 +248,7 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
     st.em[slot] = mk4u(V3(0.0f), smp.scramble);
     st.samp[slot] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
     st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
+    if (sc.nMedia) st.med[slot] = uint32_t(sc.cam.medium + 1) | (1u << 8); // cam().medium(), MediumState::reset()
 }
 
 // Retire + regenerate IN PLACE over every entry of the set extend just wrote:
@@ -767,7 +771,10 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, u
                         else stStream(&st.hitInst[path], inst);
                     }
                     stStream(&st.hit[path], make_float4(tfar, u, v, __uint_as_float(prim)));
-                    if (!RAW) cls = hitClass(sc, prim);
+                    if (!RAW) {
+                        cls = hitClass(sc, prim);
+                        if (sc.nMedia && (st.med[path] & 0xFFu)) cls = TG_CLASS_VOLUME;
+                    }
                 }
             }
             p0 = b == 0 ? path : p0; p1 = b == 1 ? path : p1; p2 = b == 2 ? path : p2; p3 = b == 3 ? path : p3;
@@ -846,7 +853,7 @@ __global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
 // =================================================================================================
 // K3 shade
 // =================================================================================================
-struct HitInfo { V3 Ng, Ns, p; float uvx, uvy; int bsdf; bool emissive; int emissionTex; bool backSide; };
+struct HitInfo { V3 Ng, Ns, p; float uvx, uvy; int bsdf; bool emissive; int emissionTex; bool backSide; int intMedium, extMedium; };
 
 TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 &D, float t, float u, float v, HitInfo &info)
 {
@@ -854,6 +861,7 @@ TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 
     info.emissive = false;
     info.emissionTex = -1;
     info.backSide = false;
+    info.intMedium = info.extMedium = -1;
     if (kind == KIND_TRI) { // primitives/TriangleMesh.cpp:344-355, :81-106
         const float4 *s = sc.triShade + size_t(idx)*5;
         float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4];
@@ -870,6 +878,9 @@ TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 
         info.uvx = w0*s2.y + u*s2.w + v*s3.y;
         info.uvy = w0*s2.z + u*s3.x + v*s3.z;
         info.bsdf = int(bits & 0x7FFFFFFFu);
+        const uint32_t mb = __float_as_uint(s4.w); // (int_medium + 1) << 16 | (ext_medium + 1)
+        info.intMedium = int(mb >> 16) - 1;
+        info.extMedium = int(mb & 0xFFFFu) - 1;
     } else if (kind == KIND_QUAD) { // primitives/Quad.cpp:71-98,123-131
         const tgpu_quad &q = sc.quads[idx];
         info.p = O + t*D;
@@ -880,6 +891,8 @@ TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 
         info.emissive = q.emission_tex >= 0;
         info.emissionTex = q.emission_tex;
         info.backSide = D.dot(V3(q.normal)) >= 0.0f;
+        info.intMedium = q.int_medium;
+        info.extMedium = q.ext_medium;
     } else { // primitives/Cube.cpp:157-170
         const tgpu_cube &cb = sc.cubes[idx];
         info.p = O + D*t;
@@ -898,6 +911,8 @@ TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 
         info.uvx = uvw.comp((dim + 1) % 3);
         info.uvy = uvw.comp((dim + 2) % 3);
         info.bsdf = cb.bsdf;
+        info.intMedium = cb.int_medium;
+        info.extMedium = cb.ext_medium;
     }
 }
 
@@ -921,6 +936,7 @@ TG_DEV void applyInstance(const DScene &sc, uint32_t inst, uint32_t prim, const 
     info.p = pos + quatRotate(rq, info.p);
     info.emissive = false; // the hit primitive is the Instance, whose masters' emission is never consulted
     info.emissionTex = -1;
+    info.intMedium = info.extMedium = -1; // ... nor their media
 }
 
 // light.directPdf for the BSDF-sampled NEE ray (InfiniteSphere.cpp:218-229, Quad.cpp:216-223)
@@ -1006,9 +1022,273 @@ TG_DEV int chooseLight(const DScene &sc, const V3 &p, Sampler &smp, float &weigh
     return result;
 }
 
+// ---- participating media ----------------------------------------------------------------------------
+// FastMath::exp(Vec3f) = fmath::exp_ps on (x, y, z, 0) (math/FastMath.hpp:23-27, thirdparty/fmath/fmath.hpp:320-363):
+// clamp to +-88 (all lanes, once any lane is out of range), r = round-to-nearest-even(x*1024/ln 2),
+// 2^(r/1024) from a 1024-entry mantissa table and the exponent bits, times the first-order term 1 + (x - r*ln2/1024)
+TG_DEV V3 fastExp(const DScene &sc, const V3 &v)
+{
+    float x[3] = {v.x, v.y, v.z};
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (int32_t(__float_as_uint(x[i]) & 0x7FFFFFFFu) > int32_t(0x42B00000)) over = true;
+    float out[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float xi = x[i];
+        if (over) {
+            xi = xi < 88.0f ? xi : 88.0f;   // _mm_min_ps(x, maxX)
+            xi = xi > -88.0f ? xi : -88.0f; // _mm_max_ps(x, minX)
+        }
+        int32_t r = __float2int_rn(xi*sc.expA);
+        float t = xi - float(r)*sc.expB;
+        t = t + 1.0f;
+        uint32_t u = ((uint32_t(r) + (127u << 10)) >> 10) << 23;
+        out[i] = t*__uint_as_float(sc.expTable[uint32_t(r) & 1023u] | u);
+    }
+    return V3(out[0], out[1], out[2]);
+}
+
+// HomogeneousMedium::transmittance (HomogeneousMedium.cpp:110-117) over a shadow segment that ends at farT; no medium: 1
+TG_DEV V3 neeTransmittance(const DScene &sc, int medium, float farT)
+{
+    if (medium < 0) return V3(1.0f);
+    if (farT == TG_INF) return V3(0.0f);
+    return fastExp(sc, -(V3(sc.media[medium].sigma_t)*farT));
+}
+
+template <int CLASS, bool MEDIA>
+TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium = false);
+TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
+
+// One step of a path whose ray runs inside a medium: PathTracer.cpp:54-63 (HomogeneousMedium::sampleDistance,
+// HomogeneousMedium.cpp:65-108), then either the surface / miss code with the attenuated throughput or
+// TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect (:323-381, :402-414, :470-481) and the loop
+// tail of traceSample (PathTracer.cpp:108-126).  The NEE rays go through the ordinary shadow kernel: their
+// transmittance is known here (the segment length is the light's distance) and folded into the contributions.
+TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
+{
+    const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
+    float4 tpw = st.tp[path];
+    uint32_t flags = __float_as_uint(tpw.w);
+    if (flagsEnd(flags) != END_ALIVE) { st.shFlag[path] = 0u; return; }
+    float4 ro = st.rayO[path], rd = st.rayD[path], hw = st.hit[path], emw = st.em[path];
+    uint4 sw = st.samp[path];
+    V3 O = xyz(ro), D = xyz(rd), tp = xyz(tpw), em = xyz(emw);
+    int bounce = flagsBounce(flags);
+    bool wasSpecular = flagsSpecular(flags);
+    if (bounce > 0 && isnanf_(tp.sum() + em.sum())) { // PathTracer.cpp:121-122 for the previous vertex
+        st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, END_ZERO));
+        st.shFlag[path] = 0u;
+        return;
+    }
+    Sampler smp;
+    smp.matrices = sc.sobol;
+    smp.sobol = sc.settings.use_sobol;
+    smp.dimension = sw.x;
+    smp.pcg = (uint64_t(sw.z) << 32) | uint64_t(sw.y);
+    smp.scramble = __float_as_uint(emw.w);
+    smp.index = sw.w;
+
+    const uint32_t med = st.med[path];
+    const int medium = int(med & 0xFFu) - 1;
+    bool firstScatter = (med >> 8) & 1u;
+    uint32_t stateBounce = med >> 9;
+    const tgpu_medium &m = sc.media[medium];
+    const V3 sigmaT(m.sigma_t), sigmaS(m.sigma_s);
+    const bool didHit = __float_as_uint(hw.w) != PRIM_MISS;
+    const float maxT = didHit ? hw.x : TG_INF;
+
+    // ---- sampleDistance ----
+    bool ok = true, exited = true;
+    float t = maxT;
+    V3 weight(1.0f);
+    if (int(stateBounce) > m.max_bounce) {
+        ok = false;
+    } else if (m.absorption_only) {
+        if (maxT == TG_INF) ok = false;
+        else weight = fastExp(sc, -(t*sigmaT));
+    } else {
+        int component = smp.nextDiscrete(3);
+        float sigmaTc = component == 0 ? sigmaT.x : (component == 1 ? sigmaT.y : sigmaT.z);
+        float ts = -tgpu_logf(1.0f - smp.next1D())/sigmaTc; // ExponentialTransmittance::sampleSurface/sampleMedium
+        t = fmin2(ts, maxT);
+        exited = ts >= maxT;
+        V3 tau = t*sigmaT;
+        weight = fastExp(sc, -tau);
+        float pdf;
+        if (exited) {
+            pdf = fastExp(sc, -tau).avg();
+        } else {
+            pdf = (sigmaT*fastExp(sc, -tau)).avg();
+            weight *= sigmaS*1.0f;
+        }
+        weight /= pdf;
+        firstScatter = false; // MediumState::advance
+        stateBounce++;
+    }
+    if (!ok) { // `return emission`
+        st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, END_RAW));
+        st.shFlag[path] = 0u;
+        return;
+    }
+    tp *= weight;
+    if (exited) {
+        st.tp[path] = mk4u(tp, flags);
+        st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
+        st.med[path] = uint32_t(medium + 1) | (firstScatter ? 1u << 8 : 0u) | (stateBounce << 9);
+        if (!didHit) { // `break`: handleInfiniteLights and the final NaN check
+            st.shFlag[path] = 0u;
+            missPath(sc, st, path);
+        } else {
+            shadePath<-1, true>(sc, st, path, true);
+        }
+        return;
+    }
+
+    // ---- handleVolume ----
+    const bool volumeNee = sc.settings.enable_volume_light_sampling != 0;
+    const V3 p = O + t*D;
+    wasSpecular = !volumeNee;
+    V3 L(0.0f), B(0.0f);
+    float tfarL = -1.0f, tfarB = -1.0f, pickWeight = 1.0f;
+    V3 dL(0.0f), dB(0.0f);
+    uint32_t endCap = PRIM_MISS;
+    const V3 tpVertex = tp;
+    if (volumeNee && bounce < maxBounces - 1 && sc.nLights > 0) {
+        int lightIdx = chooseLight(sc, p, smp, pickWeight);
+        if (lightIdx >= 0) {
+            const tgpu_light light = sc.lights[lightIdx];
+            const bool isEnv = light.kind == TGPU_LIGHT_ENV;
+            endCap = isEnv ? ((KIND_ENV << 30) | 0u) : ((KIND_QUAD << 30) | uint32_t(light.index));
+            const bool shadowPasses = bounce + 1 >= minBounces;
+            { // volumeLightSample
+                LightSample ls;
+                bool okL = isEnv ? envSampleDirect(sc, smp, ls) : quadSampleDirect(sc.quads[light.index], p, smp, ls);
+                if (okL) {
+                    V3 f(INV_FOUR_PI); // IsotropicPhaseFunction::eval
+                    V3 E(0.0f);
+                    float farT = TG_INF;
+                    bool lit = true;
+                    if (isEnv) {
+                        float ux, uy;
+                        if (sc.envConstant) E = V3(sc.textures[sc.env.emission_tex].value);
+                        else { directionToUV(sc, ls.d, ux, uy, nullptr); E = texEval(sc, sc.env.emission_tex, ux, uy); }
+                    } else {
+                        QuadHit qh;
+                        const tgpu_quad &lq = sc.quads[light.index];
+                        lit = quadIntersect(lq, p, ls.d, 0.0f, TG_INF, qh) && !(qh.t*(1.0f + 1e-3f) < ls.dist);
+                        if (lit) {
+                            farT = qh.t;
+                            E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
+                        }
+                    }
+                    E = neeTransmittance(sc, medium, farT)*E;
+                    if (lit && shadowPasses && !E.isZero()) {
+                        V3 lightF = f*E/ls.pdf;
+                        lightF *= powerHeuristic(ls.pdf, INV_FOUR_PI);
+                        L = lightF;
+                        dL = ls.d;
+                        tfarL = farT;
+                    }
+                }
+            }
+            { // volumePhaseSample (the lights in scope are never Dirac)
+                float xi0 = smp.next1D(), xi1 = smp.next1D();
+                float phi = xi0*TWO_PI; // SampleWarp::uniformSphere
+                float z = xi1*2.0f - 1.0f;
+                float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
+                float sp, cp;
+                tgpu_sincosf(phi, &sp, &cp);
+                V3 w(cp*r, sp*r, z);
+                V3 E(0.0f);
+                float farT = TG_INF, lightPdf = 0.0f;
+                bool lit = true;
+                if (isEnv) {
+                    float ux, uy;
+                    lightPdf = envDirectPdf(sc, w, ux, uy);
+                    E = sc.envConstant ? V3(sc.textures[sc.env.emission_tex].value) : texEval(sc, sc.env.emission_tex, ux, uy);
+                } else {
+                    QuadHit qh;
+                    const tgpu_quad &lq = sc.quads[light.index];
+                    lit = quadIntersect(lq, p, w, 0.0f, TG_INF, qh);
+                    if (lit) {
+                        farT = qh.t;
+                        E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
+                        V3 normal(lq.normal);
+                        float cosTheta = __builtin_fabsf(normal.dot(w));
+                        float tq = normal.dot(V3(lq.base) - p)/normal.dot(w);
+                        lightPdf = tq*tq/(cosTheta*lq.area);
+                    }
+                }
+                E = neeTransmittance(sc, medium, farT)*E;
+                if (lit && shadowPasses && !E.isZero()) {
+                    V3 phaseF = E*V3(1.0f);
+                    phaseF *= powerHeuristic(INV_FOUR_PI, lightPdf);
+                    B = phaseF;
+                    dB = w;
+                    tfarB = farT;
+                }
+            }
+        }
+    }
+    const bool pushShadow = tfarL >= 0.0f || tfarB >= 0.0f;
+
+    // IsotropicPhaseFunction::sample -> the continuation ray (nearT = 0)
+    float xi0 = smp.next1D(), xi1 = smp.next1D();
+    float phi = xi0*TWO_PI;
+    float z = xi1*2.0f - 1.0f;
+    float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
+    float sp, cp;
+    tgpu_sincosf(phi, &sp, &cp);
+    const V3 wo(cp*r, sp*r, z);
+    tp *= V3(1.0f);
+
+    // PathTracer.cpp:108-126
+    int end = END_ALIVE;
+    if (tp.max() == 0.0f) {
+        end = END_CHECKED;
+    } else {
+        float roulettePdf = vabs(tp).max();
+        bool cont = true;
+        if (bounce > 2 && roulettePdf < 0.1f) {
+            if (smp.nextBoolean(roulettePdf))
+                tp /= roulettePdf;
+            else
+                cont = false;
+        }
+        if (!cont) {
+            end = END_RAW;
+        } else if (isnanf_(wo.sum() + p.sum())) {
+            end = END_ZERO;
+        } else {
+            bounce++;
+            if (bounce >= maxBounces) end = END_CHECKED;
+        }
+    }
+    st.rayO[path] = mk4(p, 0.0f);
+    st.rayD[path] = mk4(wo, TG_INF);
+    st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
+    st.med[path] = uint32_t(medium + 1) | (firstScatter ? 1u << 8 : 0u) | (stateBounce << 9);
+    if (pushShadow) {
+        st.shA[path] = mk4(dL, tfarL);
+        st.shB[path] = mk4(dB, tfarB);
+        st.shC[path] = mk4(L, pickWeight);
+        st.shD[path] = mk4u(B, endCap);
+        st.shE[path] = mk4u(tpVertex, 0u);
+    }
+    st.em[path] = mk4u(em, smp.scramble);
+    st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
+    st.shFlag[path] = pushShadow ? 1u : 0u;
+}
+
 // One surface vertex of one path (the body of the shade kernels; the tail kernel calls it too):
 // TraceBase::handleSurface + the loop tail of PathTracer::traceSample.
-TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
+// CLASS >= 0: the caller guarantees the hit BSDF's type (the per-class shade kernels), which lets the compiler drop the
+// code of the other BSDFs; MEDIA = false compiles the medium bookkeeping out.
+template <int CLASS, bool MEDIA>
+TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium)
 {
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
     const bool neeEnabled = sc.settings.enable_light_sampling != 0;
@@ -1021,7 +1301,8 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
     bool wasSpecular = flagsSpecular(flags);
     int end = END_ALIVE;
 
-    if (bounce > 0 && isnanf_(tp.sum() + em.sum())) {
+    // afterMedium: volumePath ran the check before the distance sampling and scaled tp by the medium weight since
+    if (!afterMedium && bounce > 0 && isnanf_(tp.sum() + em.sum())) {
         end = END_ZERO; // PathTracer.cpp:121-122 for the previous vertex
     } else {
         Sampler smp;
@@ -1040,7 +1321,11 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
             if (inst != INST_NONE) applyInstance(sc, inst, prim, O, D, hw.x, info);
         }
         const tgpu_bsdf &bsdf = sc.bsdfs[info.bsdf];
+        if (CLASS >= 0) __builtin_assume(bsdf.type == CLASS);
         const uint32_t lobes = bsdfLobes(sc, bsdf);
+        const bool media = MEDIA && sc.nMedia != 0;
+        const int curMedium = media ? int(st.med[path] & 0xFFu) - 1 : -1;
+        const bool overridesMedia = info.intMedium >= 0 || info.extMedium >= 0; // Primitive::selectMedium (Primitive.hpp:172-183)
 
         // makeLocalScatterEvent (TraceBase.cpp:24-51)
         Event ev;
@@ -1114,6 +1399,8 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
                                     E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
                                 }
                             }
+                            // generalizedShadowRay: the medium on the light's side attenuates the unoccluded segment (:261-262, :100-108)
+                            if (media) E = neeTransmittance(sc, overridesMedia ? (ls.d.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium, farT)*E;
                             if (lit && shadowPasses && !E.isZero()) {
                                 V3 lightF = f*E/ls.pdf;
                                 lightF *= powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
@@ -1156,6 +1443,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
                                     lightPdf = tq*tq/(cosTheta*lq.area);
                                 }
                             }
+                            if (media) E = neeTransmittance(sc, overridesMedia ? (wo.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium, farT)*E; // :301-302
                             if (lit && shadowPasses && !E.isZero()) {
                                 V3 bsdfF = E*ev.weight;
                                 bsdfF *= powerHeuristic(ev.pdf, lightPdf);
@@ -1196,6 +1484,10 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
             }
         }
         V3 hitpoint = O + D*hw.x;
+        if (media && alive) { // medium = selectMedium(medium, geometricBackside); state.reset() (TraceBase.cpp:560-562)
+            int next = overridesMedia ? (wo.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium;
+            st.med[path] = uint32_t(next + 1) | (1u << 8);
+        }
         if (!alive) {
             end = END_RAW; // handleSurface returned false -> `return emission`
         } else {
@@ -1245,14 +1537,22 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path)
     st.shFlag[path] = pushShadow ? 1u : 0u;
 }
 
-template <int CLASS>
+template <int CLASS, bool MEDIA>
 __global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + CLASS)];
     const uint32_t *list = st.lists[set][1 + CLASS];
     const uint32_t stride = gridDim.x*blockDim.x;
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) shadePath(sc, st, list[q]);
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) shadePath<CLASS, MEDIA>(sc, st, list[q]);
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&st.stats[5], (unsigned long long)count);
+}
+
+// K3v: the slots whose ray runs inside a medium (list 1 + TG_CLASS_VOLUME)
+__global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, int set)
+{
+    const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + TG_CLASS_VOLUME)];
+    const uint32_t *list = st.lists[set][1 + TG_CLASS_VOLUME];
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) volumePath(sc, st, list[q]);
 }
 
 // =================================================================================================
@@ -1352,10 +1652,14 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
                 if (INST) st.hitInst[slot] = inst;
                 st.hit[slot] = make_float4(tfar, u, v, __uint_as_float(prim));
                 extRays++;
-                if (prim == PRIM_MISS) {
+                if (sc.nMedia && (st.med[slot] & 0xFFu)) {
+                    volumePath(sc, st, slot);
+                    events++;
+                    if (st.shFlag[slot]) shadowPath<COUNT, INST>(sc, st, stack, slot, tcS, shRays);
+                } else if (prim == PRIM_MISS) {
                     missPath(sc, st, slot);
                 } else {
-                    shadePath(sc, st, slot);
+                    shadePath<-1, true>(sc, st, slot);
                     events++;
                     if (st.shFlag[slot]) shadowPath<COUNT, INST>(sc, st, stack, slot, tcS, shRays);
                 }

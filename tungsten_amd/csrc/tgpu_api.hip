@@ -12,6 +12,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -201,8 +202,25 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
             if (l.index < 0 || uint32_t(l.index) >= s->n_quads || s->quads[l.index].emission_tex < 0) { fail(ctx, "light %u: bad quad", i); return TGPU_ERR_INVALID; }
         } else { fail(ctx, "light %u has unknown kind", i); return TGPU_ERR_INVALID; }
     }
-    if (s->n_media) { fail(ctx, "participating media: GPU path not built yet"); return TGPU_ERR_UNSUPPORTED; } // TEMP(a26)
-    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type == TGPU_BSDF_ROUGH_DIELECTRIC) { fail(ctx, "rough_dielectric: GPU path not built yet"); return TGPU_ERR_UNSUPPORTED; } // TEMP(a26)
+    // participating media
+    if (s->n_media > 254) { fail(ctx, "more than 254 media"); return TGPU_ERR_UNSUPPORTED; }
+    if (s->n_media && !s->media) { fail(ctx, "media array missing"); return TGPU_ERR_INVALID; }
+    auto mediumOk = [&](int m) { return m >= -1 && m < int(s->n_media); };
+    if (!mediumOk(s->camera.medium)) { fail(ctx, "camera references medium %d", s->camera.medium); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_quads + s->n_master_quads; ++i)
+        if (!mediumOk(s->quads[i].int_medium) || !mediumOk(s->quads[i].ext_medium)) { fail(ctx, "quad %u: bad medium", i); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_cubes + s->n_master_cubes; ++i)
+        if (!mediumOk(s->cubes[i].int_medium) || !mediumOk(s->cubes[i].ext_medium)) { fail(ctx, "cube %u: bad medium", i); return TGPU_ERR_INVALID; }
+    if (s->tri_media)
+        for (uint32_t i = 0; i < s->n_tris + s->n_master_tris; ++i)
+            if (!mediumOk(s->tri_media[size_t(i)*2]) || !mediumOk(s->tri_media[size_t(i)*2 + 1])) { fail(ctx, "triangle %u: bad medium", i); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_media; ++i)
+        if (s->media[i].max_bounce < 0 || s->media[i].max_bounce >= (1 << 22)) { fail(ctx, "medium %u: max_bounces out of range", i); return TGPU_ERR_UNSUPPORTED; }
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i)
+        if (s->bsdfs[i].type == TGPU_BSDF_ROUGH_DIELECTRIC) {
+            if (!texOk(s->bsdfs[i].roughness_tex)) { fail(ctx, "bsdf %u: bad roughness texture", i); return TGPU_ERR_INVALID; }
+            if (s->bsdfs[i].distribution == TGPU_DIST_PHONG) { fail(ctx, "bsdf %u: phong microfacet distribution is outside the hot-path scope", i); return TGPU_ERR_UNSUPPORTED; }
+        }
     // "instances" primitives
     if (s->n_instance_sets > 255) { fail(ctx, "more than 255 'instances' primitives"); return TGPU_ERR_UNSUPPORTED; }
     if (s->n_instance_sets && !s->instance_sets) { fail(ctx, "instance_sets missing"); return TGPU_ERR_INVALID; }
@@ -443,7 +461,11 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         q[1] = {n[4], n[5], n[6], n[7]};
         q[2] = {n[8], uv[0], uv[1], uv[2]};
         q[3] = {uv[3], uv[4], uv[5], fb};
-        q[4] = {ng[0], ng[1], ng[2], 0.0f};
+        uint32_t mediaBits = 0; // (int_medium + 1) << 16 | (ext_medium + 1)
+        if (s->tri_media) mediaBits = (uint32_t(int(s->tri_media[size_t(i)*2]) + 1) << 16) | uint32_t(int(s->tri_media[size_t(i)*2 + 1]) + 1);
+        float fm;
+        std::memcpy(&fm, &mediaBits, 4);
+        q[4] = {ng[0], ng[1], ng[2], fm};
         triClass[i] = uint8_t(s->bsdfs[s->tri_bsdf[i]].type);
     }
     float4 *dShade;
@@ -465,6 +487,24 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.bsdfs = dBsdfs;
     sc.textures = dTex;
     sc.lights = dLights; sc.nLights = s->n_lights;
+    {   // media + the table of fmath::exp_ps (fmath.hpp:106-126: a = n/logf(2), b = logf(2)/n, tbl[i] = mantissa(pow(2.0f, i/n)))
+        tgpu_medium *dMedia;
+        if ((rc = upload(ctx, ctx->allocs, s->media, s->n_media, &dMedia))) return rc;
+        sc.media = dMedia; sc.nMedia = s->n_media;
+        std::vector<uint32_t> tbl(1024);
+        const float log2f_ = ::logf(2.0f);
+        sc.expA = 1024/log2f_;
+        sc.expB = log2f_/1024;
+        for (int i = 0; i < 1024; ++i) {
+            float y = std::pow(2.0f, float(i)/1024);
+            uint32_t bits;
+            std::memcpy(&bits, &y, 4);
+            tbl[size_t(i)] = bits & 0x7FFFFFu;
+        }
+        uint32_t *dTbl;
+        if ((rc = upload(ctx, ctx->allocs, tbl.data(), tbl.size(), &dTbl))) return rc;
+        sc.expTable = dTbl;
+    }
     std::vector<DBitmap> bitmaps(s->n_bitmaps);
     for (uint32_t i = 0; i < s->n_bitmaps; ++i) {
         const tgpu_bitmap &b = s->bitmaps[i];
@@ -580,6 +620,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
     if (sc.nInstSets && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.hitInst))) return rc;
+    if (sc.nMedia && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.med))) return rc;
     {
         std::vector<uint32_t> ident(cap);
         for (uint64_t i = 0; i < cap; ++i) ident[i] = uint32_t(i);
@@ -736,10 +777,20 @@ static int driveIteration(tgpu_ctx *ctx)
         {
             Timer t(ctx, &ctx->stats.shade_ms);
             hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st, out);
-            hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(256), 0, stream, sc, st, out);
-            hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(256), 0, stream, sc, st, out);
-            hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(256), 0, stream, sc, st, out);
-            hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(256), 0, stream, sc, st, out);
+            if (sc.nMedia) {
+                hipLaunchKernelGGL((k_shade<0, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<1, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<2, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<3, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<4, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+            } else {
+                hipLaunchKernelGGL((k_shade<0, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<1, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<2, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<3, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<4, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+            }
+            if (sc.nMedia) hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out);
         }
         {
             Timer t(ctx, &ctx->stats.shadow_ms);

@@ -358,3 +358,28 @@ def test_cpp_host_integrator_cli_adaptive(ta, oracle_py, tmp_path):
     ref, cnt, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(48, spp_step=16, adaptive=True)
     assert cnt.min() < 48 < cnt.max()
     assert np.array_equal(img, ref)
+
+
+@pytest.mark.parametrize("scene,res,spp", [
+    ("materialtest/c5.json", (128, 72), 8),            # volume list + k_volume + class-specialised shade kernels
+    ("cornell-box/scene_fog.json", (96, 54), 8),
+    ("instances/inst_mesh.json", (96, 54), 8),         # INST variants of extend / shadow
+    ("materialtest/c1_noadapt.json", (128, 72), 8),
+])
+def test_wavefront_kernels_without_the_tail_kernel(ta, oracle_py, scene, res, spp, monkeypatch):
+    """Small renders finish inside the tail megakernel; TGPU_TAIL_MAX=0 forces every bounce through the per-stage
+    wavefront kernels (extend -> miss | shade<class> | volume -> shadow -> retire/regenerate) instead."""
+    monkeypatch.setenv("TGPU_TAIL_MAX", "0")
+    hs = ta.HostScene(scene_path(scene), resolution=res)
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    ctx = ta.Context(0)
+    try:
+        ctx.upload(hs, shard, 2048)  # a pool much smaller than the job: slots are retired and regenerated many times
+        ctx.render(spp, spp_step=spp)
+        got = ctx.download()
+        st = ctx.stats()
+        assert st["tail_launches"] == 0 and st["extend_launches"] > 10
+    finally:
+        ctx.close()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, spp, spp_step=spp)
+    assert_bit_exact(got, ref, f"{scene} wavefront-only")

@@ -90,9 +90,10 @@ def test_abi_struct_sizes_match_the_c_header(ta):
     src = r'''
 #include "tungsten_amd.h"
 #include <stdio.h>
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tgpu_texture), sizeof(tgpu_bitmap),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tgpu_texture), sizeof(tgpu_bitmap),
  sizeof(tgpu_bsdf), sizeof(tgpu_quad), sizeof(tgpu_cube), sizeof(tgpu_env), sizeof(tgpu_camera), sizeof(tgpu_settings),
- sizeof(tgpu_light), sizeof(tgpu_scene_desc), sizeof(tgpu_shard_desc), sizeof(tgpu_stats));return 0;}'''
+ sizeof(tgpu_light), sizeof(tgpu_scene_desc), sizeof(tgpu_shard_desc), sizeof(tgpu_stats), sizeof(tgpu_medium),
+ sizeof(tgpu_master), sizeof(tgpu_instances), sizeof(tgpu_sample_record));return 0;}'''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
         open(c, "w").write(src)
@@ -100,7 +101,8 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeo
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)  # header is plain C
         sizes = [int(t) for t in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     mirrors = [_abi.Texture, _abi.Bitmap, _abi.Bsdf, _abi.Quad, _abi.Cube, _abi.Env, _abi.Camera, _abi.Settings,
-               _abi.Light, _abi.SceneDesc, _abi.ShardDesc, _abi.Stats]
+               _abi.Light, _abi.SceneDesc, _abi.ShardDesc, _abi.Stats, _abi.Medium, _abi.Master, _abi.Instances,
+               _abi.SampleRecord]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

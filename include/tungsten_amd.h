@@ -66,7 +66,8 @@ enum {
     TGPU_BSDF_SMOOTH_COAT = 2,      /* SmoothCoatBsdf.cpp:41-223        */
     TGPU_BSDF_NULL = 3,             /* NullBsdf.cpp (light carriers)    */
     TGPU_BSDF_ROUGH_DIELECTRIC = 4, /* RoughDielectricBsdf.cpp:55-280   */
-    TGPU_BSDF_NUM_CLASSES = 5
+    TGPU_BSDF_FORWARD = 5,          /* ForwardBsdf.cpp:9-36 (index-matched medium boundaries) */
+    TGPU_BSDF_NUM_CLASSES = 6
 };
 enum { TGPU_DIST_BECKMANN = 0, TGPU_DIST_PHONG = 1, TGPU_DIST_GGX = 2 };
 
@@ -90,10 +91,22 @@ typedef struct tgpu_bsdf {
  * an isotropic phase function (IsotropicPhaseFunction.cpp:17-44) and the
  * exponential transmittance (ExponentialTransmittance.cpp:26-55, evaluated
  * with fmath::exp_ps, thirdparty/fmath/fmath.hpp:320-363).                    */
+/* Transmittance models of the fork (src/core/transmittances): what a free path looks like between two
+ * collisions, with separate surface->surface, surface->medium, medium->surface and medium->medium forms
+ * (Transmittance.hpp:22-60).  param[]: linear / quadratic: max_t; double_exponential: sigma_a, sigma_b;
+ * pulse: min, max, num_pulses.                                               */
+enum { TGPU_TRANS_EXPONENTIAL = 0,        /* ExponentialTransmittance.cpp:26-55       */
+       TGPU_TRANS_LINEAR = 1,             /* LinearTransmittance.cpp:30-76            */
+       TGPU_TRANS_QUADRATIC = 2,          /* QuadraticTransmittance.cpp:30-65         */
+       TGPU_TRANS_DOUBLE_EXPONENTIAL = 3, /* DoubleExponentialTransmittance.cpp:34-65 */
+       TGPU_TRANS_PULSE = 4 };            /* PulseTransmittance.cpp:43-105            */
+
 typedef struct tgpu_medium {
     float   sigma_a[3], sigma_s[3], sigma_t[3];
     int32_t absorption_only;     /* sigma_s == 0                               */
     int32_t max_bounce;          /* Medium::_maxBounce (default 1024)          */
+    int32_t transmittance;       /* TGPU_TRANS_*                               */
+    float   param[3];
 } tgpu_medium;
 
 /* ---- analytic primitives ------------------------------------------------ */

@@ -298,6 +298,10 @@ struct oracle_ctx {
     V3 fastExp(const V3 &x) const;
     bool mediumSampleDistance(int medium, Sampler &sampler, const Ray &ray, struct MediumStateO &state, struct MediumSampleO &sample) const;
     V3 mediumTransmittance(int medium, const Ray &ray, bool startOnSurface, bool endOnSurface) const;
+    V3 transEval(const tgpu_medium &m, const V3 &tau, bool startOnSurface, bool endOnSurface) const;
+    V3 transForm(const tgpu_medium &m, int form, const V3 &tau) const; // 0 surfaceSurface 1 surfaceMedium 2 mediumSurface 3 mediumMedium
+    float transSigmaBar(const tgpu_medium &m) const;
+    float transSample(const tgpu_medium &m, Sampler &sampler, bool startOnSurface) const;
     int selectMedium(const Info &info, int current, bool geometricBackside) const;
     V3 volumeEstimateDirect(Sampler &sampler, const struct MediumSampleO &ms, int medium, int bounce, const Ray &parent, Counters &c) const;
     bool handleVolume(Sampler &sampler, const struct MediumSampleO &ms, int medium, int bounce, bool enableLightSampling, Ray &ray, V3 &throughput, V3 &emission,
@@ -1330,6 +1334,7 @@ uint32_t oracle_ctx::bsdfLobes(int b) const
     case TGPU_BSDF_LAMBERT: return DiffuseReflectionLobe;
     case TGPU_BSDF_ROUGH_CONDUCTOR: return GlossyReflectionLobe;
     case TGPU_BSDF_SMOOTH_COAT: return SpecularReflectionLobe | bsdfLobes(d.substrate);
+    case TGPU_BSDF_FORWARD: return ForwardLobe; // ForwardBsdf.cpp:9-12
     case TGPU_BSDF_ROUGH_DIELECTRIC: // RoughDielectricBsdf.cpp:38-41
         return d.enable_refraction ? (GlossyReflectionLobe | GlossyTransmissionLobe) : GlossyReflectionLobe;
     default: return 0;
@@ -1461,6 +1466,11 @@ V3 oracle_ctx::bsdfEval(int b, const Event &e) const
         float D = mf.D(alpha, hr);
         float fr = (G*D*0.25f)/e.wi.z;
         return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*fr);
+    }
+    case TGPU_BSDF_FORWARD: { // bsdfs/ForwardBsdf.cpp:26-29
+        bool isForward = (e.requestedLobe & ForwardLobe) != 0; // BsdfLobes::isForward
+        V3 nwi = -e.wi;
+        return (isForward && nwi.x == e.wo.x && nwi.y == e.wo.y && nwi.z == e.wo.z) ? V3(1.0f) : V3(0.0f);
     }
     case TGPU_BSDF_ROUGH_DIELECTRIC: { // bsdfs/RoughDielectricBsdf.cpp:133-164 (evalBase), :242-249
         bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
@@ -1779,18 +1789,37 @@ Event oracle_ctx::makeLocalScatterEvent(const Temp & /*data*/, const Info &info,
 }
 
 V3 oracle_ctx::shadowRay(Ray &ray, int medium, int endKind, uint32_t endIndex, int bounce, bool startsOnSurface, bool endsOnSurface, Counters &c) const
-{   // TraceBase.cpp:62-125 (generalizedShadowRayImpl<false>).  None of the BSDFs in scope has a ForwardLobe, so the
-    // first non-end-cap hit blocks and the loop body runs once; the medium attenuates the unoccluded segment.
-    c.shadow++;
+{   // TraceBase.cpp:62-125 (generalizedShadowRayImpl<false>): surfaces with a forward lobe let the ray through (and may
+    // switch the medium), anything else blocks; every segment is attenuated by the medium it runs in
     Temp data;
     Info info;
+    float initialFarT = ray.farT;
     V3 throughput(1.0f);
-    bool didHit = intersect(ray, data, info, c) && !(info.kind == endKind && info.index == endIndex);
-    if (didHit) {
-        if (!(bsdfLobes(info.bsdf) & ForwardLobe)) return V3(0.0f);
-    }
-    if (medium >= 0) throughput *= mediumTransmittance(medium, ray, startsOnSurface, endsOnSurface);
-    return bounce >= sc.settings.min_bounces ? throughput : V3(0.0f);
+    do {
+        c.shadow++;
+        bool didHit = intersect(ray, data, info, c) && !(info.kind == endKind && info.index == endIndex);
+        if (didHit) {
+            if (!(bsdfLobes(info.bsdf) & ForwardLobe)) return V3(0.0f);
+            Event event = makeLocalScatterEvent(data, info, ray, nullptr);
+            Event fwd = event; // makeForwardEvent
+            fwd.wo = -fwd.wi;
+            fwd.requestedLobe = ForwardLobe;
+            V3 transparency = bsdfEval(info.bsdf, fwd);
+            if (transparency == 0.0f) return V3(0.0f);
+            throughput *= transparency;
+            bounce++;
+            if (bounce >= sc.settings.max_bounces) return V3(0.0f);
+        }
+        if (medium >= 0) throughput *= mediumTransmittance(medium, ray, startsOnSurface, endsOnSurface);
+        if (info.kind == PRIM_NONE || (info.kind == endKind && info.index == endIndex))
+            return bounce >= sc.settings.min_bounces ? throughput : V3(0.0f);
+        medium = selectMedium(info, medium, !data.backSide); // selectMedium(medium, !hitBackside(data))
+        startsOnSurface = true;
+        ray.pos = ray.pos + ray.dir*ray.farT; // ray.hitpoint()
+        initialFarT -= ray.farT;
+        ray.nearT = info.epsilon;
+        ray.farT = initialFarT;
+    } while (true);
 }
 
 V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, int medium, float expectedDist, Temp &data, Info &info, int bounce, bool startsOnSurface,
@@ -1995,8 +2024,130 @@ V3 oracle_ctx::fastExp(const V3 &v) const
     return V3(out[0], out[1], out[2]);
 }
 
+// ---- transmittances (transmittances/*.cpp; Transmittance.hpp:22-42 picks the form from where the segment starts / ends)
+V3 oracle_ctx::transForm(const tgpu_medium &m, int form, const V3 &tau) const
+{
+    auto vmin1 = [](const V3 &a) { return V3(fmin2(a.x, 1.0f), fmin2(a.y, 1.0f), fmin2(a.z, 1.0f)); }; // min(a, Vec3f(1))
+    switch (m.transmittance) {
+    case TGPU_TRANS_EXPONENTIAL: return fastExp(-tau); // all four forms (ExponentialTransmittance.cpp:26-41)
+    case TGPU_TRANS_LINEAR: { // LinearTransmittance.cpp:30-59
+        const float maxT = m.param[0];
+        if (form == 0) return V3(1.0f) - vmin1(tau/maxT);
+        V3 r;
+        for (int i = 0; i < 3; ++i) {
+            if (form == 1) r[i] = tau[i] > maxT ? 0.0f : 1.0f/maxT;
+            else if (form == 2) r[i] = tau[i] > maxT ? 0.0f : 1.0f;
+            else r[i] = std::abs(tau[i] - maxT) < 1e-3f ? 1.0f : 0.0f;
+        }
+        return r;
+    }
+    case TGPU_TRANS_QUADRATIC: { // QuadraticTransmittance.cpp:30-51
+        const float maxT = m.param[0];
+        if (form == 0) { V3 t = vmin1(tau/maxT); return V3(1.0f) - 2.0f*t + t*t; }
+        if (form == 1) return (2.0f/maxT)*(V3(1.0f) - vmin1(tau/maxT));
+        if (form == 2) return V3(1.0f) - vmin1(tau/maxT);
+        V3 r(1.0f/maxT);
+        for (int i = 0; i < 3; ++i) if (tau[i] > maxT) r[i] = 0.0f;
+        return r;
+    }
+    case TGPU_TRANS_DOUBLE_EXPONENTIAL: { // DoubleExponentialTransmittance.cpp:34-49 (std::exp per component)
+        const float sa = m.param[0], sb = m.param[1];
+        auto ex = [&](const V3 &v) { return V3(mexp(v.x), mexp(v.y), mexp(v.z)); };
+        V3 ea = ex(-sa*tau), eb = ex(-sb*tau);
+        if (form == 0) return 0.5f*(ea + eb);
+        if (form == 1) return 0.5f*(sa*ea + sb*eb);
+        if (form == 2) return (sa*ea + sb*eb)/(sa + sb);
+        return ((sa*sa)*ea + (sb*sb)*eb)/(sa + sb);
+    }
+    case TGPU_TRANS_PULSE: { // PulseTransmittance.cpp:43-81
+        const float a = m.param[0], b = m.param[1];
+        const int numPulses = int(m.param[2]);
+        if (form == 0) {
+            V3 idxF = (float(numPulses)*(tau - a))/(b - a) + 0.5f;
+            V3 res;
+            for (int i = 0; i < 3; ++i) {
+                float f = clampf(idxF[i], 0.0f, float(numPulses));
+                int idx = int(f);
+                float height = float(numPulses - idx)/float(numPulses);
+                float cellIntegral = height*(f - float(idx));
+                if (idx > 0) cellIntegral += (idx - 0.5f) - (idx*(idx - 1))/(2.0f*numPulses);
+                else cellIntegral -= 0.5f;
+                res[i] = 1.0f - (2.0f/numPulses)*cellIntegral;
+            }
+            return res;
+        }
+        if (form == 1 || form == 2) {
+            V3 res;
+            for (int i = 0; i < 3; ++i) {
+                int idx = int((float(numPulses)*(tau[i] - a))/(b - a) + 0.5f);
+                idx = std::min(std::max(idx, 0), numPulses);
+                res[i] = 1.0f - float(idx)/float(numPulses);
+            }
+            return form == 1 ? 2.0f/(b - a)*res : res;
+        }
+        V3 res;
+        for (int i = 0; i < 3; ++i) {
+            float f = clampf((float(numPulses)*(tau[i] - a))/(b - a), 0.0f, float(numPulses));
+            int idx = int(f);
+            res[i] = std::abs(f - idx - 0.5f) < 1e-3f ? 1.0f : 0.0f;
+        }
+        return (1.0f/numPulses)*res;
+    }
+    default: return V3(0.0f);
+    }
+}
+
+float oracle_ctx::transSigmaBar(const tgpu_medium &m) const
+{
+    switch (m.transmittance) {
+    case TGPU_TRANS_LINEAR: return 1.0f/m.param[0];
+    case TGPU_TRANS_QUADRATIC: return 2.0f/m.param[0];
+    case TGPU_TRANS_DOUBLE_EXPONENTIAL: return 0.5f*(m.param[0] + m.param[1]);
+    case TGPU_TRANS_PULSE: return 2.0f/(m.param[1] - m.param[0]);
+    default: return 1.0f;
+    }
+}
+
+V3 oracle_ctx::transEval(const tgpu_medium &m, const V3 &tau, bool startOnSurface, bool endOnSurface) const
+{   // Transmittance::eval (Transmittance.hpp:22-30)
+    if (startOnSurface && endOnSurface) return transForm(m, 0, tau);
+    if (!startOnSurface && !endOnSurface) return transForm(m, 3, tau)/transSigmaBar(m);
+    return transForm(m, 2, tau);
+}
+
+float oracle_ctx::transSample(const tgpu_medium &m, Sampler &sampler, bool startOnSurface) const
+{   // Transmittance::sample -> sampleSurface / sampleMedium
+    switch (m.transmittance) {
+    case TGPU_TRANS_LINEAR: return startOnSurface ? m.param[0]*sampler.next1D() : m.param[0];
+    case TGPU_TRANS_QUADRATIC:
+        return startOnSurface ? m.param[0]*(1.0f - std::sqrt(1.0f - sampler.next1D())) : m.param[0]*sampler.next1D();
+    case TGPU_TRANS_DOUBLE_EXPONENTIAL: {
+        float t = -mlog(1.0f - sampler.next1D());
+        float p = startOnSurface ? 0.5f : m.param[0]/(m.param[0] + m.param[1]);
+        return sampler.nextBoolean(p) ? t/m.param[0] : t/m.param[1];
+    }
+    case TGPU_TRANS_PULSE: {
+        const float a = m.param[0], b = m.param[1];
+        const int numPulses = int(m.param[2]);
+        if (!startOnSurface) return a + (0.5f + int(sampler.next1D()*numPulses))/float(numPulses)*(b - a);
+        float xi = sampler.next1D()*numPulses*0.5f;
+        float delta = 1.0f/numPulses;
+        for (int i = 0; i < numPulses; ++i) {
+            float h0 = 1.0f - (i + 0.0f)*delta;
+            float h1 = 1.0f - (i + 1.0f)*delta;
+            xi -= h0*0.5f;
+            if (xi < 0.0f) return a + (i + 0.0f + 0.5f*sampler.next1D())*(b - a)*delta;
+            xi -= h1*0.5f;
+            if (xi < 0.0f) return a + (i + 0.5f + 0.5f*sampler.next1D())*(b - a)*delta;
+        }
+        return 0.0f;
+    }
+    default: return -mlog(1.0f - sampler.next1D());
+    }
+}
+
 bool oracle_ctx::mediumSampleDistance(int medium, Sampler &sampler, const Ray &ray, MediumStateO &state, MediumSampleO &sample) const
-{   // HomogeneousMedium.cpp:65-108 ; ExponentialTransmittance: every surface/medium variant is exp(-tau), sigmaBar = 1
+{   // HomogeneousMedium.cpp:65-108
     const tgpu_medium &m = sc.media[medium];
     const V3 sigmaT(m.sigma_t), sigmaS(m.sigma_s);
     sample.emission = V3(0.0f);
@@ -2005,22 +2156,22 @@ bool oracle_ctx::mediumSampleDistance(int medium, Sampler &sampler, const Ray &r
     if (m.absorption_only) {
         if (maxT == INF) return false;
         sample.t = maxT;
-        sample.weight = fastExp(-(sample.t*sigmaT));
+        sample.weight = transEval(m, sample.t*sigmaT, state.firstScatter, true);
         sample.pdf = 1.0f;
         sample.exited = true;
     } else {
         int component = sampler.nextDiscrete(3);
         float sigmaTc = sigmaT[component];
-        float t = -mlog(1.0f - sampler.next1D())/sigmaTc; // ExponentialTransmittance::sampleSurface/sampleMedium :46-53
+        float t = transSample(m, sampler, state.firstScatter)/sigmaTc;
         sample.t = fmin2(t, maxT);
         sample.exited = t >= maxT;
         V3 tau = sample.t*sigmaT;
-        sample.weight = fastExp(-tau); // eval(tau, firstScatter, exited): mediumMedium(tau)/sigmaBar() == exp(-tau)/1
+        sample.weight = transEval(m, tau, state.firstScatter, sample.exited);
         if (sample.exited) {
-            sample.pdf = fastExp(-tau).avg();
+            sample.pdf = transForm(m, state.firstScatter ? 0 : 2, tau).avg();         // surfaceProbability
         } else {
-            sample.pdf = (sigmaT*fastExp(-tau)).avg();
-            sample.weight *= sigmaS*1.0f;
+            sample.pdf = (sigmaT*transForm(m, state.firstScatter ? 1 : 3, tau)).avg(); // sigmaT*mediumPdf
+            sample.weight *= sigmaS*transSigmaBar(m);
         }
         sample.weight /= sample.pdf;
         state.advance();
@@ -2029,10 +2180,10 @@ bool oracle_ctx::mediumSampleDistance(int medium, Sampler &sampler, const Ray &r
     return true;
 }
 
-V3 oracle_ctx::mediumTransmittance(int medium, const Ray &ray, bool /*startOnSurface*/, bool /*endOnSurface*/) const
+V3 oracle_ctx::mediumTransmittance(int medium, const Ray &ray, bool startOnSurface, bool endOnSurface) const
 {   // HomogeneousMedium.cpp:110-117
     if (ray.farT == INF) return V3(0.0f);
-    return fastExp(-(V3(sc.media[medium].sigma_t)*ray.farT));
+    return transEval(sc.media[medium], V3(sc.media[medium].sigma_t)*ray.farT, startOnSurface, endOnSurface);
 }
 
 int oracle_ctx::selectMedium(const Info &info, int current, bool geometricBackside) const

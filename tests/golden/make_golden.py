@@ -37,6 +37,12 @@ FIXTURES = [
     ("c5_128x72_16spp", "materialtest/c5.json", (128, 72), 16),
     ("c5_absorb_128x72_8spp", "materialtest/c5_absorb.json", (128, 72), 8),
     ("cornell_fog_96x54_8spp", "cornell-box/scene_fog.json", (96, 54), 8),   # camera medium + quad light: finite-segment transmittance
+    # the fork's own example scene: four Cornell boxes behind forward-scattering walls, filled with linear / quadratic /
+    # double-exponential / pulse media, lit by 'power' quads (data/example-scenes/non-exponential/scene.json, unmodified)
+    ("nonexp_stock_128_16spp", "non-exponential/scene.json", (128, 128), 16, False, {}),                          # stock: uniform sampler
+    ("nonexp_stock_sobol_128_16spp", "non-exponential/scene.json", (128, 128), 16, False, {"stratified_sampler": True}),
+    ("nonexp_stock_deep_96_8spp", "non-exponential/scene.json", (96, 96), 8, False, {"stratified_sampler": True, "max_bounces": 16}),
+    ("nonexp_stock_adaptive_128_48spp", "non-exponential/scene.json", (128, 128), 48, True, {}),
     ("c1_adaptive_128x72_64spp", "materialtest/materialtest.json", (128, 72), 64, True),
 ]
 
@@ -45,7 +51,9 @@ def main():
     if not os.path.exists(REF_BIN):
         sys.exit(f"reference binary {REF_BIN} not found; fixtures cannot be regenerated here")
     only = set(sys.argv[1:])
-    for name, scene, res, spp, *adaptive in FIXTURES:
+    for name, scene, res, spp, *rest in FIXTURES:
+        adaptive = rest[:1]
+        overrides = rest[1] if len(rest) > 1 else {}
         if only and name not in only:
             continue
         src = os.path.join(REPO, "assets", scene)
@@ -56,6 +64,10 @@ def main():
         d["camera"]["resolution"] = list(res)
         d["renderer"].update({"spp": spp, "output_file": name + ".png", "hdr_output_file": name + ".pfm",
                               "overwrite_output_files": True, "adaptive_sampling": bool(adaptive and adaptive[0])})
+        if "max_bounces" in overrides:
+            d["integrator"]["max_bounces"] = overrides["max_bounces"]
+        if "stratified_sampler" in overrides:
+            d["renderer"]["stratified_sampler"] = overrides["stratified_sampler"]
         tmp = os.path.join(os.path.dirname(src), f"_tmp_{name}.json")
         json.dump(d, open(tmp, "w"))
         try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden images for rows of SURVEY.md section 8f that are NOT built yet (other stock BSDFs, Sphere/Disk, Henyey-
-Greenstein, the fork's non-exponential transmittances behind forward-scattering boundaries): rendered by the compiled,
+Greenstein): rendered by the compiled,
 unmodified reference while it is available (same provenance as ../make_golden.py), so that the oracle of a later round
 can be pinned even if the reference binary is gone.  Data only: float framebuffers + the scene files under assets/.
 """
@@ -14,10 +14,6 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 REF_BIN = os.environ.get("TUNGSTEN_REF_BIN", "/tmp/tungsten-build/tungsten")
 
 FIXTURES = [  # name, scene, resolution, spp, renderer overrides, integrator overrides
-    ("nonexp_stock_128_16spp", "non-exponential/scene.json", (128, 128), 16, {"adaptive_sampling": False}, {}),
-    ("nonexp_stock_sobol_128_16spp", "non-exponential/scene.json", (128, 128), 16, {"adaptive_sampling": False, "stratified_sampler": True}, {}),
-    ("nonexp_stock_adaptive_128_48spp", "non-exponential/scene.json", (128, 128), 48, {"adaptive_sampling": True}, {}),
-    ("nonexp_stock_deep_96_8spp", "non-exponential/scene.json", (96, 96), 8, {"adaptive_sampling": False, "stratified_sampler": True}, {"max_bounces": 16}),
 ] + [(f"{n}_128x72_4spp", f"next/{n}.json", (128, 72), 4, {"adaptive_sampling": False}, {}) for n in (
     "dielectric", "mirror", "conductor", "plastic", "rough_plastic", "rough_coat", "thinsheet", "oren_nayar", "phong",
     "transparency", "mixed", "dielectric_hg_medium", "sphere_disk")]

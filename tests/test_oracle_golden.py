@@ -74,6 +74,26 @@ def test_oracle_adaptive_sampling_matches_reference(ta, oracle_py):
         assert np.abs(img - ref).max() < 1e-5
 
 
+@pytest.mark.parametrize("name,res,spp,kw,adaptive", [
+    ("nonexp_stock_128_16spp", (128, 128), 16, {}, False),                                   # as shipped: uniform sampler
+    ("nonexp_stock_sobol_128_16spp", (128, 128), 16, {"sobol": True}, False),
+    ("nonexp_stock_deep_96_8spp", (96, 96), 8, {"sobol": True, "max_bounces": 16}, False),
+    ("nonexp_stock_adaptive_128_48spp", (128, 128), 48, {}, True),                           # as shipped: adaptive on
+])
+def test_oracle_matches_reference_on_the_non_exponential_scene(ta, oracle_py, name, res, spp, kw, adaptive):
+    """data/example-scenes/non-exponential/scene.json, the scene this fork of Tungsten exists for: linear, quadratic,
+    double-exponential and pulse transmittances (surface/medium start and end forms), ForwardBsdf walls that switch the
+    medium, multi-segment shadow rays through them, 'power' quad lights, max_bounces 3."""
+    ref = ta.load_pfm(os.path.join(GOLDEN, name + ".pfm"))
+    hs = ta.HostScene(scene_path("non-exponential/scene.json"), resolution=res, **kw)
+    o = oracle_py.Oracle(hs, **oracle_py.REF_RCP)
+    img = o.render_reference(spp, spp_step=16, adaptive=True)[0] if adaptive else o.render_image(spp)[0]
+    assert float(np.sqrt(((img - ref)**2).mean())) < 1e-4
+    if intel_rcp(oracle_py):
+        assert float((img == ref).all(axis=2).mean()) > 0.999
+        assert np.abs(img - ref).max() < 1e-5
+
+
 def test_ieee_division_mode_stays_within_tolerance(ta, oracle_py):
     """What the GPU computes (IEEE division for t,u,v instead of RCPPS) differs from the reference
     only through chaotic path divergence: quantify it on a fixture."""

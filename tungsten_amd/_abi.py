@@ -29,7 +29,8 @@ class Bsdf(C.Structure):
 
 
 class Medium(C.Structure):
-    _fields_ = [("sigma_a", f32*3), ("sigma_s", f32*3), ("sigma_t", f32*3), ("absorption_only", i32), ("max_bounce", i32)]
+    _fields_ = [("sigma_a", f32*3), ("sigma_s", f32*3), ("sigma_t", f32*3), ("absorption_only", i32), ("max_bounce", i32),
+                ("transmittance", i32), ("param", f32*3)]
 
 
 class Quad(C.Structure):

@@ -487,6 +487,8 @@ int Scene::parseBsdf(const Json &v)
         b.type = TGPU_BSDF_LAMBERT;
     } else if (type == "null") {
         b.type = TGPU_BSDF_NULL;
+    } else if (type == "forward") {
+        b.type = TGPU_BSDF_FORWARD;
     } else if (type == "rough_conductor") { // RoughConductorBsdf.cpp:14-45
         b.type = TGPU_BSDF_ROUGH_CONDUCTOR;
         std::string material;
@@ -560,9 +562,31 @@ int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp
         std::string pt = ph.isObject() ? ph["type"].asString() : ph.asString();
         if (pt != "isotropic") throw std::runtime_error("phase function '" + pt + "' is outside the hot-path scope");
     }
-    if (const Json &tr = v["transmittance"]) {
+    int transType = TGPU_TRANS_EXPONENTIAL;
+    float transParam[3] = {0, 0, 0};
+    if (const Json &tr = v["transmittance"]) { // TransmittanceFactory.cpp:14-24
         std::string tt = tr.isObject() ? tr["type"].asString() : tr.asString();
-        if (tt != "exponential") throw std::runtime_error("transmittance '" + tt + "' is outside the hot-path scope");
+        if (tt == "exponential") {
+            transType = TGPU_TRANS_EXPONENTIAL;
+        } else if (tt == "linear" || tt == "quadratic") { // LinearTransmittance.cpp:10-20, QuadraticTransmittance.cpp:10-20
+            transType = tt == "linear" ? TGPU_TRANS_LINEAR : TGPU_TRANS_QUADRATIC;
+            transParam[0] = 1.0f;
+            if (tr.isObject()) tr.getField("max_t", transParam[0]);
+        } else if (tt == "double_exponential") { // DoubleExponentialTransmittance.cpp:13-24
+            transType = TGPU_TRANS_DOUBLE_EXPONENTIAL;
+            transParam[0] = 0.5f;
+            transParam[1] = 10.0f;
+            if (tr.isObject()) { tr.getField("sigma_a", transParam[0]); tr.getField("sigma_b", transParam[1]); }
+        } else if (tt == "pulse") { // PulseTransmittance.cpp:13-27
+            transType = TGPU_TRANS_PULSE;
+            transParam[0] = 0.0f;
+            transParam[1] = 1.0f;
+            int numPulses = 4;
+            if (tr.isObject()) { tr.getField("min", transParam[0]); tr.getField("max", transParam[1]); tr.getField("num_pulses", numPulses); }
+            transParam[2] = float(numPulses);
+        } else {
+            throw std::runtime_error("transmittance '" + tt + "' is outside the hot-path scope");
+        }
     }
     float sa[3] = {0, 0, 0}, ss[3] = {0, 0, 0}, density = 1.0f;
     v.getVec("sigma_a", sa, 3);
@@ -577,6 +601,8 @@ int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp
         m.sigma_t[i] = m.sigma_a[i] + m.sigma_s[i];
     }
     m.absorption_only = m.sigma_s[0] == 0.0f && m.sigma_s[1] == 0.0f && m.sigma_s[2] == 0.0f;
+    m.transmittance = transType;
+    for (int i = 0; i < 3; ++i) m.param[i] = transParam[i];
     _media.push_back(m);
     return int(_media.size()) - 1;
 }
@@ -719,12 +745,23 @@ void Scene::parsePrimitive(const Json &v)
     std::string type = v["type"].asString();
     Mat4 transform;
     if (v["transform"]) transform = parseTransform(v["transform"]);
-    if (v["power"]) throw std::runtime_error("'power' emitters are outside the hot-path scope");
+    if (v["power"] && type != "quad") throw std::runtime_error("'power' emitters other than quads are outside the hot-path scope");
     int intMedium = -1, extMedium = -1;
     if (v["int_medium"]) intMedium = fetchMedium(v["int_medium"]);
     if (v["ext_medium"]) extMedium = fetchMedium(v["ext_medium"]);
     int emissionTex = -1;
     if (v["emission"]) emissionTex = fetchTexture(v["emission"], false);
+    if (v["power"]) { // Primitive::prepareForRender (Primitive.cpp:111-117): _emission = power*powerToRadianceFactor()
+        int powerTex = fetchTexture(v["power"], false);
+        tgpu_texture t = _textures[size_t(powerTex)];
+        if (t.type != TGPU_TEX_CONSTANT) throw std::runtime_error("textured 'power' is outside the hot-path scope");
+        Vec3 edge0 = transform.transformVector(Vec3(1.0f, 0.0f, 0.0f)), edge1 = transform.transformVector(Vec3(0.0f, 0.0f, 1.0f));
+        float area = edge1.cross(edge0).length();           // Quad.cpp:298-316
+        float factor = (1.0f/3.1415926536f)*(1.0f/area);    // Quad::powerToRadianceFactor (:50-53): INV_PI*_invArea
+        for (int i = 0; i < 3; ++i) t.value[i] *= factor;   // ConstantTexture::scaleValues
+        _textures.push_back(t);
+        emissionTex = int(_textures.size()) - 1;
+    }
 
     if (type == "mesh") {
         meshes.push_back(parseMesh(v, transform, emissionTex));

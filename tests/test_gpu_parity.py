@@ -40,6 +40,8 @@ def assert_bit_exact(got, ref, what):
     ("materialtest/c5.json", (128, 72), 16, 8),
     ("materialtest/c5_absorb.json", (128, 72), 8, 8),
     ("cornell-box/scene_fog.json", (96, 54), 16, 16),      # camera medium + quad light
+    # the fork's example scene: non-exponential media behind ForwardBsdf walls, 'power' lights, uniform sampler
+    ("non-exponential/scene.json", (128, 128), 16, 16),
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)
@@ -365,6 +367,7 @@ def test_cpp_host_integrator_cli_adaptive(ta, oracle_py, tmp_path):
     ("cornell-box/scene_fog.json", (96, 54), 8),
     ("instances/inst_mesh.json", (96, 54), 8),         # INST variants of extend / shadow
     ("materialtest/c1_noadapt.json", (128, 72), 8),
+    ("non-exponential/scene.json", (96, 96), 8),       # FWD variant of the shadow kernel (multi-segment walk)
 ])
 def test_wavefront_kernels_without_the_tail_kernel(ta, oracle_py, scene, res, spp, monkeypatch):
     """Small renders finish inside the tail megakernel; TGPU_TAIL_MAX=0 forces every bounce through the per-stage

@@ -133,6 +133,7 @@ struct DScene {
     const tgpu_medium *media; uint32_t nMedia;
     const uint32_t *expTable; // 1024 mantissas of 2^(i/1024)
     float expA, expB;         // 1024/logf(2), logf(2)/1024
+    int32_t hasForward;       // some BSDF has a ForwardLobe: shadow rays may pass through surfaces (TraceBase.cpp:62-125)
 };
 
 // prim id encoding shared with the C ABI: kind << 30 | index; 0xFFFFFFFF = miss
@@ -526,6 +527,7 @@ TG_DEV uint32_t baseLobes(int type)
 TG_DEV uint32_t bsdfLobes(const DScene &sc, const tgpu_bsdf &d)
 {
     if (d.type == TGPU_BSDF_SMOOTH_COAT) return SpecularReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);
+    if (d.type == TGPU_BSDF_FORWARD) return uint32_t(ForwardLobe); // ForwardBsdf.cpp:9-12
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) // RoughDielectricBsdf.cpp:38-41
         return d.enable_refraction ? uint32_t(GlossyReflectionLobe | GlossyTransmissionLobe) : uint32_t(GlossyReflectionLobe);
     return baseLobes(d.type);

@@ -63,6 +63,10 @@ struct DState {
     float4 *rayO;   // origin.xyz, tnear
     float4 *rayD;   // dir.xyz, tfar
     float4 *hit;                // t, u, v, bits(prim)
+    // only with forward-scattering surfaces (sc.hasForward): the factors of the two NEE terms, so that the shadow kernel can
+    // apply the transmittance where the reference does (e = shadow*E before f*e/pdf): shG = (E_L, pdf_L), shH = (mis_L, mis_B),
+    // shI = (weight_B); shC then holds f_L and shD E_B
+    float4 *shG, *shH, *shI;
     uint32_t *med;              // medium state: [7:0] medium + 1, [8] MediumState::firstScatter, [31:9] MediumState::bounce; only with media
     uint32_t *hitInst;          // instance of the hit (set << 24 | index) or INST_NONE; only with "instances" in the scene
     float4 *tp;     // throughput.xyz, bits(flags)
@@ -1050,12 +1054,132 @@ TG_DEV V3 fastExp(const DScene &sc, const V3 &v)
     return V3(out[0], out[1], out[2]);
 }
 
-// HomogeneousMedium::transmittance (HomogeneousMedium.cpp:110-117) over a shadow segment that ends at farT; no medium: 1
-TG_DEV V3 neeTransmittance(const DScene &sc, int medium, float farT)
+// ---- transmittance models (transmittances/*.cpp).  form: 0 surfaceSurface, 1 surfaceMedium, 2 mediumSurface,
+// 3 mediumMedium; Transmittance.hpp:22-42 picks the form from where the segment starts and ends
+TG_DEV V3 vmin1(const V3 &a) { return V3(fmin2(a.x, 1.0f), fmin2(a.y, 1.0f), fmin2(a.z, 1.0f)); }
+TG_DEV V3 transForm(const DScene &sc, const tgpu_medium &m, int form, const V3 &tau)
+{
+    switch (m.transmittance) {
+    case TGPU_TRANS_LINEAR: { // LinearTransmittance.cpp:30-59
+        const float maxT = m.param[0];
+        if (form == 0) return V3(1.0f) - vmin1(tau/maxT);
+        float r[3], tv[3] = {tau.x, tau.y, tau.z};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (form == 1) r[i] = tv[i] > maxT ? 0.0f : 1.0f/maxT;
+            else if (form == 2) r[i] = tv[i] > maxT ? 0.0f : 1.0f;
+            else r[i] = __builtin_fabsf(tv[i] - maxT) < 1e-3f ? 1.0f : 0.0f;
+        }
+        return V3(r[0], r[1], r[2]);
+    }
+    case TGPU_TRANS_QUADRATIC: { // QuadraticTransmittance.cpp:30-51
+        const float maxT = m.param[0];
+        if (form == 0) { V3 t = vmin1(tau/maxT); return V3(1.0f) - 2.0f*t + t*t; }
+        if (form == 1) return (2.0f/maxT)*(V3(1.0f) - vmin1(tau/maxT));
+        if (form == 2) return V3(1.0f) - vmin1(tau/maxT);
+        return V3(tau.x > maxT ? 0.0f : 1.0f/maxT, tau.y > maxT ? 0.0f : 1.0f/maxT, tau.z > maxT ? 0.0f : 1.0f/maxT);
+    }
+    case TGPU_TRANS_DOUBLE_EXPONENTIAL: { // DoubleExponentialTransmittance.cpp:34-49
+        const float sa = m.param[0], sb = m.param[1];
+        V3 ea = expV3(-sa*tau), eb = expV3(-sb*tau);
+        if (form == 0) return 0.5f*(ea + eb);
+        if (form == 1) return 0.5f*(sa*ea + sb*eb);
+        if (form == 2) return (sa*ea + sb*eb)/(sa + sb);
+        return ((sa*sa)*ea + (sb*sb)*eb)/(sa + sb);
+    }
+    case TGPU_TRANS_PULSE: { // PulseTransmittance.cpp:43-81
+        const float a = m.param[0], b = m.param[1];
+        const int numPulses = int(m.param[2]);
+        float tv[3] = {tau.x, tau.y, tau.z}, res[3];
+        if (form == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float f = clampf((float(numPulses)*(tv[i] - a))/(b - a) + 0.5f, 0.0f, float(numPulses));
+                int idx = int(f);
+                float height = float(numPulses - idx)/float(numPulses);
+                float cellIntegral = height*(f - float(idx));
+                if (idx > 0) cellIntegral += (idx - 0.5f) - (idx*(idx - 1))/(2.0f*numPulses);
+                else cellIntegral -= 0.5f;
+                res[i] = 1.0f - (2.0f/numPulses)*cellIntegral;
+            }
+            return V3(res[0], res[1], res[2]);
+        }
+        if (form == 1 || form == 2) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int idx = int((float(numPulses)*(tv[i] - a))/(b - a) + 0.5f);
+                idx = idx < 0 ? 0 : (idx > numPulses ? numPulses : idx);
+                res[i] = 1.0f - float(idx)/float(numPulses);
+            }
+            V3 ms(res[0], res[1], res[2]);
+            return form == 1 ? 2.0f/(b - a)*ms : ms;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float f = clampf((float(numPulses)*(tv[i] - a))/(b - a), 0.0f, float(numPulses));
+            int idx = int(f);
+            res[i] = __builtin_fabsf(f - idx - 0.5f) < 1e-3f ? 1.0f : 0.0f;
+        }
+        return (1.0f/numPulses)*V3(res[0], res[1], res[2]);
+    }
+    default: return fastExp(sc, -tau); // ExponentialTransmittance.cpp:26-41: all four forms
+    }
+}
+TG_DEV float transSigmaBar(const tgpu_medium &m)
+{
+    switch (m.transmittance) {
+    case TGPU_TRANS_LINEAR: return 1.0f/m.param[0];
+    case TGPU_TRANS_QUADRATIC: return 2.0f/m.param[0];
+    case TGPU_TRANS_DOUBLE_EXPONENTIAL: return 0.5f*(m.param[0] + m.param[1]);
+    case TGPU_TRANS_PULSE: return 2.0f/(m.param[1] - m.param[0]);
+    default: return 1.0f;
+    }
+}
+TG_DEV V3 transEval(const DScene &sc, const tgpu_medium &m, const V3 &tau, bool startOnSurface, bool endOnSurface)
+{   // Transmittance::eval (Transmittance.hpp:22-30)
+    if (startOnSurface && endOnSurface) return transForm(sc, m, 0, tau);
+    if (!startOnSurface && !endOnSurface) return transForm(sc, m, 3, tau)/transSigmaBar(m);
+    return transForm(sc, m, 2, tau);
+}
+TG_DEV float transSample(const tgpu_medium &m, Sampler &smp, bool startOnSurface)
+{   // sampleSurface / sampleMedium of the model
+    switch (m.transmittance) {
+    case TGPU_TRANS_LINEAR: return startOnSurface ? m.param[0]*smp.next1D() : m.param[0];
+    case TGPU_TRANS_QUADRATIC:
+        return startOnSurface ? m.param[0]*(1.0f - __builtin_sqrtf(1.0f - smp.next1D())) : m.param[0]*smp.next1D();
+    case TGPU_TRANS_DOUBLE_EXPONENTIAL: {
+        float t = -tgpu_logf(1.0f - smp.next1D());
+        float p = startOnSurface ? 0.5f : m.param[0]/(m.param[0] + m.param[1]);
+        return smp.nextBoolean(p) ? t/m.param[0] : t/m.param[1];
+    }
+    case TGPU_TRANS_PULSE: {
+        const float a = m.param[0], b = m.param[1];
+        const int numPulses = int(m.param[2]);
+        if (!startOnSurface) return a + (0.5f + int(smp.next1D()*numPulses))/float(numPulses)*(b - a);
+        float xi = smp.next1D()*numPulses*0.5f;
+        float delta = 1.0f/numPulses;
+        for (int i = 0; i < numPulses; ++i) {
+            float h0 = 1.0f - (i + 0.0f)*delta;
+            float h1 = 1.0f - (i + 1.0f)*delta;
+            xi -= h0*0.5f;
+            if (xi < 0.0f) return a + (i + 0.0f + 0.5f*smp.next1D())*(b - a)*delta;
+            xi -= h1*0.5f;
+            if (xi < 0.0f) return a + (i + 0.5f + 0.5f*smp.next1D())*(b - a)*delta;
+        }
+        return 0.0f;
+    }
+    default: return -tgpu_logf(1.0f - smp.next1D());
+    }
+}
+
+// HomogeneousMedium::transmittance (HomogeneousMedium.cpp:110-117) over a shadow segment that ends (on a surface) at
+// farT; no medium: 1
+TG_DEV V3 neeTransmittance(const DScene &sc, int medium, float farT, bool startOnSurface)
 {
     if (medium < 0) return V3(1.0f);
     if (farT == TG_INF) return V3(0.0f);
-    return fastExp(sc, -(V3(sc.media[medium].sigma_t)*farT));
+    const tgpu_medium &m = sc.media[medium];
+    return transEval(sc, m, V3(m.sigma_t)*farT, startOnSurface, true);
 }
 
 template <int CLASS, bool MEDIA>
@@ -1108,21 +1232,21 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
         ok = false;
     } else if (m.absorption_only) {
         if (maxT == TG_INF) ok = false;
-        else weight = fastExp(sc, -(t*sigmaT));
+        else weight = transEval(sc, m, t*sigmaT, firstScatter, true);
     } else {
         int component = smp.nextDiscrete(3);
         float sigmaTc = component == 0 ? sigmaT.x : (component == 1 ? sigmaT.y : sigmaT.z);
-        float ts = -tgpu_logf(1.0f - smp.next1D())/sigmaTc; // ExponentialTransmittance::sampleSurface/sampleMedium
+        float ts = transSample(m, smp, firstScatter)/sigmaTc;
         t = fmin2(ts, maxT);
         exited = ts >= maxT;
         V3 tau = t*sigmaT;
-        weight = fastExp(sc, -tau);
+        weight = transEval(sc, m, tau, firstScatter, exited);
         float pdf;
         if (exited) {
-            pdf = fastExp(sc, -tau).avg();
+            pdf = transForm(sc, m, firstScatter ? 0 : 2, tau).avg();          // surfaceProbability
         } else {
-            pdf = (sigmaT*fastExp(sc, -tau)).avg();
-            weight *= sigmaS*1.0f;
+            pdf = (sigmaT*transForm(sc, m, firstScatter ? 1 : 3, tau)).avg(); // sigmaT*mediumPdf
+            weight *= sigmaS*transSigmaBar(m);
         }
         weight /= pdf;
         firstScatter = false; // MediumState::advance
@@ -1149,11 +1273,15 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
 
     // ---- handleVolume ----
     const bool volumeNee = sc.settings.enable_volume_light_sampling != 0;
+    const bool fwdScene = sc.hasForward != 0;
+    const int neeBounce = bounce + 1;
     const V3 p = O + t*D;
     wasSpecular = !volumeNee;
     V3 L(0.0f), B(0.0f);
     float tfarL = -1.0f, tfarB = -1.0f, pickWeight = 1.0f;
     V3 dL(0.0f), dB(0.0f);
+    V3 fL(0.0f), EL(0.0f), EB(0.0f), wB(0.0f);
+    float pdfL = 1.0f, misL = 0.0f, misB = 0.0f;
     uint32_t endCap = PRIM_MISS;
     const V3 tpVertex = tp;
     if (volumeNee && bounce < maxBounces - 1 && sc.nLights > 0) {
@@ -1184,13 +1312,15 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                             E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
                         }
                     }
-                    E = neeTransmittance(sc, medium, farT)*E;
+                    if (!fwdScene) E = neeTransmittance(sc, medium, farT, false)*E;
                     if (lit && shadowPasses && !E.isZero()) {
                         V3 lightF = f*E/ls.pdf;
-                        lightF *= powerHeuristic(ls.pdf, INV_FOUR_PI);
+                        const float mis = powerHeuristic(ls.pdf, INV_FOUR_PI);
+                        lightF *= mis;
                         L = lightF;
                         dL = ls.d;
                         tfarL = farT;
+                        fL = f; EL = E; pdfL = ls.pdf; misL = mis;
                     }
                 }
             }
@@ -1222,13 +1352,15 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                         lightPdf = tq*tq/(cosTheta*lq.area);
                     }
                 }
-                E = neeTransmittance(sc, medium, farT)*E;
+                if (!fwdScene) E = neeTransmittance(sc, medium, farT, false)*E;
                 if (lit && shadowPasses && !E.isZero()) {
                     V3 phaseF = E*V3(1.0f);
-                    phaseF *= powerHeuristic(INV_FOUR_PI, lightPdf);
+                    const float mis = powerHeuristic(INV_FOUR_PI, lightPdf);
+                    phaseF *= mis;
                     B = phaseF;
                     dB = w;
                     tfarB = farT;
+                    EB = E; wB = V3(1.0f); misB = mis;
                 }
             }
         }
@@ -1274,9 +1406,16 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     if (pushShadow) {
         st.shA[path] = mk4(dL, tfarL);
         st.shB[path] = mk4(dB, tfarB);
-        st.shC[path] = mk4(L, pickWeight);
-        st.shD[path] = mk4u(B, endCap);
-        st.shE[path] = mk4u(tpVertex, 0u);
+        st.shC[path] = mk4(fwdScene ? fL : L, pickWeight);
+        st.shD[path] = mk4u(fwdScene ? EB : B, endCap);
+        if (fwdScene) {
+            st.shG[path] = mk4(EL, pdfL);
+            st.shH[path] = make_float4(misL, misB, 0.0f, 0.0f);
+            st.shI[path] = mk4(wB, 0.0f);
+        }
+        // both rays start inside `medium`, not on a surface (startsOnSurface bit 2 clear)
+        st.shE[path] = mk4u(tpVertex, fwdScene ? ((uint32_t(medium + 1) << 8) | (uint32_t(medium + 1) << 16)) : 0u);
+        if (fwdScene) st.shF[path] = mk4(V3(0.0f), __uint_as_float(uint32_t(neeBounce)));
     }
     st.em[path] = mk4u(em, smp.scramble);
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
@@ -1345,18 +1484,24 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         ev.flippedFrame = flipFrame;
         ev.sampledLobe = 0;
 
-        // handleSurface (TraceBase.cpp:516-568): forward-lobe test draws from the supplemental
-        // stream for every surface hit; none of the BSDFs in scope has a forward lobe -> pTrue = 0
-        (void)smp.nextBoolean(0.0f);
+        // handleSurface (TraceBase.cpp:516-568): the forward-lobe test draws from the supplemental stream for every surface
+        // hit.  transparency = bsdf.eval(forward event): (1,1,1) for a ForwardBsdf (ForwardBsdf.cpp:26-29; avg() == 1.0f),
+        // zero for every other BSDF in scope
+        const bool passThrough = smp.nextBoolean((lobes & ForwardLobe) ? 1.0f : 0.0f);
+        const bool fwdScene = sc.hasForward != 0; // shadow rays may cross surfaces: the shadow kernel applies the media
+        int mediumL = -1, mediumB = -1;
 
         const float eps = 5e-4f; // TraceableScene.hpp:39
         V3 L(0.0f), B(0.0f);
         float tfarL = -1.0f, tfarB = -1.0f, pickWeight = 1.0f;
         V3 dL(0.0f), dB(0.0f);
+        V3 fL(0.0f), EL(0.0f), EB(0.0f), wB(0.0f);
+        float pdfL = 1.0f, misL = 0.0f, misB = 0.0f;
         uint32_t endCap = PRIM_MISS;
         const V3 tpVertex = tp;
+        const int neeBounce = bounce + 1; // estimateDirect(event, medium, bounce + 1, ...)
 
-        if (neeEnabled && bounce < maxBounces - 1 && sc.nLights > 0) {
+        if (!passThrough && neeEnabled && bounce < maxBounces - 1 && sc.nLights > 0) {
             // estimateDirect -> chooseLight (TraceBase.cpp:416-459)
             int lightIdx = chooseLight(sc, info.p, smp, pickWeight);
             bool haveLight = lightIdx >= 0;
@@ -1400,13 +1545,18 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
                                 }
                             }
                             // generalizedShadowRay: the medium on the light's side attenuates the unoccluded segment (:261-262, :100-108)
-                            if (media) E = neeTransmittance(sc, overridesMedia ? (ls.d.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium, farT)*E;
+                            if (media) {
+                                mediumL = overridesMedia ? (ls.d.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium;
+                                if (!fwdScene) E = neeTransmittance(sc, mediumL, farT, true)*E;
+                            }
                             if (lit && shadowPasses && !E.isZero()) {
                                 V3 lightF = f*E/ls.pdf;
-                                lightF *= powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
+                                const float mis = powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
+                                lightF *= mis;
                                 L = lightF;
                                 dL = ls.d;
                                 tfarL = farT;
+                                fL = f; EL = E; pdfL = ls.pdf; misL = mis;
                             }
                         }
                     }
@@ -1443,13 +1593,18 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
                                     lightPdf = tq*tq/(cosTheta*lq.area);
                                 }
                             }
-                            if (media) E = neeTransmittance(sc, overridesMedia ? (wo.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium, farT)*E; // :301-302
+                            if (media) { // :301-302
+                                mediumB = overridesMedia ? (wo.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium;
+                                if (!fwdScene) E = neeTransmittance(sc, mediumB, farT, true)*E;
+                            }
                             if (lit && shadowPasses && !E.isZero()) {
                                 V3 bsdfF = E*ev.weight;
-                                bsdfF *= powerHeuristic(ev.pdf, lightPdf);
+                                const float mis = powerHeuristic(ev.pdf, lightPdf);
+                                bsdfF *= mis;
                                 B = bsdfF;
                                 dB = wo;
                                 tfarB = farT;
+                                EB = E; wB = ev.weight; misB = mis;
                             }
                         }
                     }
@@ -1461,7 +1616,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         // emitter hit (TraceBase.cpp:540-543): added after the NEE term, as the reference does
         V3 postAdd(0.0f);
         bool hasPostAdd = false;
-        if (info.emissive && bounce >= minBounces) {
+        if (!passThrough && info.emissive && bounce >= minBounces) {
             if (!neeEnabled || wasSpecular) { // every emissive primitive in scope is samplable
                 V3 Ed = info.backSide ? V3(0.0f) : texEval(sc, info.emissionTex, info.uvx, info.uvy);
                 postAdd = Ed*tp;
@@ -1472,9 +1627,14 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
 
         // continuation (TraceBase.cpp:546-565)
         ev.requestedLobe = AllLobes;
-        bool sampled = bsdfSample(sc, bsdf, ev, smp);
+        bool sampled = !passThrough && bsdfSample(sc, bsdf, ev, smp);
         V3 wo(0.0f);
         bool alive = sampled;
+        if (passThrough) { // wo = ray.dir(); weight = transparency/transparencyScalar = 1; sampledLobe = ForwardLobe
+            wo = D;
+            alive = true;
+            ev.weight = V3(1.0f);
+        }
         if (sampled) {
             wo = ev.frame.toGlobal(ev.wo);
             if (sc.settings.enable_consistency_checks) {
@@ -1492,7 +1652,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
             end = END_RAW; // handleSurface returned false -> `return emission`
         } else {
             tp *= ev.weight;
-            wasSpecular = (ev.sampledLobe & SpecularLobe) != 0;
+            if (!passThrough) wasSpecular = (ev.sampledLobe & SpecularLobe) != 0;
             // PathTracer.cpp:108-126
             if (tp.max() == 0.0f) {
                 end = END_CHECKED; // break: the environment term is throughput(=0)*E
@@ -1525,11 +1685,21 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         if (pushShadow) {
             st.shA[path] = mk4(dL, tfarL);
             st.shB[path] = mk4(dB, tfarB);
-            st.shC[path] = mk4(L, pickWeight);
-            st.shD[path] = mk4u(B, endCap);
-            st.shE[path] = mk4u(tpVertex, (hasPostAdd ? 1u : 0u) | (neeOriginMoved ? 2u : 0u));
-            if (hasPostAdd) st.shF[path] = mk4(postAdd, 0.0f);
-            else if (neeOriginMoved) st.shF[path] = mk4(info.p, 0.0f);
+            st.shC[path] = mk4(fwdScene ? fL : L, pickWeight);
+            st.shD[path] = mk4u(fwdScene ? EB : B, endCap);
+            if (fwdScene) {
+                st.shG[path] = mk4(EL, pdfL);
+                st.shH[path] = make_float4(misL, misB, 0.0f, 0.0f);
+                st.shI[path] = mk4(wB, 0.0f);
+            }
+            // with forward-scattering surfaces in the scene the shadow kernel walks the segments itself and needs the
+            // media the two rays start in, startsOnSurface (bit 2) and the bounce argument (shF.w)
+            const uint32_t fwdBits = fwdScene ? (4u | (uint32_t(mediumL + 1) << 8) | (uint32_t(mediumB + 1) << 16)) : 0u;
+            st.shE[path] = mk4u(tpVertex, (hasPostAdd ? 1u : 0u) | (neeOriginMoved ? 2u : 0u) | fwdBits);
+            const float bounceBits = __uint_as_float(uint32_t(neeBounce));
+            if (hasPostAdd) st.shF[path] = mk4(postAdd, bounceBits);
+            else if (neeOriginMoved) st.shF[path] = mk4(info.p, bounceBits);
+            else if (fwdScene) st.shF[path] = mk4(V3(0.0f), bounceBits);
         }
         st.em[path] = mk4u(em, smp.scramble);
     }
@@ -1560,7 +1730,62 @@ __global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, int set
 //   emission += ((0 + L*visL) + B*visB) * weight * throughput   (TraceBase.cpp:383-400,483-494,537-538)
 // =================================================================================================
 // Both NEE rays of the path's current vertex, then the resolve (body of the shadow kernel and of the tail kernel)
+// generalizedShadowRayImpl<false> (TraceBase.cpp:62-125) for scenes with forward-scattering surfaces: closest hit per
+// segment; a surface with a ForwardLobe lets the ray through (ForwardBsdf::eval == 1) and may switch the medium, anything
+// else blocks; every segment is attenuated by the medium it runs in (Transmittance::eval with the start / end flags).
 template <bool COUNT, bool INST>
+TG_DEV V3 shadowWalk(const DScene &sc, uint32_t *stack, V3 O, const V3 &D, float tnear, float tfar, uint32_t endCap, int medium, bool startsOnSurface,
+                     int bounce, TraceCounters &tc, uint32_t &rays)
+{
+    float initialFarT = tfar;
+    V3 throughput(1.0f);
+    while (true) {
+        rays++;
+        float t = tfar, u = 0.0f, v = 0.0f;
+        uint32_t inst;
+        const uint32_t prim = closestHit<COUNT, INST>(sc, stack, O, D, tnear, t, u, v, inst, tc);
+        const bool isEnd = prim == PRIM_MISS || (inst == INST_NONE && prim == endCap);
+        int intMedium = -1, extMedium = -1;
+        bool backSide = false;
+        if (!isEnd) {
+            const uint32_t kind = primKind(prim), idx = primIndex(prim);
+            int bsdf;
+            if (kind == KIND_TRI) {
+                const float4 s3 = sc.triShade[size_t(idx)*5 + 3], s4 = sc.triShade[size_t(idx)*5 + 4];
+                bsdf = int(__float_as_uint(s3.w) & 0x7FFFFFFFu);
+                const uint32_t mb = __float_as_uint(s4.w);
+                intMedium = int(mb >> 16) - 1;
+                extMedium = int(mb & 0xFFFFu) - 1;
+                backSide = V3(s4.x, s4.y, s4.z).dot(D) > 0.0f; // TriangleMesh.cpp:331
+            } else if (kind == KIND_QUAD) {
+                const tgpu_quad &q = sc.quads[idx];
+                bsdf = q.bsdf; intMedium = q.int_medium; extMedium = q.ext_medium;
+                backSide = D.dot(V3(q.normal)) >= 0.0f;        // Quad.cpp:93
+            } else {
+                const tgpu_cube &cb = sc.cubes[idx];
+                bsdf = cb.bsdf; intMedium = cb.int_medium; extMedium = cb.ext_medium;
+                float tc2 = 0.0f; // Cube.cpp:113-124: the front face if it lies past nearT, else the back face
+                bool front = cubeIntersect(cb, O, D, tnear, TG_INF, tc2, backSide);
+                if (!front || tc2 != t) backSide = true;
+            }
+            if (inst != INST_NONE) { intMedium = extMedium = -1; }
+            if (!(bsdfLobes(sc, sc.bsdfs[bsdf]) & ForwardLobe)) return V3(0.0f);
+            // transparency = eval(forward event) = 1
+            bounce++;
+            if (bounce >= sc.settings.max_bounces) return V3(0.0f);
+        }
+        if (medium >= 0) throughput *= neeTransmittance(sc, medium, t, startsOnSurface);
+        if (isEnd) return bounce >= sc.settings.min_bounces ? throughput : V3(0.0f);
+        if (intMedium >= 0 || extMedium >= 0) medium = !backSide ? intMedium : extMedium; // selectMedium(medium, !hitBackside(data))
+        startsOnSurface = true;
+        O = O + D*t; // ray.hitpoint()
+        initialFarT -= t;
+        tnear = 5e-4f;
+        tfar = initialFarT;
+    }
+}
+
+template <bool COUNT, bool INST, bool FWD>
 TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint32_t path, TraceCounters &tc, uint32_t &rays)
 {
     float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
@@ -1568,13 +1793,37 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
     if (INST && (__float_as_uint(e.w) & 2u)) O = xyz(ldStream(&st.shF[path])); // info.p of an instance hit (shadePath)
     uint32_t endCap = __float_as_uint(d.w);
     V3 result(0.0f);
-    if (a.w >= 0.0f) {
-        rays++;
-        if (!occluded<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
-    }
-    if (b.w >= 0.0f) {
-        rays++;
-        if (!occluded<COUNT, INST>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
+    if (FWD) {
+        const uint32_t bits = __float_as_uint(e.w);
+        const bool startsOnSurface = (bits & 4u) != 0;
+        const int mediumL = int((bits >> 8) & 0xFFu) - 1, mediumB = int((bits >> 16) & 0xFFu) - 1;
+        const int bounce = int(__float_as_uint(ldStream(&st.shF[path]).w));
+        const float4 g = ldStream(&st.shG[path]), h = ldStream(&st.shH[path]);
+        if (a.w >= 0.0f) { // lightSample: e = shadow*E; lightF = f*e/pdf; lightF *= mis (TraceBase.cpp:272-283)
+            V3 eL = shadowWalk<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, mediumL, startsOnSurface, bounce, tc, rays)*xyz(g);
+            if (!eL.isZero()) {
+                V3 lightF = xyz(c)*eL/g.w;
+                lightF *= h.x;
+                result += lightF;
+            }
+        }
+        if (b.w >= 0.0f) { // bsdfSample: bsdfF = e*weight; bsdfF *= mis (:309-318)
+            V3 eB = shadowWalk<COUNT, INST>(sc, stack, O, xyz(b), ro.w, b.w, endCap, mediumB, startsOnSurface, bounce, tc, rays)*xyz(d);
+            if (!eB.isZero()) {
+                V3 bsdfF = eB*xyz(ldStream(&st.shI[path]));
+                bsdfF *= h.y;
+                result += bsdfF;
+            }
+        }
+    } else {
+        if (a.w >= 0.0f) {
+            rays++;
+            if (!occluded<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
+        }
+        if (b.w >= 0.0f) {
+            rays++;
+            if (!occluded<COUNT, INST>(sc, stack, O, xyz(b), ro.w, b.w, endCap, tc)) result += xyz(d);
+        }
     }
     float4 emw = ldStream(&st.em[path]);
     V3 em = xyz(emw);
@@ -1583,7 +1832,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
     stStream(&st.em[path], make_float4(em.x, em.y, em.z, emw.w));
 }
 
-template <bool COUNT, bool INST>
+template <bool COUNT, bool INST, bool FWD>
 __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -1601,7 +1850,7 @@ __global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
         uint32_t idx = base + lane;
         uint32_t path = 0;
         // no `continue` here: the dequeue above must be executed by the whole wave together
-        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) shadowPath<COUNT, INST>(sc, st, stack, path, tc, rays);
+        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) shadowPath<COUNT, INST, FWD>(sc, st, stack, path, tc, rays);
     }
     if (COUNT) flushCounters(st.stats, 2, tc);
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
@@ -1628,7 +1877,7 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
 // ..., using exactly the per-path functions of the wavefront kernels (so the bits do not change), then
 // retires it.  Every slot of the lists ends on the free list.
 // =================================================================================================
-template <bool COUNT, bool INST>
+template <bool COUNT, bool INST, bool FWD>
 __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -1655,13 +1904,13 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
                 if (sc.nMedia && (st.med[slot] & 0xFFu)) {
                     volumePath(sc, st, slot);
                     events++;
-                    if (st.shFlag[slot]) shadowPath<COUNT, INST>(sc, st, stack, slot, tcS, shRays);
+                    if (st.shFlag[slot]) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
                 } else if (prim == PRIM_MISS) {
                     missPath(sc, st, slot);
                 } else {
                     shadePath<-1, true>(sc, st, slot);
                     events++;
-                    if (st.shFlag[slot]) shadowPath<COUNT, INST>(sc, st, stack, slot, tcS, shRays);
+                    if (st.shFlag[slot]) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
                 }
             }
             float4 tpw = st.tp[slot];

@@ -214,6 +214,14 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
     if (s->tri_media)
         for (uint32_t i = 0; i < s->n_tris + s->n_master_tris; ++i)
             if (!mediumOk(s->tri_media[size_t(i)*2]) || !mediumOk(s->tri_media[size_t(i)*2 + 1])) { fail(ctx, "triangle %u: bad medium", i); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_media; ++i) {
+        const tgpu_medium &m = s->media[i];
+        bool ok = m.transmittance >= TGPU_TRANS_EXPONENTIAL && m.transmittance <= TGPU_TRANS_PULSE;
+        if ((m.transmittance == TGPU_TRANS_LINEAR || m.transmittance == TGPU_TRANS_QUADRATIC) && !(m.param[0] > 0.0f)) ok = false;
+        if (m.transmittance == TGPU_TRANS_DOUBLE_EXPONENTIAL && !(m.param[0] > 0.0f && m.param[1] > 0.0f)) ok = false;
+        if (m.transmittance == TGPU_TRANS_PULSE && !(m.param[1] > m.param[0] && m.param[2] >= 1.0f && m.param[2] <= 4096.0f)) ok = false;
+        if (!ok) { fail(ctx, "medium %u: bad transmittance model / parameters", i); return TGPU_ERR_INVALID; }
+    }
     for (uint32_t i = 0; i < s->n_media; ++i)
         if (s->media[i].max_bounce < 0 || s->media[i].max_bounce >= (1 << 22)) { fail(ctx, "medium %u: max_bounces out of range", i); return TGPU_ERR_UNSUPPORTED; }
     for (uint32_t i = 0; i < s->n_bsdfs; ++i)
@@ -485,6 +493,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.quads = dQuads; sc.nQuads = s->n_quads;
     sc.cubes = dCubes; sc.nCubes = s->n_cubes;
     sc.bsdfs = dBsdfs;
+    sc.hasForward = 0;
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type == TGPU_BSDF_FORWARD) sc.hasForward = 1;
     sc.textures = dTex;
     sc.lights = dLights; sc.nLights = s->n_lights;
     {   // media + the table of fmath::exp_ps (fmath.hpp:106-126: a = n/logf(2), b = logf(2)/n, tbl[i] = mantissa(pow(2.0f, i/n)))
@@ -621,6 +631,11 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
     if (sc.nInstSets && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.hitInst))) return rc;
     if (sc.nMedia && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.med))) return rc;
+    if (sc.hasForward) {
+        float4 **fw[] = {&st.shG, &st.shH, &st.shI};
+        for (float4 **pp : fw)
+            if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
+    }
     {
         std::vector<uint32_t> ident(cap);
         for (uint64_t i = 0; i < cap; ++i) ident[i] = uint32_t(i);
@@ -751,13 +766,20 @@ static int driveIteration(tgpu_ctx *ctx)
     if (tail) {
         Timer t(ctx, &ctx->stats.other_ms);
         int grid = gridFor(ctx, nCur);
-        if (sc.nInstSets) {
-            if (count) hipLaunchKernelGGL((k_tail<true, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-            else hipLaunchKernelGGL((k_tail<false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-        } else {
-            if (count) hipLaunchKernelGGL((k_tail<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-            else hipLaunchKernelGGL((k_tail<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+        // variants: COUNT (visit counters), INST ("instances" in the scene), FWD (forward-scattering surfaces: shadow walk)
+        const int variant = (count ? 4 : 0) | (sc.nInstSets ? 2 : 0) | (sc.hasForward ? 1 : 0);
+#define TG_LAUNCH_TAIL(C, I, F) hipLaunchKernelGGL((k_tail<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur)
+        switch (variant) {
+        case 0: TG_LAUNCH_TAIL(false, false, false); break;
+        case 1: TG_LAUNCH_TAIL(false, false, true); break;
+        case 2: TG_LAUNCH_TAIL(false, true, false); break;
+        case 3: TG_LAUNCH_TAIL(false, true, true); break;
+        case 4: TG_LAUNCH_TAIL(true, false, false); break;
+        case 5: TG_LAUNCH_TAIL(true, false, true); break;
+        case 6: TG_LAUNCH_TAIL(true, true, false); break;
+        default: TG_LAUNCH_TAIL(true, true, true); break;
         }
+#undef TG_LAUNCH_TAIL
         // every listed slot ends on the free list: both list sets are empty afterwards
         (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0), 0, 2*TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
         ctx->stats.tail_launches++;
@@ -783,24 +805,32 @@ static int driveIteration(tgpu_ctx *ctx)
                 hipLaunchKernelGGL((k_shade<2, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
                 hipLaunchKernelGGL((k_shade<3, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
                 hipLaunchKernelGGL((k_shade<4, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<5, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
             } else {
                 hipLaunchKernelGGL((k_shade<0, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
                 hipLaunchKernelGGL((k_shade<1, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
                 hipLaunchKernelGGL((k_shade<2, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
                 hipLaunchKernelGGL((k_shade<3, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
                 hipLaunchKernelGGL((k_shade<4, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
+                hipLaunchKernelGGL((k_shade<5, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
             }
             if (sc.nMedia) hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out);
         }
         {
             Timer t(ctx, &ctx->stats.shadow_ms);
-            if (sc.nInstSets) {
-                if (count) hipLaunchKernelGGL((k_shadow<true, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
-                else hipLaunchKernelGGL((k_shadow<false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
-            } else {
-                if (count) hipLaunchKernelGGL((k_shadow<true, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
-                else hipLaunchKernelGGL((k_shadow<false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+            const int variant = (count ? 4 : 0) | (sc.nInstSets ? 2 : 0) | (sc.hasForward ? 1 : 0);
+#define TG_LAUNCH_SHADOW(C, I, F) hipLaunchKernelGGL((k_shadow<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out)
+            switch (variant) {
+            case 0: TG_LAUNCH_SHADOW(false, false, false); break;
+            case 1: TG_LAUNCH_SHADOW(false, false, true); break;
+            case 2: TG_LAUNCH_SHADOW(false, true, false); break;
+            case 3: TG_LAUNCH_SHADOW(false, true, true); break;
+            case 4: TG_LAUNCH_SHADOW(true, false, false); break;
+            case 5: TG_LAUNCH_SHADOW(true, false, true); break;
+            case 6: TG_LAUNCH_SHADOW(true, true, false); break;
+            default: TG_LAUNCH_SHADOW(true, true, true); break;
             }
+#undef TG_LAUNCH_SHADOW
         }
         ctx->stats.shadow_launches++;
         {

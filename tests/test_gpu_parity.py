@@ -386,3 +386,22 @@ def test_wavefront_kernels_without_the_tail_kernel(ta, oracle_py, scene, res, sp
         ctx.close()
     ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, spp, spp_step=spp)
     assert_bit_exact(got, ref, f"{scene} wavefront-only")
+
+
+def test_cli_renders_the_unmodified_non_exponential_scene(ta, oracle_py, tmp_path):
+    """The reference's own data/example-scenes/non-exponential/scene.json, byte for byte as it ships (512x512, uniform
+    sampler, adaptive sampling on, max_bounces 3), through the C++ Integrator mirror; only --spp is lowered."""
+    import subprocess
+    from conftest import REPO, ASSETS
+    scene_file = scene_path("non-exponential/scene.json")
+    exe = os.path.join(REPO, "tungsten_amd", "tungsten_amd_cli")
+    r = subprocess.run([exe, "-d", str(tmp_path), "--spp", "64", "-e", "out.pfm", scene_file], capture_output=True, text=True,
+                       env=dict(os.environ, TUNGSTEN_AMD_ASSETS=ASSETS))
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = ta.load_pfm(tmp_path / "out.pfm")
+    assert img.shape == (512, 512, 3)
+    hs = ta.HostScene(scene_file)
+    assert hs.adaptive and not hs.use_sobol
+    ref, cnt, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(64, spp_step=16, adaptive=True)
+    assert cnt.min() < 64 < cnt.max()
+    assert np.array_equal(img, ref)

@@ -67,7 +67,11 @@ enum {
     TGPU_BSDF_NULL = 3,             /* NullBsdf.cpp (light carriers)    */
     TGPU_BSDF_ROUGH_DIELECTRIC = 4, /* RoughDielectricBsdf.cpp:55-280   */
     TGPU_BSDF_FORWARD = 5,          /* ForwardBsdf.cpp:9-36 (index-matched medium boundaries) */
-    TGPU_BSDF_NUM_CLASSES = 6
+    TGPU_BSDF_NUM_CLASSES = 6,      /* types 0..5 get a shade kernel of their own; the ones below share one */
+    TGPU_BSDF_MIRROR = 6,           /* MirrorBsdf.cpp:16-60              */
+    TGPU_BSDF_DIELECTRIC = 7,       /* DielectricBsdf.cpp:50-190 (ior, enable_refraction) */
+    TGPU_BSDF_CONDUCTOR = 8,        /* ConductorBsdf.cpp:53-90 (eta, k)  */
+    TGPU_BSDF_NUM_TYPES = 9
 };
 enum { TGPU_DIST_BECKMANN = 0, TGPU_DIST_PHONG = 1, TGPU_DIST_GGX = 2 };
 

@@ -1335,6 +1335,9 @@ uint32_t oracle_ctx::bsdfLobes(int b) const
     case TGPU_BSDF_ROUGH_CONDUCTOR: return GlossyReflectionLobe;
     case TGPU_BSDF_SMOOTH_COAT: return SpecularReflectionLobe | bsdfLobes(d.substrate);
     case TGPU_BSDF_FORWARD: return ForwardLobe; // ForwardBsdf.cpp:9-12
+    case TGPU_BSDF_MIRROR: case TGPU_BSDF_CONDUCTOR: return SpecularReflectionLobe;
+    case TGPU_BSDF_DIELECTRIC: // DielectricBsdf.cpp:181-188
+        return d.enable_refraction ? (SpecularReflectionLobe | SpecularTransmissionLobe) : SpecularReflectionLobe;
     case TGPU_BSDF_ROUGH_DIELECTRIC: // RoughDielectricBsdf.cpp:38-41
         return d.enable_refraction ? (GlossyReflectionLobe | GlossyTransmissionLobe) : GlossyReflectionLobe;
     default: return 0;
@@ -1440,6 +1443,11 @@ inline bool checkReflectionConstraint(const V3 &wi, const V3 &wo) // bsdfs/Bsdf.
 {
     return std::abs(wi.z*wo.z - wi.x*wo.x - wi.y*wo.y - 1.0f) < 1e-3f;
 }
+inline bool checkRefractionConstraint(const V3 &wi, const V3 &wo, float eta, float cosThetaT) // bsdfs/Bsdf.hpp:50-54
+{
+    float dotP = -wi.x*wo.x*eta - wi.y*wo.y*eta - std::copysign(cosThetaT, wi.z)*wo.z;
+    return std::abs(dotP - 1.0f) < 1e-3f;
+}
 inline Event warped(const Event &e, const V3 &wi, const V3 &wo) { Event c = e; c.wi = wi; c.wo = wo; return c; }
 } // namespace
 
@@ -1466,6 +1474,30 @@ V3 oracle_ctx::bsdfEval(int b, const Event &e) const
         float D = mf.D(alpha, hr);
         float fr = (G*D*0.25f)/e.wi.z;
         return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*fr);
+    }
+    case TGPU_BSDF_MIRROR: { // bsdfs/MirrorBsdf.cpp:40-47
+        if ((e.requestedLobe & SpecularReflectionLobe) && checkReflectionConstraint(e.wi, e.wo)) return texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        return V3(0.0f);
+    }
+    case TGPU_BSDF_CONDUCTOR: { // bsdfs/ConductorBsdf.cpp:66-73
+        if ((e.requestedLobe & SpecularReflectionLobe) && checkReflectionConstraint(e.wi, e.wo))
+            return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*conductorReflectance3(d.eta, d.k, e.wi.z);
+        return V3(0.0f);
+    }
+    case TGPU_BSDF_DIELECTRIC: { // bsdfs/DielectricBsdf.cpp:92-112 ; eval(event, false) *= sqr(eta)
+        bool evalR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool evalT = (e.requestedLobe & SpecularTransmissionLobe) != 0 && d.enable_refraction;
+        float eta = e.wi.z < 0.0f ? d.ior : 1.0f/d.ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(eta, std::abs(e.wi.z), cosThetaT);
+        V3 f(0.0f);
+        if (e.wi.z*e.wo.z >= 0.0f) {
+            if (evalR && checkReflectionConstraint(e.wi, e.wo)) f = F*texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        } else {
+            if (evalT && checkRefractionConstraint(e.wi, e.wo, eta, cosThetaT)) f = (1.0f - F)*texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        }
+        f *= dielectricEtaSq(d.ior, e.wi, e.wo);
+        return f;
     }
     case TGPU_BSDF_FORWARD: { // bsdfs/ForwardBsdf.cpp:26-29
         bool isForward = (e.requestedLobe & ForwardLobe) != 0; // BsdfLobes::isForward
@@ -1572,6 +1604,49 @@ bool oracle_ctx::bsdfSample(int b, Event &e) const
         e.pdf = pdf;
         e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*weight);
         e.sampledLobe = GlossyReflectionLobe;
+        return true;
+    }
+    case TGPU_BSDF_MIRROR: { // bsdfs/MirrorBsdf.cpp:29-38
+        if (!(e.requestedLobe & SpecularReflectionLobe)) return false;
+        e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+        e.pdf = 1.0f;
+        e.sampledLobe = SpecularReflectionLobe;
+        e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        return true;
+    }
+    case TGPU_BSDF_CONDUCTOR: { // bsdfs/ConductorBsdf.cpp:53-64
+        if (!(e.requestedLobe & SpecularReflectionLobe)) return false;
+        e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+        e.pdf = 1.0f;
+        e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*conductorReflectance3(d.eta, d.k, e.wi.z);
+        e.sampledLobe = SpecularReflectionLobe;
+        return true;
+    }
+    case TGPU_BSDF_DIELECTRIC: { // bsdfs/DielectricBsdf.cpp:50-90 ; sample(event, false) *= sqr(eta)
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & SpecularTransmissionLobe) != 0 && d.enable_refraction;
+        float eta = e.wi.z < 0.0f ? d.ior : 1.0f/d.ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(eta, std::abs(e.wi.z), cosThetaT);
+        float reflectionProbability;
+        if (sampleR && sampleT) reflectionProbability = F;
+        else if (sampleR) reflectionProbability = 1.0f;
+        else if (sampleT) reflectionProbability = 0.0f;
+        else return false;
+        if (e.sampler->nextBoolean(reflectionProbability)) {
+            e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+            e.pdf = reflectionProbability;
+            e.sampledLobe = SpecularReflectionLobe;
+            e.weight = sampleT ? V3(1.0f) : V3(F);
+        } else {
+            if (F == 1.0f) return false;
+            e.wo = V3(-e.wi.x*eta, -e.wi.y*eta, -std::copysign(cosThetaT, e.wi.z));
+            e.pdf = 1.0f - reflectionProbability;
+            e.sampledLobe = SpecularTransmissionLobe;
+            e.weight = sampleR ? V3(1.0f) : V3(1.0f - F);
+        }
+        e.weight *= texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        e.weight *= dielectricEtaSq(d.ior, e.wi, e.wo);
         return true;
     }
     case TGPU_BSDF_ROUGH_DIELECTRIC: { // bsdfs/RoughDielectricBsdf.cpp:55-131 (sampleBase), :232-240
@@ -1699,6 +1774,21 @@ float oracle_ctx::bsdfPdf(int b, const Event &e) const
         float sampleAlpha = roughnessToAlpha(roughness);
         V3 hr = (e.wi + e.wo).normalized();
         return mf.pdf(sampleAlpha, hr)*0.25f/e.wi.dot(hr);
+    }
+    case TGPU_BSDF_MIRROR: case TGPU_BSDF_CONDUCTOR: // MirrorBsdf.cpp:58-65, ConductorBsdf.cpp:80-87
+        return ((e.requestedLobe & SpecularReflectionLobe) && checkReflectionConstraint(e.wi, e.wo)) ? 1.0f : 0.0f;
+    case TGPU_BSDF_DIELECTRIC: { // bsdfs/DielectricBsdf.cpp:148-168
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & SpecularTransmissionLobe) != 0 && d.enable_refraction;
+        float eta = e.wi.z < 0.0f ? d.ior : 1.0f/d.ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(eta, std::abs(e.wi.z), cosThetaT);
+        if (e.wi.z*e.wo.z >= 0.0f) {
+            if (sampleR && checkReflectionConstraint(e.wi, e.wo)) return sampleT ? F : 1.0f;
+            return 0.0f;
+        }
+        if (sampleT && checkRefractionConstraint(e.wi, e.wo, eta, cosThetaT)) return sampleR ? 1.0f - F : 1.0f;
+        return 0.0f;
     }
     case TGPU_BSDF_ROUGH_DIELECTRIC: { // bsdfs/RoughDielectricBsdf.cpp:198-234 (pdfBase)
         bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;

@@ -42,6 +42,10 @@ def assert_bit_exact(got, ref, what):
     ("cornell-box/scene_fog.json", (96, 54), 16, 16),      # camera medium + quad light
     # the fork's example scene: non-exponential media behind ForwardBsdf walls, 'power' lights, uniform sampler
     ("non-exponential/scene.json", (128, 128), 16, 16),
+    # specular BSDFs (shared generic shade kernel)
+    ("next/mirror.json", (128, 72), 8, 8),
+    ("next/dielectric.json", (128, 72), 8, 8),
+    ("next/conductor.json", (128, 72), 8, 8),
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)

@@ -23,6 +23,9 @@ CASES = [
     ("c5_128x72_16spp", "materialtest/c5.json", (128, 72), 16),
     ("c5_absorb_128x72_8spp", "materialtest/c5_absorb.json", (128, 72), 8),  # absorption only + beckmann glass
     ("cornell_fog_96x54_8spp", "cornell-box/scene_fog.json", (96, 54), 8),   # camera medium, quad light: finite transmittance
+    ("mirror_128x72_4spp", "next/mirror.json", (128, 72), 4),
+    ("dielectric_128x72_4spp", "next/dielectric.json", (128, 72), 4),
+    ("conductor_128x72_4spp", "next/conductor.json", (128, 72), 4),
 ]
 
 

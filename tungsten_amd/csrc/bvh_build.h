@@ -9,7 +9,7 @@
 //   q2 = (c1.lo.z, c1.hi.x, c1.hi.y, c1.hi.z)
 //   q3 = (bits child0, bits child1, 0, 0)
 // child >= 0: inner node index; child < 0: leaf, payload = child & 0x7FFFFFFF =
-// (firstTri << 2) | (count - 1), count in 1..4, triangles stored in BVH order.
+// (firstTri << 3) | (count - 1), count in 1..8, triangles stored in BVH order.
 // Triangle layout (48 B = 3 x float4), Embree's precomputed form
 // (thirdparty/embree/kernels/geometry/triangle.h:53-54): v0, e1 = v0-v1, e2 = v2-v0, Ng = e1 x e2
 //   t0 = (v0.x, v0.y, v0.z, e1.x)  t1 = (e1.y, e1.z, e2.x, e2.y)  t2 = (e2.z, Ng.x, Ng.y, Ng.z)
@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -87,7 +88,14 @@ public:
 
 private:
     static constexpr int Bins = 32;
-    static constexpr uint32_t MaxLeaf = 4;
+    // leaves hold 1..8 triangles (3 bits of the payload); TGPU_BVH_LEAF=1..8 sets the limit (experiments)
+    uint32_t MaxLeaf = leafLimit();
+    static uint32_t leafLimit()
+    {
+        const char *e = std::getenv("TGPU_BVH_LEAF");
+        int v = e ? std::atoi(e) : 4;
+        return uint32_t(v < 1 ? 1 : (v > 8 ? 8 : v));
+    }
 
     int32_t makeLeaf(uint32_t first, uint32_t count, Box &box)
     {
@@ -106,7 +114,7 @@ private:
             _out->tris.push_back({e2[2], ng[0], ng[1], ng[2]});
             _out->triId.push_back(id);
         }
-        return int32_t(0x80000000u | (start << 2) | (count - 1));
+        return int32_t(0x80000000u | (start << 3) | (count - 1));
     }
 
     int32_t recurse(uint32_t first, uint32_t count, int depth, Box &box)

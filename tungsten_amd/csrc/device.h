@@ -528,6 +528,9 @@ TG_DEV uint32_t bsdfLobes(const DScene &sc, const tgpu_bsdf &d)
 {
     if (d.type == TGPU_BSDF_SMOOTH_COAT) return SpecularReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);
     if (d.type == TGPU_BSDF_FORWARD) return uint32_t(ForwardLobe); // ForwardBsdf.cpp:9-12
+    if (d.type == TGPU_BSDF_MIRROR || d.type == TGPU_BSDF_CONDUCTOR) return uint32_t(SpecularReflectionLobe);
+    if (d.type == TGPU_BSDF_DIELECTRIC) // DielectricBsdf.cpp:181-188
+        return d.enable_refraction ? uint32_t(SpecularReflectionLobe | SpecularTransmissionLobe) : uint32_t(SpecularReflectionLobe);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) // RoughDielectricBsdf.cpp:38-41
         return d.enable_refraction ? uint32_t(GlossyReflectionLobe | GlossyTransmissionLobe) : uint32_t(GlossyReflectionLobe);
     return baseLobes(d.type);
@@ -745,11 +748,94 @@ TG_DEV bool dielectricSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sam
     return true;
 }
 
+// ---- the specular BSDFs: MirrorBsdf.cpp:29-65, ConductorBsdf.cpp:53-87, DielectricBsdf.cpp:50-190 ----------------
+TG_DEV bool checkRefractionConstraint(const V3 &wi, const V3 &wo, float eta, float cosThetaT) // bsdfs/Bsdf.hpp:50-54
+{
+    float dotP = -wi.x*wo.x*eta - wi.y*wo.y*eta - __builtin_copysignf(cosThetaT, wi.z)*wo.z;
+    return __builtin_fabsf(dotP - 1.0f) < 1e-3f;
+}
+TG_DEV V3 specularEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    if (d.type == TGPU_BSDF_DIELECTRIC) {
+        bool evalR = (requested & SpecularReflectionLobe) != 0;
+        bool evalT = (requested & SpecularTransmissionLobe) != 0 && d.enable_refraction;
+        float eta = wi.z < 0.0f ? d.ior : 1.0f/d.ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(eta, __builtin_fabsf(wi.z), cosThetaT);
+        V3 f(0.0f);
+        if (wi.z*wo.z >= 0.0f) {
+            if (evalR && checkReflectionConstraint(wi, wo)) f = F*texEval(sc, d.albedo_tex, uvx, uvy);
+        } else {
+            if (evalT && checkRefractionConstraint(wi, wo, eta, cosThetaT)) f = (1.0f - F)*texEval(sc, d.albedo_tex, uvx, uvy);
+        }
+        f *= dielectricEtaSq(d.ior, wi, wo);
+        return f;
+    }
+    if (!((requested & SpecularReflectionLobe) && checkReflectionConstraint(wi, wo))) return V3(0.0f);
+    if (d.type == TGPU_BSDF_MIRROR) return texEval(sc, d.albedo_tex, uvx, uvy);
+    return texEval(sc, d.albedo_tex, uvx, uvy)*conductorReflectance3(d.eta, d.k, wi.z);
+}
+TG_DEV float specularPdf(const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested)
+{
+    if (d.type == TGPU_BSDF_DIELECTRIC) {
+        bool sampleR = (requested & SpecularReflectionLobe) != 0;
+        bool sampleT = (requested & SpecularTransmissionLobe) != 0 && d.enable_refraction;
+        float eta = wi.z < 0.0f ? d.ior : 1.0f/d.ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(eta, __builtin_fabsf(wi.z), cosThetaT);
+        if (wi.z*wo.z >= 0.0f) {
+            if (sampleR && checkReflectionConstraint(wi, wo)) return sampleT ? F : 1.0f;
+            return 0.0f;
+        }
+        if (sampleT && checkRefractionConstraint(wi, wo, eta, cosThetaT)) return sampleR ? 1.0f - F : 1.0f;
+        return 0.0f;
+    }
+    return ((requested & SpecularReflectionLobe) && checkReflectionConstraint(wi, wo)) ? 1.0f : 0.0f;
+}
+TG_DEV bool specularSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{
+    if (d.type == TGPU_BSDF_DIELECTRIC) {
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & SpecularTransmissionLobe) != 0 && d.enable_refraction;
+        float eta = e.wi.z < 0.0f ? d.ior : 1.0f/d.ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectance(eta, __builtin_fabsf(e.wi.z), cosThetaT);
+        float reflectionProbability;
+        if (sampleR && sampleT) reflectionProbability = F;
+        else if (sampleR) reflectionProbability = 1.0f;
+        else if (sampleT) reflectionProbability = 0.0f;
+        else return false;
+        if (s.nextBoolean(reflectionProbability)) {
+            e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+            e.pdf = reflectionProbability;
+            e.sampledLobe = SpecularReflectionLobe;
+            e.weight = sampleT ? V3(1.0f) : V3(F);
+        } else {
+            if (F == 1.0f) return false;
+            e.wo = V3(-e.wi.x*eta, -e.wi.y*eta, -__builtin_copysignf(cosThetaT, e.wi.z));
+            e.pdf = 1.0f - reflectionProbability;
+            e.sampledLobe = SpecularTransmissionLobe;
+            e.weight = sampleR ? V3(1.0f) : V3(1.0f - F);
+        }
+        e.weight *= texEval(sc, d.albedo_tex, e.uvx, e.uvy);
+        e.weight *= dielectricEtaSq(d.ior, e.wi, e.wo);
+        return true;
+    }
+    if (!(e.requestedLobe & SpecularReflectionLobe)) return false;
+    e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+    e.pdf = 1.0f;
+    e.sampledLobe = SpecularReflectionLobe;
+    e.weight = texEval(sc, d.albedo_tex, e.uvx, e.uvy);
+    if (d.type == TGPU_BSDF_CONDUCTOR) e.weight = e.weight*conductorReflectance3(d.eta, d.k, e.wi.z);
+    return true;
+}
+
 TG_DEV V3 expV3(const V3 &a) { return V3(tgpu_expf(a.x), tgpu_expf(a.y), tgpu_expf(a.z)); }
 
 TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (d.type >= TGPU_BSDF_MIRROR) return specularEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:146-178
     if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
@@ -778,6 +864,7 @@ TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (d.type >= TGPU_BSDF_MIRROR) return specularPdf(d, e.wi, e.wo, e.requestedLobe);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return basePdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:180-215
     if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
@@ -810,6 +897,7 @@ TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricSample(sc, d, e, s);
+    if (d.type >= TGPU_BSDF_MIRROR) return specularSample(sc, d, e, s);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseSample(sc, d, e, s);
     // bsdfs/SmoothCoatBsdf.cpp:41-100
     if (e.wi.z <= 0.0f) return false;

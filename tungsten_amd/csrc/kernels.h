@@ -25,8 +25,9 @@ namespace tg {
 // The extend kernel reads the concatenation of the current set and writes the other set; every other
 // kernel works in place on the set extend just wrote, so a slot keeps its list entry while its path is
 // retired and the next sample is started in it.
-#define TG_LISTS (2 + TGPU_BSDF_NUM_CLASSES)
-#define TG_CLASS_VOLUME TGPU_BSDF_NUM_CLASSES /* paths whose ray travels inside a participating medium (hit or miss) */
+#define TG_LISTS (3 + TGPU_BSDF_NUM_CLASSES)
+#define TG_CLASS_OTHER TGPU_BSDF_NUM_CLASSES        /* BSDF types without a shade kernel of their own share the generic one */
+#define TG_CLASS_VOLUME (TGPU_BSDF_NUM_CLASSES + 1) /* paths whose ray travels inside a participating medium (hit or miss) */
 enum { CNT_LIST0 = 0 /* 2 x TG_LISTS list lengths */, CNT_HEAD_EXT = 2*TG_LISTS, CNT_HEAD_SHADOW = CNT_HEAD_EXT + 1,
        CNT_REGEN = CNT_HEAD_EXT + 2 /* samples claimed this iteration */,
        CNT_FREE = CNT_HEAD_EXT + 3 /* persistent: length of the free-slot list */,
@@ -436,7 +437,7 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
 #undef TG_CHILD
         } else {
             uint32_t payload = node & 0x7FFFFFFFu;
-            uint32_t first = payload >> 2, cnt = (payload & 3u) + 1u;
+            uint32_t first = payload >> 3, cnt = (payload & 7u) + 1u;
             for (uint32_t j = 0; j < cnt; ++j) {
                 const float4 *tp = sc.tris + size_t(first + j)*3;
                 float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
@@ -717,10 +718,11 @@ TG_DEV void flushCounters(unsigned long long *stats, int slot, const TraceCounte
 TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
 {
     if (prim == PRIM_MISS) return 0xFFu;
-    uint32_t kind = primKind(prim), idx = primIndex(prim);
-    if (kind == KIND_TRI) return sc.triClass[idx];
-    if (kind == KIND_QUAD) return uint32_t(sc.bsdfs[sc.quads[idx].bsdf].type);
-    return uint32_t(sc.bsdfs[sc.cubes[idx].bsdf].type);
+    uint32_t kind = primKind(prim), idx = primIndex(prim), type;
+    if (kind == KIND_TRI) type = sc.triClass[idx];
+    else if (kind == KIND_QUAD) type = uint32_t(sc.bsdfs[sc.quads[idx].bsdf].type);
+    else type = uint32_t(sc.bsdfs[sc.cubes[idx].bsdf].type);
+    return type < uint32_t(TG_CLASS_OTHER) ? type : uint32_t(TG_CLASS_OTHER);
 }
 
 // =================================================================================================
@@ -1713,7 +1715,8 @@ __global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + CLASS)];
     const uint32_t *list = st.lists[set][1 + CLASS];
     const uint32_t stride = gridDim.x*blockDim.x;
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) shadePath<CLASS, MEDIA>(sc, st, list[q]);
+    constexpr int KNOWN = CLASS < TG_CLASS_OTHER ? CLASS : -1; // the shared list holds several BSDF types
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) shadePath<KNOWN, MEDIA>(sc, st, list[q]);
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&st.stats[5], (unsigned long long)count);
 }
 

@@ -56,6 +56,7 @@ struct tgpu_ctx {
         bool adaptive = false;
         std::vector<uint32_t> offsets, vtIndex; // adaptive jobs: per-pixel sample offsets, per-tile sample index
     };
+    uint32_t classMask = 0;               // BSDF classes (shade kernels) the uploaded scene can hit
     bool trackRecords = false;            // settings.adaptive_sampling
     uint32_t varW = 0, varH = 0;
     std::vector<uint32_t> vtGlobal;       // local variance tile -> whole-image variance tile
@@ -159,7 +160,7 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
     if (s->camera.res_x == 0 || s->camera.res_y == 0) { fail(ctx, "camera resolution is zero"); return TGPU_ERR_INVALID; }
     if (s->n_tris && (!s->tri_pos || !s->tri_normal || !s->tri_uv || !s->tri_bsdf || !s->tri_smooth)) { fail(ctx, "triangle arrays missing"); return TGPU_ERR_INVALID; }
     if ((s->n_tris || s->n_master_tris) && (!s->tri_pos || !s->tri_normal || !s->tri_uv || !s->tri_bsdf || !s->tri_smooth)) { fail(ctx, "triangle arrays missing"); return TGPU_ERR_INVALID; }
-    if (uint64_t(s->n_tris) + s->n_master_tris >= (1u << 29)) { fail(ctx, "too many triangles (%u + %u)", s->n_tris, s->n_master_tris); return TGPU_ERR_UNSUPPORTED; }
+    if (uint64_t(s->n_tris) + s->n_master_tris >= (1u << 28)) { fail(ctx, "too many triangles (%u + %u)", s->n_tris, s->n_master_tris); return TGPU_ERR_UNSUPPORTED; }
     if (!s->sobol_matrices) { fail(ctx, "Sobol matrices missing"); return TGPU_ERR_INVALID; }
     if (s->n_lights > TG_MAX_LIGHTS) { fail(ctx, "more than %d samplable lights are not supported", TG_MAX_LIGHTS); return TGPU_ERR_UNSUPPORTED; }
     if (s->settings.max_bounces < 0 || s->settings.max_bounces > 0xFFFF) { fail(ctx, "max_bounces out of range"); return TGPU_ERR_INVALID; }
@@ -173,7 +174,7 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         if (s->bitmaps[i].w <= 0 || s->bitmaps[i].h <= 0 || !s->bitmaps[i].texels) { fail(ctx, "bitmap %u is empty", i); return TGPU_ERR_INVALID; }
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) {
         const tgpu_bsdf &b = s->bsdfs[i];
-        if (b.type < 0 || b.type >= TGPU_BSDF_NUM_CLASSES) { fail(ctx, "bsdf %u has type %d outside the hot-path scope", i, b.type); return TGPU_ERR_UNSUPPORTED; }
+        if (b.type < 0 || b.type >= TGPU_BSDF_NUM_TYPES) { fail(ctx, "bsdf %u has type %d outside the hot-path scope", i, b.type); return TGPU_ERR_UNSUPPORTED; }
         if (!texOk(b.albedo_tex)) { fail(ctx, "bsdf %u: bad albedo texture", i); return TGPU_ERR_INVALID; }
         if (b.type == TGPU_BSDF_ROUGH_CONDUCTOR && !texOk(b.roughness_tex)) { fail(ctx, "bsdf %u: bad roughness texture", i); return TGPU_ERR_INVALID; }
         if (b.type == TGPU_BSDF_ROUGH_CONDUCTOR && b.distribution == TGPU_DIST_PHONG) { fail(ctx, "bsdf %u: phong microfacet distribution is outside the hot-path scope", i); return TGPU_ERR_UNSUPPORTED; }
@@ -367,9 +368,9 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/3);
         auto rebase = [&](uint32_t ref) -> uint32_t {
             if (ref == 0xFFFFFFFFu) return ref;                               // empty slot
-            if (ref & 0x80000000u) {                                          // leaf: first << 2 | count - 1
+            if (ref & 0x80000000u) {                                          // leaf: first << 3 | count - 1
                 uint32_t payload = ref & 0x7FFFFFFFu;
-                return 0x80000000u | ((((payload >> 2) + triBase) << 2) | (payload & 3u));
+                return 0x80000000u | ((((payload >> 3) + triBase) << 3) | (payload & 7u));
             }
             return ref + nodeBase;
         };
@@ -494,6 +495,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.cubes = dCubes; sc.nCubes = s->n_cubes;
     sc.bsdfs = dBsdfs;
     sc.hasForward = 0;
+    ctx->classMask = 0;
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) ctx->classMask |= 1u << std::min<uint32_t>(uint32_t(s->bsdfs[i].type), uint32_t(TG_CLASS_OTHER));
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type == TGPU_BSDF_FORWARD) sc.hasForward = 1;
     sc.textures = dTex;
     sc.lights = dLights; sc.nLights = s->n_lights;
@@ -799,21 +802,12 @@ static int driveIteration(tgpu_ctx *ctx)
         {
             Timer t(ctx, &ctx->stats.shade_ms);
             hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st, out);
-            if (sc.nMedia) {
-                hipLaunchKernelGGL((k_shade<0, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<1, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<2, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<3, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<4, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<5, true>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-            } else {
-                hipLaunchKernelGGL((k_shade<0, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<1, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<2, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<3, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<4, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-                hipLaunchKernelGGL((k_shade<5, false>), dim3(grid), dim3(256), 0, stream, sc, st, out);
-            }
+            // one launch per BSDF class that occurs in the scene (ctx->classMask, set at upload)
+#define TG_LAUNCH_SHADE(C) if (ctx->classMask & (1u << (C))) { \
+                if (sc.nMedia) hipLaunchKernelGGL((k_shade<C, true>), dim3(grid), dim3(256), 0, stream, sc, st, out); \
+                else hipLaunchKernelGGL((k_shade<C, false>), dim3(grid), dim3(256), 0, stream, sc, st, out); }
+            TG_LAUNCH_SHADE(0) TG_LAUNCH_SHADE(1) TG_LAUNCH_SHADE(2) TG_LAUNCH_SHADE(3) TG_LAUNCH_SHADE(4) TG_LAUNCH_SHADE(5) TG_LAUNCH_SHADE(TG_CLASS_OTHER)
+#undef TG_LAUNCH_SHADE
             if (sc.nMedia) hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out);
         }
         {

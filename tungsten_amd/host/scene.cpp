@@ -458,6 +458,10 @@ static bool lookupComplexIor(const std::string &name, float *eta, float *k)
 {
     struct Entry { const char *name; float eta[3]; float k[3]; };
     static const Entry table[] = {
+        // measured complex IORs at R/G/B, the values of bsdfs/ComplexIorData.hpp:18-26 (data)
+        {"Ag", {0.1552646489f, 0.1167232965f, 0.1383806959f}, {4.8283433224f, 3.1222459278f, 2.1469504455f}},
+        {"Al", {1.6574599595f, 0.8803689579f, 0.5212287346f}, {9.2238691996f, 6.2695232477f, 4.8370012281f}},
+        {"Au", {0.1431189557f, 0.3749570432f, 1.4424785571f}, {3.9831604247f, 2.3857207478f, 1.6032152899f}},
         {"Cu", {0.2004376970f, 0.9240334304f, 1.1022119527f}, {3.9129485033f, 2.4528477015f, 2.1421879552f}},
     };
     for (const Entry &e : table) {
@@ -489,6 +493,24 @@ int Scene::parseBsdf(const Json &v)
         b.type = TGPU_BSDF_NULL;
     } else if (type == "forward") {
         b.type = TGPU_BSDF_FORWARD;
+    } else if (type == "mirror") {
+        b.type = TGPU_BSDF_MIRROR;
+    } else if (type == "dielectric") { // DielectricBsdf.cpp:34-40
+        b.type = TGPU_BSDF_DIELECTRIC;
+        b.ior = 1.5f;
+        v.getField("ior", b.ior);
+        bool enableT = true;
+        v.getField("enable_refraction", enableT);
+        b.enable_refraction = enableT ? 1 : 0;
+    } else if (type == "conductor") { // ConductorBsdf.cpp:14-38 (default material Cu)
+        b.type = TGPU_BSDF_CONDUCTOR;
+        std::string material;
+        const float defEta[3] = {0.200438f, 0.924033f, 1.10221f}, defK[3] = {3.91295f, 2.45285f, 2.14219f};
+        for (int i = 0; i < 3; ++i) { b.eta[i] = defEta[i]; b.k[i] = defK[i]; }
+        v.getVec("eta", b.eta, 3);
+        v.getVec("k", b.k, 3);
+        if (v.getField("material", material) && !lookupComplexIor(material, b.eta, b.k))
+            throw JsonLoadException("Unable to find material with name '" + material + "'");
     } else if (type == "rough_conductor") { // RoughConductorBsdf.cpp:14-45
         b.type = TGPU_BSDF_ROUGH_CONDUCTOR;
         std::string material;

@@ -71,7 +71,9 @@ enum {
     TGPU_BSDF_MIRROR = 6,           /* MirrorBsdf.cpp:16-60              */
     TGPU_BSDF_DIELECTRIC = 7,       /* DielectricBsdf.cpp:50-190 (ior, enable_refraction) */
     TGPU_BSDF_CONDUCTOR = 8,        /* ConductorBsdf.cpp:53-90 (eta, k)  */
-    TGPU_BSDF_NUM_TYPES = 9
+    TGPU_BSDF_PLASTIC = 9,          /* PlasticBsdf.cpp:45-195 (ior, thickness, sigma_a) */
+    TGPU_BSDF_ROUGH_PLASTIC = 10,   /* RoughPlasticBsdf.cpp:55-260 (+ distribution, roughness) */
+    TGPU_BSDF_NUM_TYPES = 11
 };
 enum { TGPU_DIST_BECKMANN = 0, TGPU_DIST_PHONG = 1, TGPU_DIST_GGX = 2 };
 
@@ -88,6 +90,8 @@ typedef struct tgpu_bsdf {
     float   scaled_sigma_a[3];   /* thickness*sigma_a   (SmoothCoatBsdf.cpp:217-223, */
     float   avg_transmittance;   /* exp(-2*avg(scaled)) baked at prepareForRender)   */
     int32_t enable_refraction;   /* rough_dielectric "enable_refraction" (default 1)  */
+    float   diffuse_fresnel;     /* plastics: Fresnel::computeDiffuseFresnel(ior, 1000000) (Fresnel.hpp:141-153) */
+    float   substrate_weight;    /* rough_plastic: albedo->average().avg() (RoughPlasticBsdf.cpp:252-258) */
 } tgpu_bsdf;
 
 /* ---- participating media (src/core/media) ------------------------------- */

@@ -294,6 +294,10 @@ struct oracle_ctx {
     V3 bsdfSampleNee(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
     V3 estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
     const tgpu_light *chooseLight(const V3 &p, Sampler &sampler, float &weight) const;
+    // RoughDielectricBsdf::sampleBase/evalBase/pdfBase (static helpers shared with RoughPlasticBsdf)
+    bool rdSampleBase(Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const;
+    V3 rdEvalBase(const Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const;
+    float rdPdfBase(const Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const;
     // media (media/HomogeneousMedium.cpp, transmittances/ExponentialTransmittance.cpp, phasefunctions/IsotropicPhaseFunction.cpp)
     V3 fastExp(const V3 &x) const;
     bool mediumSampleDistance(int medium, Sampler &sampler, const Ray &ray, struct MediumStateO &state, struct MediumSampleO &sample) const;
@@ -1336,6 +1340,8 @@ uint32_t oracle_ctx::bsdfLobes(int b) const
     case TGPU_BSDF_SMOOTH_COAT: return SpecularReflectionLobe | bsdfLobes(d.substrate);
     case TGPU_BSDF_FORWARD: return ForwardLobe; // ForwardBsdf.cpp:9-12
     case TGPU_BSDF_MIRROR: case TGPU_BSDF_CONDUCTOR: return SpecularReflectionLobe;
+    case TGPU_BSDF_PLASTIC: return SpecularReflectionLobe | DiffuseReflectionLobe;     // PlasticBsdf.cpp:19-24
+    case TGPU_BSDF_ROUGH_PLASTIC: return GlossyReflectionLobe | DiffuseReflectionLobe; // RoughPlasticBsdf.cpp:21-29
     case TGPU_BSDF_DIELECTRIC: // DielectricBsdf.cpp:181-188
         return d.enable_refraction ? (SpecularReflectionLobe | SpecularTransmissionLobe) : SpecularReflectionLobe;
     case TGPU_BSDF_ROUGH_DIELECTRIC: // RoughDielectricBsdf.cpp:38-41
@@ -1451,6 +1457,112 @@ inline bool checkRefractionConstraint(const V3 &wi, const V3 &wo, float eta, flo
 inline Event warped(const Event &e, const V3 &wi, const V3 &wo) { Event c = e; c.wi = wi; c.wo = wo; return c; }
 } // namespace
 
+bool oracle_ctx::rdSampleBase(Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const
+{   // bsdfs/RoughDielectricBsdf.cpp:55-131
+    MF mf{this, distribution};
+    float wiDotN = e.wi.z;
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    float sampleRoughness = (1.2f - 0.2f*std::sqrt(std::abs(wiDotN)))*roughness;
+    float alpha = roughnessToAlpha(roughness);
+    float sampleAlpha = roughnessToAlpha(sampleRoughness);
+    float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+    V3 m = mf.sample(sampleAlpha, xix, xiy);
+    float pm = mf.pdf(sampleAlpha, m);
+    if (pm < 1e-10f) return false;
+    float wiDotM = e.wi.dot(m);
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+    float etaM = wiDotM < 0.0f ? ior : 1.0f/ior;
+    bool reflect;
+    if (sampleR && sampleT) {
+        reflect = e.sampler->nextBoolean(F);
+    } else if (sampleT) {
+        if (F == 1.0f) return false;
+        reflect = false;
+    } else if (sampleR) {
+        reflect = true;
+    } else {
+        return false;
+    }
+    if (reflect) e.wo = 2.0f*wiDotM*m - e.wi;
+    else e.wo = (etaM*wiDotM - sgnE(wiDotM)*cosThetaT)*m - etaM*e.wi;
+    float woDotN = e.wo.z;
+    bool reflected = wiDotN*woDotN > 0.0f;
+    if (reflected != reflect) return false;
+    float woDotM = e.wo.dot(m);
+    float G = mf.G(alpha, e.wi, e.wo, m);
+    float D = mf.D(alpha, m);
+    e.weight = V3(std::abs(wiDotM)*G*D/(std::abs(wiDotN)*pm));
+    if (reflect) {
+        e.pdf = pm*0.25f/std::abs(wiDotM);
+        e.sampledLobe = GlossyReflectionLobe;
+    } else {
+        float q = eta*wiDotM + woDotM;
+        e.pdf = pm*std::abs(woDotM)/(q*q);
+        e.sampledLobe = GlossyTransmissionLobe;
+    }
+    if (sampleR && sampleT) {
+        if (reflect) e.pdf *= F; else e.pdf *= 1.0f - F;
+    } else {
+        if (reflect) e.weight *= F; else e.weight *= 1.0f - F;
+    }
+    return true;
+}
+
+V3 oracle_ctx::rdEvalBase(const Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const
+{   // bsdfs/RoughDielectricBsdf.cpp:133-164
+    float wiDotN = e.wi.z, woDotN = e.wo.z;
+    bool reflect = wiDotN*woDotN >= 0.0f;
+    if ((reflect && !sampleR) || (!reflect && !sampleT)) return V3(0.0f);
+    MF mf{this, distribution};
+    float alpha = roughnessToAlpha(roughness);
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    V3 m;
+    if (reflect) m = sgnE(wiDotN)*(e.wi + e.wo).normalized();
+    else m = -(e.wi*eta + e.wo).normalized();
+    float wiDotM = e.wi.dot(m), woDotM = e.wo.dot(m);
+    float cosThetaT;
+    float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+    float G = mf.G(alpha, e.wi, e.wo, m);
+    float D = mf.D(alpha, m);
+    if (reflect) {
+        float fr = (F*G*D*0.25f)/std::abs(wiDotN);
+        return V3(fr);
+    }
+    float q = eta*wiDotM + woDotM;
+    float fs = std::abs(wiDotM*woDotM)*(1.0f - F)*G*D/((q*q)*std::abs(wiDotN));
+    return V3(fs);
+}
+
+float oracle_ctx::rdPdfBase(const Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const
+{   // bsdfs/RoughDielectricBsdf.cpp:198-234
+    float wiDotN = e.wi.z, woDotN = e.wo.z;
+    bool reflect = wiDotN*woDotN >= 0.0f;
+    if ((reflect && !sampleR) || (!reflect && !sampleT)) return 0.0f;
+    MF mf{this, distribution};
+    float sampleRoughness = (1.2f - 0.2f*std::sqrt(std::abs(wiDotN)))*roughness;
+    float sampleAlpha = roughnessToAlpha(sampleRoughness);
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    V3 m;
+    if (reflect) m = sgnE(wiDotN)*(e.wi + e.wo).normalized();
+    else m = -(e.wi*eta + e.wo).normalized();
+    float wiDotM = e.wi.dot(m), woDotM = e.wo.dot(m);
+    float cosThetaT;
+    float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+    float pm = mf.pdf(sampleAlpha, m);
+    float pdf;
+    if (reflect) {
+        pdf = pm*0.25f/std::abs(wiDotM);
+    } else {
+        float q = eta*wiDotM + woDotM;
+        pdf = pm*std::abs(woDotM)/(q*q);
+    }
+    if (sampleR && sampleT) {
+        if (reflect) pdf *= F; else pdf *= 1.0f - F;
+    }
+    return pdf;
+}
+
 V3 oracle_ctx::bsdfEval(int b, const Event &e) const
 {
     if (b < 0) return V3(0.0f);
@@ -1474,6 +1586,45 @@ V3 oracle_ctx::bsdfEval(int b, const Event &e) const
         float D = mf.D(alpha, hr);
         float fr = (G*D*0.25f)/e.wi.z;
         return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*fr);
+    }
+    case TGPU_BSDF_PLASTIC: { // bsdfs/PlasticBsdf.cpp:139-163
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        bool evalR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool evalT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        float eta = 1.0f/d.ior;
+        float ct;
+        float Fi = dielectricReflectance(eta, e.wi.z, ct);
+        float Fo = dielectricReflectance(eta, e.wo.z, ct);
+        if (evalR && checkReflectionConstraint(e.wi, e.wo)) return V3(Fi);
+        if (evalT) {
+            V3 diffuseAlbedo = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+            V3 brdf = ((1.0f - Fi)*(1.0f - Fo)*eta*eta*e.wo.z*INV_PI)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel));
+            V3 ssa(d.scaled_sigma_a);
+            if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/e.wo.z - 1.0f/e.wi.z); brdf *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+            return brdf;
+        }
+        return V3(0.0f);
+    }
+    case TGPU_BSDF_ROUGH_PLASTIC: { // bsdfs/RoughPlasticBsdf.cpp:128-157
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!sampleR && !sampleT) return V3(0.0f);
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        V3 glossyR(0.0f);
+        if (sampleR) glossyR = rdEvalBase(e, true, false, roughness, d.ior, d.distribution);
+        V3 diffuseR(0.0f);
+        if (sampleT) {
+            float eta = 1.0f/d.ior;
+            float ct;
+            float Fi = dielectricReflectance(eta, e.wi.z, ct);
+            float Fo = dielectricReflectance(eta, e.wo.z, ct);
+            V3 diffuseAlbedo = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+            diffuseR = ((1.0f - Fi)*(1.0f - Fo)*eta*eta*e.wo.z*INV_PI)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel));
+            V3 ssa(d.scaled_sigma_a);
+            if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/e.wo.z - 1.0f/e.wi.z); diffuseR *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+        }
+        return glossyR + diffuseR;
     }
     case TGPU_BSDF_MIRROR: { // bsdfs/MirrorBsdf.cpp:40-47
         if ((e.requestedLobe & SpecularReflectionLobe) && checkReflectionConstraint(e.wi, e.wo)) return texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
@@ -1604,6 +1755,94 @@ bool oracle_ctx::bsdfSample(int b, Event &e) const
         e.pdf = pdf;
         e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(F*weight);
         e.sampledLobe = GlossyReflectionLobe;
+        return true;
+    }
+    case TGPU_BSDF_PLASTIC: { // bsdfs/PlasticBsdf.cpp:45-91
+        if (e.wi.z <= 0.0f) return false;
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        const V3 wi = e.wi;
+        float eta = 1.0f/d.ior;
+        float ct;
+        float Fi = dielectricReflectance(eta, wi.z, ct);
+        float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability;
+        if (sampleR && sampleT) specularProbability = specularWeight/(specularWeight + substrateWeight);
+        else if (sampleR) specularProbability = 1.0f;
+        else if (sampleT) specularProbability = 0.0f;
+        else return false;
+        if (sampleR && e.sampler->nextBoolean(specularProbability)) {
+            e.wo = V3(-wi.x, -wi.y, wi.z);
+            e.pdf = specularProbability;
+            e.weight = V3(Fi/specularProbability);
+            e.sampledLobe = SpecularReflectionLobe;
+        } else {
+            float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+            float phi = xix*TWO_PI; // SampleWarp::cosineHemisphere
+            float r = std::sqrt(xiy);
+            V3 wo(mcos(phi)*r, msin(phi)*r, std::sqrt(fmax2(1.0f - xiy, 0.0f)));
+            float Fo = dielectricReflectance(eta, wo.z, ct);
+            V3 diffuseAlbedo = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+            e.wo = wo;
+            e.weight = ((1.0f - Fi)*(1.0f - Fo)*eta*eta)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel));
+            V3 ssa(d.scaled_sigma_a);
+            if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/e.wo.z - 1.0f/e.wi.z); e.weight *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+            e.pdf = (std::abs(e.wo.z)*INV_PI)*(1.0f - specularProbability);
+            e.weight /= 1.0f - specularProbability;
+            e.sampledLobe = DiffuseReflectionLobe;
+        }
+        return true;
+    }
+    case TGPU_BSDF_ROUGH_PLASTIC: { // bsdfs/RoughPlasticBsdf.cpp:55-126
+        if (e.wi.z <= 0.0f) return false;
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!sampleR && !sampleT) return false;
+        const V3 wi = e.wi;
+        float eta = 1.0f/d.ior;
+        float ct;
+        float Fi = dielectricReflectance(eta, wi.z, ct);
+        float substrateWeight = d.substrate_weight*d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability = specularWeight/(specularWeight + substrateWeight);
+        if (sampleR && (e.sampler->nextBoolean(specularProbability) || !sampleT)) {
+            float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+            if (!rdSampleBase(e, true, false, roughness, d.ior, d.distribution)) return false;
+            if (sampleT) {
+                V3 diffuseAlbedo = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+                float Fo = dielectricReflectance(eta, e.wo.z, ct);
+                V3 brdfSubstrate = ((1.0f - Fi)*(1.0f - Fo)*eta*eta)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel))*INV_PI*e.wo.z;
+                V3 brdfSpecular = e.weight*e.pdf;
+                float pdfSubstrate = (std::abs(e.wo.z)*INV_PI)*(1.0f - specularProbability);
+                float pdfSpecular = e.pdf*specularProbability;
+                e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+                e.pdf = pdfSpecular + pdfSubstrate;
+            }
+            return true;
+        }
+        float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+        float phi = xix*TWO_PI;
+        float r = std::sqrt(xiy);
+        V3 wo(mcos(phi)*r, msin(phi)*r, std::sqrt(fmax2(1.0f - xiy, 0.0f)));
+        float Fo = dielectricReflectance(eta, wo.z, ct);
+        V3 diffuseAlbedo = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        e.wo = wo;
+        e.weight = ((1.0f - Fi)*(1.0f - Fo)*eta*eta)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel));
+        V3 ssa(d.scaled_sigma_a);
+        if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/e.wo.z - 1.0f/e.wi.z); e.weight *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+        e.pdf = std::abs(e.wo.z)*INV_PI;
+        if (sampleR) {
+            float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+            V3 brdfSubstrate = e.weight*e.pdf;
+            float pdfSubstrate = e.pdf*(1.0f - specularProbability);
+            V3 brdfSpecular = rdEvalBase(e, true, false, roughness, d.ior, d.distribution);
+            float pdfSpecular = rdPdfBase(e, true, false, roughness, d.ior, d.distribution);
+            pdfSpecular *= specularProbability;
+            e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+            e.pdf = pdfSpecular + pdfSubstrate;
+        }
+        e.sampledLobe = DiffuseReflectionLobe;
         return true;
     }
     case TGPU_BSDF_MIRROR: { // bsdfs/MirrorBsdf.cpp:29-38
@@ -1774,6 +2013,45 @@ float oracle_ctx::bsdfPdf(int b, const Event &e) const
         float sampleAlpha = roughnessToAlpha(roughness);
         V3 hr = (e.wi + e.wo).normalized();
         return mf.pdf(sampleAlpha, hr)*0.25f/e.wi.dot(hr);
+    }
+    case TGPU_BSDF_PLASTIC: { // bsdfs/PlasticBsdf.cpp:165-187
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        bool sampleR = (e.requestedLobe & SpecularReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (sampleR && sampleT) {
+            float ct;
+            float Fi = dielectricReflectance(1.0f/d.ior, e.wi.z, ct);
+            float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            if (checkReflectionConstraint(e.wi, e.wo)) return specularProbability;
+            return (std::abs(e.wo.z)*INV_PI)*(1.0f - specularProbability);
+        } else if (sampleT) {
+            return std::abs(e.wo.z)*INV_PI;
+        } else if (sampleR) {
+            return checkReflectionConstraint(e.wi, e.wo) ? 1.0f : 0.0f;
+        }
+        return 0.0f;
+    }
+    case TGPU_BSDF_ROUGH_PLASTIC: { // bsdfs/RoughPlasticBsdf.cpp:223-250
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!sampleR && !sampleT) return 0.0f;
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        float glossyPdf = 0.0f;
+        if (sampleR) glossyPdf = rdPdfBase(e, true, false, texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x, d.ior, d.distribution);
+        float diffusePdf = 0.0f;
+        if (sampleT) diffusePdf = std::abs(e.wo.z)*INV_PI;
+        if (sampleT && sampleR) {
+            float ct;
+            float Fi = dielectricReflectance(1.0f/d.ior, e.wi.z, ct);
+            float substrateWeight = d.substrate_weight*d.avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            diffusePdf *= (1.0f - specularProbability);
+            glossyPdf *= specularProbability;
+        }
+        return glossyPdf + diffusePdf;
     }
     case TGPU_BSDF_MIRROR: case TGPU_BSDF_CONDUCTOR: // MirrorBsdf.cpp:58-65, ConductorBsdf.cpp:80-87
         return ((e.requestedLobe & SpecularReflectionLobe) && checkReflectionConstraint(e.wi, e.wo)) ? 1.0f : 0.0f;

@@ -46,6 +46,8 @@ def assert_bit_exact(got, ref, what):
     ("next/mirror.json", (128, 72), 8, 8),
     ("next/dielectric.json", (128, 72), 8, 8),
     ("next/conductor.json", (128, 72), 8, 8),
+    ("next/plastic.json", (128, 72), 8, 8),
+    ("next/rough_plastic.json", (128, 72), 8, 8),
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)

@@ -26,6 +26,8 @@ CASES = [
     ("mirror_128x72_4spp", "next/mirror.json", (128, 72), 4),
     ("dielectric_128x72_4spp", "next/dielectric.json", (128, 72), 4),
     ("conductor_128x72_4spp", "next/conductor.json", (128, 72), 4),
+    ("plastic_128x72_4spp", "next/plastic.json", (128, 72), 4),
+    ("rough_plastic_128x72_4spp", "next/rough_plastic.json", (128, 72), 4),
 ]
 
 

@@ -25,7 +25,8 @@ class Bitmap(C.Structure):
 class Bsdf(C.Structure):
     _fields_ = [("type", i32), ("albedo_tex", i32), ("roughness_tex", i32), ("distribution", i32),
                 ("eta", f32*3), ("k", f32*3), ("ior", f32), ("thickness", f32), ("sigma_a", f32*3),
-                ("substrate", i32), ("scaled_sigma_a", f32*3), ("avg_transmittance", f32), ("enable_refraction", i32)]
+                ("substrate", i32), ("scaled_sigma_a", f32*3), ("avg_transmittance", f32), ("enable_refraction", i32),
+                ("diffuse_fresnel", f32), ("substrate_weight", f32)]
 
 
 class Medium(C.Structure):

@@ -432,6 +432,7 @@ struct Event { // samplerecords/SurfaceScatterEvent.hpp:14-66 (info fields folde
     bool flippedFrame;
 };
 
+TG_DEV V3 expV3(const V3 &a) { return V3(tgpu_expf(a.x), tgpu_expf(a.y), tgpu_expf(a.z)); }
 TG_DEV float roughnessToAlpha(float roughness) { return fmax2(roughness, 1e-3f); } // bsdfs/Microfacet.hpp:27-36
 
 // bsdfs/Microfacet.hpp:38-130 (Beckmann, GGX)
@@ -529,6 +530,8 @@ TG_DEV uint32_t bsdfLobes(const DScene &sc, const tgpu_bsdf &d)
     if (d.type == TGPU_BSDF_SMOOTH_COAT) return SpecularReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);
     if (d.type == TGPU_BSDF_FORWARD) return uint32_t(ForwardLobe); // ForwardBsdf.cpp:9-12
     if (d.type == TGPU_BSDF_MIRROR || d.type == TGPU_BSDF_CONDUCTOR) return uint32_t(SpecularReflectionLobe);
+    if (d.type == TGPU_BSDF_PLASTIC) return uint32_t(SpecularReflectionLobe | DiffuseReflectionLobe);
+    if (d.type == TGPU_BSDF_ROUGH_PLASTIC) return uint32_t(GlossyReflectionLobe | DiffuseReflectionLobe);
     if (d.type == TGPU_BSDF_DIELECTRIC) // DielectricBsdf.cpp:181-188
         return d.enable_refraction ? uint32_t(SpecularReflectionLobe | SpecularTransmissionLobe) : uint32_t(SpecularReflectionLobe);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) // RoughDielectricBsdf.cpp:38-41
@@ -544,55 +547,45 @@ TG_DEV float dielectricEtaSq(float ior, const V3 &wi, const V3 &wo)
     float eta = wi.z*wo.z >= 0.0f ? 1.0f : (wi.z < 0.0f ? ior : 1.0f/ior);
     return eta*eta;
 }
-TG_DEV V3 dielectricEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
-{   // evalBase :133-164, eval :242-249
-    bool sampleR = (requested & GlossyReflectionLobe) != 0;
-    bool sampleT = (requested & GlossyTransmissionLobe) != 0 && d.enable_refraction;
-    float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+// RoughDielectricBsdf::evalBase / pdfBase / sampleBase: static helpers RoughPlasticBsdf shares (:55-234)
+TG_DEV V3 rdEvalBase(const V3 &wi, const V3 &wo, bool sampleR, bool sampleT, float roughness, float ior, int distribution)
+{
     float wiDotN = wi.z, woDotN = wo.z;
     bool reflect = wiDotN*woDotN >= 0.0f;
     if ((reflect && !sampleR) || (!reflect && !sampleT)) return V3(0.0f);
     float alpha = roughnessToAlpha(roughness);
-    float eta = wiDotN < 0.0f ? d.ior : 1.0f/d.ior;
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
     V3 m;
     if (reflect) m = sgnE(wiDotN)*(wi + wo).normalized();
     else m = -(wi*eta + wo).normalized();
     float wiDotM = wi.dot(m), woDotM = wo.dot(m);
     float cosThetaT;
-    float F = dielectricReflectance(1.0f/d.ior, wiDotM, cosThetaT);
-    float G = mfG(d.distribution, alpha, wi, wo, m);
-    float D = mfD(d.distribution, alpha, m);
-    V3 f;
+    float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+    float G = mfG(distribution, alpha, wi, wo, m);
+    float D = mfD(distribution, alpha, m);
     if (reflect) {
         float fr = (F*G*D*0.25f)/__builtin_fabsf(wiDotN);
-        f = V3(fr);
-    } else {
-        float q = eta*wiDotM + woDotM;
-        float fs = __builtin_fabsf(wiDotM*woDotM)*(1.0f - F)*G*D/((q*q)*__builtin_fabsf(wiDotN));
-        f = V3(fs);
+        return V3(fr);
     }
-    f = f*texEval(sc, d.albedo_tex, uvx, uvy);
-    f *= dielectricEtaSq(d.ior, wi, wo);
-    return f;
+    float q = eta*wiDotM + woDotM;
+    float fs = __builtin_fabsf(wiDotM*woDotM)*(1.0f - F)*G*D/((q*q)*__builtin_fabsf(wiDotN));
+    return V3(fs);
 }
-TG_DEV float dielectricPdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
-{   // pdfBase :198-234
-    bool sampleR = (requested & GlossyReflectionLobe) != 0;
-    bool sampleT = (requested & GlossyTransmissionLobe) != 0 && d.enable_refraction;
-    float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+TG_DEV float rdPdfBase(const V3 &wi, const V3 &wo, bool sampleR, bool sampleT, float roughness, float ior, int distribution)
+{
     float wiDotN = wi.z, woDotN = wo.z;
     bool reflect = wiDotN*woDotN >= 0.0f;
     if ((reflect && !sampleR) || (!reflect && !sampleT)) return 0.0f;
     float sampleRoughness = (1.2f - 0.2f*__builtin_sqrtf(__builtin_fabsf(wiDotN)))*roughness;
     float sampleAlpha = roughnessToAlpha(sampleRoughness);
-    float eta = wiDotN < 0.0f ? d.ior : 1.0f/d.ior;
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
     V3 m;
     if (reflect) m = sgnE(wiDotN)*(wi + wo).normalized();
     else m = -(wi*eta + wo).normalized();
     float wiDotM = wi.dot(m), woDotM = wo.dot(m);
     float cosThetaT;
-    float F = dielectricReflectance(1.0f/d.ior, wiDotM, cosThetaT);
-    float pm = mfPdf(d.distribution, sampleAlpha, m);
+    float F = dielectricReflectance(1.0f/ior, wiDotM, cosThetaT);
+    float pm = mfPdf(distribution, sampleAlpha, m);
     float pdf;
     if (reflect) {
         pdf = pm*0.25f/__builtin_fabsf(wiDotM);
@@ -604,6 +597,23 @@ TG_DEV float dielectricPdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, c
         if (reflect) pdf *= F; else pdf *= 1.0f - F;
     }
     return pdf;
+}
+TG_DEV V3 dielectricEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{   // eval :242-249
+    bool sampleR = (requested & GlossyReflectionLobe) != 0;
+    bool sampleT = (requested & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+    float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+    V3 f = rdEvalBase(wi, wo, sampleR, sampleT, roughness, d.ior, d.distribution);
+    f = f*texEval(sc, d.albedo_tex, uvx, uvy);
+    f *= dielectricEtaSq(d.ior, wi, wo);
+    return f;
+}
+TG_DEV float dielectricPdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    bool sampleR = (requested & GlossyReflectionLobe) != 0;
+    bool sampleT = (requested & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+    float roughness = texEval(sc, d.roughness_tex, uvx, uvy).x;
+    return rdPdfBase(wi, wo, sampleR, sampleT, roughness, d.ior, d.distribution);
 }
 
 // Lambert (bsdfs/LambertBsdf.cpp:27-68) and RoughConductor (bsdfs/RoughConductorBsdf.cpp:60-143):
@@ -691,20 +701,16 @@ TG_DEV bool baseSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &
     return false;
 }
 
-TG_DEV bool dielectricSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
-{   // sampleBase :55-131, sample :232-240
-    bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
-    bool sampleT = (e.requestedLobe & GlossyTransmissionLobe) != 0 && d.enable_refraction;
-    float roughness = texEval(sc, d.roughness_tex, e.uvx, e.uvy).x;
-    const float ior = d.ior;
+TG_DEV bool rdSampleBase(Event &e, Sampler &s, bool sampleR, bool sampleT, float roughness, float ior, int distribution)
+{
     float wiDotN = e.wi.z;
     float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
     float sampleRoughness = (1.2f - 0.2f*__builtin_sqrtf(__builtin_fabsf(wiDotN)))*roughness;
     float alpha = roughnessToAlpha(roughness);
     float sampleAlpha = roughnessToAlpha(sampleRoughness);
     float xix = s.next1D(), xiy = s.next1D();
-    V3 m = mfSample(d.distribution, sampleAlpha, xix, xiy);
-    float pm = mfPdf(d.distribution, sampleAlpha, m);
+    V3 m = mfSample(distribution, sampleAlpha, xix, xiy);
+    float pm = mfPdf(distribution, sampleAlpha, m);
     if (pm < 1e-10f) return false;
     float wiDotM = e.wi.dot(m);
     float cosThetaT = 0.0f;
@@ -727,8 +733,8 @@ TG_DEV bool dielectricSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sam
     bool reflected = wiDotN*woDotN > 0.0f;
     if (reflected != reflect) return false;
     float woDotM = e.wo.dot(m);
-    float G = mfG(d.distribution, alpha, e.wi, e.wo, m);
-    float D = mfD(d.distribution, alpha, m);
+    float G = mfG(distribution, alpha, e.wi, e.wo, m);
+    float D = mfD(distribution, alpha, m);
     e.weight = V3(__builtin_fabsf(wiDotM)*G*D/(__builtin_fabsf(wiDotN)*pm));
     if (reflect) {
         e.pdf = pm*0.25f/__builtin_fabsf(wiDotM);
@@ -743,8 +749,166 @@ TG_DEV bool dielectricSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sam
     } else {
         if (reflect) e.weight *= F; else e.weight *= 1.0f - F;
     }
+    return true;
+}
+TG_DEV bool dielectricSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{   // sample :232-240
+    bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+    bool sampleT = (e.requestedLobe & GlossyTransmissionLobe) != 0 && d.enable_refraction;
+    float roughness = texEval(sc, d.roughness_tex, e.uvx, e.uvy).x;
+    if (!rdSampleBase(e, s, sampleR, sampleT, roughness, d.ior, d.distribution)) return false;
     e.weight *= texEval(sc, d.albedo_tex, e.uvx, e.uvy);
-    e.weight *= dielectricEtaSq(ior, e.wi, e.wo);
+    e.weight *= dielectricEtaSq(d.ior, e.wi, e.wo);
+    return true;
+}
+
+// ---- PlasticBsdf (bsdfs/PlasticBsdf.cpp:45-187) and RoughPlasticBsdf (bsdfs/RoughPlasticBsdf.cpp:55-250) ----------
+TG_DEV V3 plasticSubstrate(const DScene &sc, const tgpu_bsdf &d, float Fi, float Fo, float eta, float uvx, float uvy)
+{   // ((1 - Fi)*(1 - Fo)*eta*eta)*(albedo/(1 - albedo*diffuseFresnel))
+    V3 diffuseAlbedo = texEval(sc, d.albedo_tex, uvx, uvy);
+    return ((1.0f - Fi)*(1.0f - Fo)*eta*eta)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel));
+}
+TG_DEV V3 plasticAbsorption(const tgpu_bsdf &d, float wiz, float woz)
+{
+    V3 ssa(d.scaled_sigma_a);
+    return expV3(ssa*(-1.0f/woz - 1.0f/wiz));
+}
+TG_DEV V3 plasticEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    const bool rough = d.type == TGPU_BSDF_ROUGH_PLASTIC;
+    bool evalR = (requested & (rough ? GlossyReflectionLobe : SpecularReflectionLobe)) != 0;
+    bool evalT = (requested & DiffuseReflectionLobe) != 0;
+    if (rough && !evalR && !evalT) return V3(0.0f);
+    if (wi.z <= 0.0f || wo.z <= 0.0f) return V3(0.0f);
+    float eta = 1.0f/d.ior;
+    float ct;
+    float Fi = dielectricReflectance(eta, wi.z, ct);
+    float Fo = dielectricReflectance(eta, wo.z, ct);
+    V3 diffuseAlbedo = texEval(sc, d.albedo_tex, uvx, uvy);
+    V3 diffuse = ((1.0f - Fi)*(1.0f - Fo)*eta*eta*wo.z*INV_PI)*(diffuseAlbedo/(V3(1.0f) - diffuseAlbedo*d.diffuse_fresnel));
+    if (V3(d.scaled_sigma_a).max() > 0.0f) diffuse *= plasticAbsorption(d, wi.z, wo.z);
+    if (!rough) {
+        if (evalR && checkReflectionConstraint(wi, wo)) return V3(Fi);
+        return evalT ? diffuse : V3(0.0f);
+    }
+    V3 glossyR(0.0f);
+    if (evalR) glossyR = rdEvalBase(wi, wo, true, false, texEval(sc, d.roughness_tex, uvx, uvy).x, d.ior, d.distribution);
+    return glossyR + (evalT ? diffuse : V3(0.0f));
+}
+TG_DEV float plasticPdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    const bool rough = d.type == TGPU_BSDF_ROUGH_PLASTIC;
+    bool sampleR = (requested & (rough ? GlossyReflectionLobe : SpecularReflectionLobe)) != 0;
+    bool sampleT = (requested & DiffuseReflectionLobe) != 0;
+    if (rough && !sampleR && !sampleT) return 0.0f;
+    if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+    float ct;
+    float Fi = dielectricReflectance(1.0f/d.ior, wi.z, ct);
+    if (!rough) {
+        if (sampleR && sampleT) {
+            float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            if (checkReflectionConstraint(wi, wo)) return specularProbability;
+            return (__builtin_fabsf(wo.z)*INV_PI)*(1.0f - specularProbability);
+        } else if (sampleT) {
+            return __builtin_fabsf(wo.z)*INV_PI;
+        } else if (sampleR) {
+            return checkReflectionConstraint(wi, wo) ? 1.0f : 0.0f;
+        }
+        return 0.0f;
+    }
+    float glossyPdf = 0.0f;
+    if (sampleR) glossyPdf = rdPdfBase(wi, wo, true, false, texEval(sc, d.roughness_tex, uvx, uvy).x, d.ior, d.distribution);
+    float diffusePdf = 0.0f;
+    if (sampleT) diffusePdf = __builtin_fabsf(wo.z)*INV_PI;
+    if (sampleT && sampleR) {
+        float substrateWeight = d.substrate_weight*d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability = specularWeight/(specularWeight + substrateWeight);
+        diffusePdf *= (1.0f - specularProbability);
+        glossyPdf *= specularProbability;
+    }
+    return glossyPdf + diffusePdf;
+}
+TG_DEV V3 cosineHemisphereSample(Sampler &s)
+{
+    float xix = s.next1D(), xiy = s.next1D();
+    float phi = xix*TWO_PI; // SampleWarp::cosineHemisphere (sampling/SampleWarp.hpp:42-52)
+    float r = __builtin_sqrtf(xiy);
+    float sp, cp;
+    tgpu_sincosf(phi, &sp, &cp);
+    return V3(cp*r, sp*r, __builtin_sqrtf(fmax2(1.0f - xiy, 0.0f)));
+}
+TG_DEV bool plasticSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{
+    if (e.wi.z <= 0.0f) return false;
+    const bool rough = d.type == TGPU_BSDF_ROUGH_PLASTIC;
+    bool sampleR = (e.requestedLobe & (rough ? GlossyReflectionLobe : SpecularReflectionLobe)) != 0;
+    bool sampleT = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+    const V3 wi = e.wi;
+    float eta = 1.0f/d.ior;
+    float ct;
+    float Fi = dielectricReflectance(eta, wi.z, ct);
+    if (!rough) {
+        float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability;
+        if (sampleR && sampleT) specularProbability = specularWeight/(specularWeight + substrateWeight);
+        else if (sampleR) specularProbability = 1.0f;
+        else if (sampleT) specularProbability = 0.0f;
+        else return false;
+        if (sampleR && s.nextBoolean(specularProbability)) {
+            e.wo = V3(-wi.x, -wi.y, wi.z);
+            e.pdf = specularProbability;
+            e.weight = V3(Fi/specularProbability);
+            e.sampledLobe = SpecularReflectionLobe;
+        } else {
+            V3 wo = cosineHemisphereSample(s);
+            float Fo = dielectricReflectance(eta, wo.z, ct);
+            e.wo = wo;
+            e.weight = plasticSubstrate(sc, d, Fi, Fo, eta, e.uvx, e.uvy);
+            if (V3(d.scaled_sigma_a).max() > 0.0f) e.weight *= plasticAbsorption(d, e.wi.z, e.wo.z);
+            e.pdf = (__builtin_fabsf(e.wo.z)*INV_PI)*(1.0f - specularProbability);
+            e.weight /= 1.0f - specularProbability;
+            e.sampledLobe = DiffuseReflectionLobe;
+        }
+        return true;
+    }
+    if (!sampleR && !sampleT) return false;
+    float substrateWeight = d.substrate_weight*d.avg_transmittance*(1.0f - Fi);
+    float specularWeight = Fi;
+    float specularProbability = specularWeight/(specularWeight + substrateWeight);
+    const float roughness = texEval(sc, d.roughness_tex, e.uvx, e.uvy).x;
+    if (sampleR && (s.nextBoolean(specularProbability) || !sampleT)) {
+        if (!rdSampleBase(e, s, true, false, roughness, d.ior, d.distribution)) return false;
+        if (sampleT) {
+            float Fo = dielectricReflectance(eta, e.wo.z, ct);
+            V3 brdfSubstrate = plasticSubstrate(sc, d, Fi, Fo, eta, e.uvx, e.uvy)*INV_PI*e.wo.z;
+            V3 brdfSpecular = e.weight*e.pdf;
+            float pdfSubstrate = (__builtin_fabsf(e.wo.z)*INV_PI)*(1.0f - specularProbability);
+            float pdfSpecular = e.pdf*specularProbability;
+            e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+            e.pdf = pdfSpecular + pdfSubstrate;
+        }
+        return true;
+    }
+    V3 wo = cosineHemisphereSample(s);
+    float Fo = dielectricReflectance(eta, wo.z, ct);
+    e.wo = wo;
+    e.weight = plasticSubstrate(sc, d, Fi, Fo, eta, e.uvx, e.uvy);
+    if (V3(d.scaled_sigma_a).max() > 0.0f) e.weight *= plasticAbsorption(d, e.wi.z, e.wo.z);
+    e.pdf = __builtin_fabsf(e.wo.z)*INV_PI;
+    if (sampleR) {
+        V3 brdfSubstrate = e.weight*e.pdf;
+        float pdfSubstrate = e.pdf*(1.0f - specularProbability);
+        V3 brdfSpecular = rdEvalBase(e.wi, e.wo, true, false, roughness, d.ior, d.distribution);
+        float pdfSpecular = rdPdfBase(e.wi, e.wo, true, false, roughness, d.ior, d.distribution);
+        pdfSpecular *= specularProbability;
+        e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+        e.pdf = pdfSpecular + pdfSubstrate;
+    }
+    e.sampledLobe = DiffuseReflectionLobe;
     return true;
 }
 
@@ -830,11 +994,11 @@ TG_DEV bool specularSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampl
     return true;
 }
 
-TG_DEV V3 expV3(const V3 &a) { return V3(tgpu_expf(a.x), tgpu_expf(a.y), tgpu_expf(a.z)); }
 
 TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type >= TGPU_BSDF_MIRROR) return specularEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:146-178
@@ -864,6 +1028,7 @@ TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type >= TGPU_BSDF_MIRROR) return specularPdf(d, e.wi, e.wo, e.requestedLobe);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return basePdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:180-215
@@ -897,6 +1062,7 @@ TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricSample(sc, d, e, s);
+    if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticSample(sc, d, e, s);
     if (d.type >= TGPU_BSDF_MIRROR) return specularSample(sc, d, e, s);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseSample(sc, d, e, s);
     // bsdfs/SmoothCoatBsdf.cpp:41-100

@@ -493,6 +493,58 @@ int Scene::parseBsdf(const Json &v)
         b.type = TGPU_BSDF_NULL;
     } else if (type == "forward") {
         b.type = TGPU_BSDF_FORWARD;
+    } else if (type == "plastic" || type == "rough_plastic") { // PlasticBsdf.cpp:19-33,189-195, RoughPlasticBsdf.cpp:19-41,252-258
+        b.type = type == "plastic" ? TGPU_BSDF_PLASTIC : TGPU_BSDF_ROUGH_PLASTIC;
+        b.ior = 1.5f;
+        b.thickness = 1.0f;
+        b.sigma_a[0] = b.sigma_a[1] = b.sigma_a[2] = 0.0f;
+        v.getField("ior", b.ior);
+        v.getField("thickness", b.thickness);
+        v.getVec("sigma_a", b.sigma_a, 3);
+        for (int i = 0; i < 3; ++i) b.scaled_sigma_a[i] = b.thickness*b.sigma_a[i];
+        {
+            float sum = b.scaled_sigma_a[0]; sum += b.scaled_sigma_a[1]; sum += b.scaled_sigma_a[2];
+            b.avg_transmittance = std::exp(-2.0f*(sum*(1.0f/3.0f)));
+        }
+        { // Fresnel::computeDiffuseFresnel(ior, 1000000) (Fresnel.hpp:141-153) with dielectricReflectance (:75-92)
+            auto fresnel = [](float eta, float cosThetaI) {
+                if (cosThetaI < 0.0f) { eta = 1.0f/eta; cosThetaI = -cosThetaI; }
+                float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+                if (sinThetaTSq > 1.0f) return 1.0f;
+                float cosThetaT = std::sqrt(std::max(1.0f - sinThetaTSq, 0.0f));
+                float Rs = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT);
+                float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
+                return (Rs*Rs + Rp*Rp)*0.5f;
+            };
+            const int sampleCount = 1000000;
+            double diffuseFresnel = 0.0;
+            float fb = fresnel(b.ior, 0.0f);
+            for (int i = 1; i <= sampleCount; ++i) {
+                float cosThetaSq = float(i)/sampleCount;
+                float fa = fresnel(b.ior, std::min(std::sqrt(cosThetaSq), 1.0f));
+                diffuseFresnel += double(fa + fb)*(0.5/sampleCount);
+                fb = fa;
+            }
+            b.diffuse_fresnel = float(diffuseFresnel);
+        }
+        if (type == "rough_plastic") {
+            std::string dist = "ggx";
+            v.getField("distribution", dist);
+            if (dist == "beckmann") b.distribution = TGPU_DIST_BECKMANN;
+            else if (dist == "phong") b.distribution = TGPU_DIST_PHONG;
+            else if (dist == "ggx") b.distribution = TGPU_DIST_GGX;
+            else throw JsonLoadException("Unknown microfacet distribution '" + dist + "'");
+            if (v["roughness"])
+                b.roughness_tex = fetchTexture(v["roughness"], true);
+            else {
+                Json r; r.type = Json::Number; r.num = 0.02; // RoughPlasticBsdf.cpp:26
+                b.roughness_tex = fetchTexture(r, true);
+            }
+            const tgpu_texture &at = _textures[size_t(b.albedo_tex)];
+            if (at.type != TGPU_TEX_CONSTANT) throw std::runtime_error("rough_plastic with a textured albedo is outside the hot-path scope");
+            float sum = at.value[0]; sum += at.value[1]; sum += at.value[2]; // ConstantTexture::average() = _value, Vec::avg()
+            b.substrate_weight = sum*(1.0f/3.0f);
+        }
     } else if (type == "mirror") {
         b.type = TGPU_BSDF_MIRROR;
     } else if (type == "dielectric") { // DielectricBsdf.cpp:34-40

@@ -96,7 +96,7 @@ typedef struct tgpu_bsdf {
 
 /* ---- participating media (src/core/media) ------------------------------- */
 /* HomogeneousMedium after prepareForRender (HomogeneousMedium.cpp:42-48) with
- * an isotropic phase function (IsotropicPhaseFunction.cpp:17-44) and the
+ * an isotropic or Henyey-Greenstein phase function and the
  * exponential transmittance (ExponentialTransmittance.cpp:26-55, evaluated
  * with fmath::exp_ps, thirdparty/fmath/fmath.hpp:320-363).                    */
 /* Transmittance models of the fork (src/core/transmittances): what a free path looks like between two
@@ -115,6 +115,8 @@ typedef struct tgpu_medium {
     int32_t max_bounce;          /* Medium::_maxBounce (default 1024)          */
     int32_t transmittance;       /* TGPU_TRANS_*                               */
     float   param[3];
+    int32_t phase;               /* 0 isotropic (IsotropicPhaseFunction.cpp:17-44), 1 Henyey-Greenstein (HenyeyGreensteinPhaseFunction.cpp:19-90) */
+    float   phase_g;
 } tgpu_medium;
 
 /* ---- analytic primitives ------------------------------------------------ */

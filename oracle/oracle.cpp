@@ -307,6 +307,8 @@ struct oracle_ctx {
     float transSigmaBar(const tgpu_medium &m) const;
     float transSample(const tgpu_medium &m, Sampler &sampler, bool startOnSurface) const;
     int selectMedium(const Info &info, int current, bool geometricBackside) const;
+    float phaseEval(const tgpu_medium &m, const V3 &wi, const V3 &wo) const;
+    V3 phaseSample(const tgpu_medium &m, Sampler &sampler, const V3 &wi, float &pdf) const;
     V3 volumeEstimateDirect(Sampler &sampler, const struct MediumSampleO &ms, int medium, int bounce, const Ray &parent, Counters &c) const;
     bool handleVolume(Sampler &sampler, const struct MediumSampleO &ms, int medium, int bounce, bool enableLightSampling, Ray &ray, V3 &throughput, V3 &emission,
                       bool &wasSpecular, Counters &c) const;
@@ -2554,6 +2556,36 @@ V3 oracle_ctx::mediumTransmittance(int medium, const Ray &ray, bool startOnSurfa
     return transEval(sc.media[medium], V3(sc.media[medium].sigma_t)*ray.farT, startOnSurface, endOnSurface);
 }
 
+float oracle_ctx::phaseEval(const tgpu_medium &m, const V3 &wi, const V3 &wo) const
+{   // IsotropicPhaseFunction.cpp:24-27 / HenyeyGreensteinPhaseFunction.cpp:19-23,40-43 (eval == pdf for both)
+    if (m.phase == 0) return INV_FOUR_PI;
+    const float g = m.phase_g;
+    float cosTheta = wi.dot(wo);
+    float term = 1.0f + g*g - 2.0f*g*cosTheta;
+    return INV_FOUR_PI*(1.0f - g*g)/(term*std::sqrt(term));
+}
+
+V3 oracle_ctx::phaseSample(const tgpu_medium &m, Sampler &sampler, const V3 &wi, float &pdf) const
+{   // IsotropicPhaseFunction.cpp:29-35 / HenyeyGreensteinPhaseFunction.cpp:45-66 ; weight = 1
+    float xi0 = sampler.next1D(), xi1 = sampler.next1D();
+    const float g = m.phase_g;
+    if (m.phase == 0 || g == 0.0f) {
+        float phi = xi0*TWO_PI; // SampleWarp::uniformSphere (SampleWarp.hpp:96-107)
+        float z = xi1*2.0f - 1.0f;
+        float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
+        pdf = INV_FOUR_PI;
+        return V3(mcos(phi)*r, msin(phi)*r, z);
+    }
+    float phi = xi0*TWO_PI;
+    float q = (1.0f - g*g)/(1.0f + g*(xi1*2.0f - 1.0f));
+    float cosTheta = (1.0f + g*g - q*q)/(2.0f*g);
+    float sinTheta = std::sqrt(fmax2(1.0f - cosTheta*cosTheta, 0.0f));
+    Frame f = duffFrame(wi);
+    float term = 1.0f + g*g - 2.0f*g*cosTheta;
+    pdf = INV_FOUR_PI*(1.0f - g*g)/(term*std::sqrt(term));
+    return f.toGlobal(V3(mcos(phi)*sinTheta, msin(phi)*sinTheta, cosTheta));
+}
+
 int oracle_ctx::selectMedium(const Info &info, int current, bool geometricBackside) const
 {   // Primitive::selectMedium (primitives/Primitive.hpp:172-183)
     int im = -1, em = -1;
@@ -2574,25 +2606,22 @@ V3 oracle_ctx::volumeEstimateDirect(Sampler &sampler, const MediumSampleO &ms, i
         LightSample ls;
         V3 lightF(0.0f);
         if (lightSampleDirect(*light, ms.p, sampler, ls)) {
-            V3 f(INV_FOUR_PI); // IsotropicPhaseFunction::eval
+            V3 f(phaseEval(sc.media[medium], parent.dir, ls.d)); // phase->eval(parentRay.dir(), lightSample.d)
             Ray ray{ms.p, ls.d, 0.0f, INF};
             Temp data;
             Info info;
             V3 e = attenuatedEmission(*light, medium, ls.dist, data, info, bounce, false, ray, c);
             if (!(e == 0.0f)) {
                 lightF = f*e/ls.pdf;
-                float pp = INV_FOUR_PI; // phase->pdf
+                float pp = phaseEval(sc.media[medium], parent.dir, ls.d); // phase->pdf
                 lightF *= (ls.pdf*ls.pdf)/(ls.pdf*ls.pdf + pp*pp);
             }
         }
         result = lightF;
     }
     { // volumePhaseSample (lights in scope are never Dirac)
-        float xi0 = sampler.next1D(), xi1 = sampler.next1D();
-        float phi = xi0*TWO_PI; // SampleWarp::uniformSphere (SampleWarp.hpp:96-107)
-        float z = xi1*2.0f - 1.0f;
-        float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
-        V3 w(mcos(phi)*r, msin(phi)*r, z);
+        float pp;
+        V3 w = phaseSample(sc.media[medium], sampler, parent.dir, pp);
         Ray ray{ms.p, w, 0.0f, INF};
         Temp data;
         Info info;
@@ -2600,12 +2629,10 @@ V3 oracle_ctx::volumeEstimateDirect(Sampler &sampler, const MediumSampleO &ms, i
         if (!(e == 0.0f)) {
             V3 phaseF = e*V3(1.0f); // phaseSample.weight
             float lp = lightDirectPdf(*light, data, info, ms.p);
-            float pp = INV_FOUR_PI;
             phaseF *= (pp*pp)/(pp*pp + lp*lp);
             result += phaseF;
         }
     }
-    (void)parent;
     return result*weight;
 }
 
@@ -2615,11 +2642,8 @@ bool oracle_ctx::handleVolume(Sampler &sampler, const MediumSampleO &ms, int med
     wasSpecular = !enableLightSampling;
     if (enableLightSampling && bounce < sc.settings.max_bounces - 1)
         emission += throughput*volumeEstimateDirect(sampler, ms, medium, bounce + 1, ray, c);
-    float xi0 = sampler.next1D(), xi1 = sampler.next1D(); // IsotropicPhaseFunction::sample
-    float phi = xi0*TWO_PI;
-    float z = xi1*2.0f - 1.0f;
-    float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
-    V3 w(mcos(phi)*r, msin(phi)*r, z);
+    float pp;
+    V3 w = phaseSample(sc.media[medium], sampler, ray.dir, pp);
     ray = Ray{ms.p, w, 0.0f, INF};
     throughput *= V3(1.0f);
     return true;

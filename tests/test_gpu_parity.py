@@ -48,6 +48,7 @@ def assert_bit_exact(got, ref, what):
     ("next/conductor.json", (128, 72), 8, 8),
     ("next/plastic.json", (128, 72), 8, 8),
     ("next/rough_plastic.json", (128, 72), 8, 8),
+    ("next/dielectric_hg_medium.json", (128, 72), 8, 8),   # Henyey-Greenstein phase function
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)

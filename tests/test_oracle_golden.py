@@ -28,6 +28,7 @@ CASES = [
     ("conductor_128x72_4spp", "next/conductor.json", (128, 72), 4),
     ("plastic_128x72_4spp", "next/plastic.json", (128, 72), 4),
     ("rough_plastic_128x72_4spp", "next/rough_plastic.json", (128, 72), 4),
+    ("dielectric_hg_medium_128x72_4spp", "next/dielectric_hg_medium.json", (128, 72), 4),
 ]
 
 

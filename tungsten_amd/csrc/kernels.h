@@ -1188,6 +1188,39 @@ template <int CLASS, bool MEDIA>
 TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium = false);
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
 
+// phase functions: IsotropicPhaseFunction.cpp:24-44, HenyeyGreensteinPhaseFunction.cpp:19-23,40-66 (eval == pdf, weight 1)
+TG_DEV float phaseEval(const tgpu_medium &m, const V3 &wi, const V3 &wo)
+{
+    if (m.phase == 0) return INV_FOUR_PI;
+    const float g = m.phase_g;
+    float cosTheta = wi.dot(wo);
+    float term = 1.0f + g*g - 2.0f*g*cosTheta;
+    return INV_FOUR_PI*(1.0f - g*g)/(term*__builtin_sqrtf(term));
+}
+TG_DEV V3 phaseSample(const tgpu_medium &m, Sampler &smp, const V3 &wi, float &pdf)
+{
+    float xi0 = smp.next1D(), xi1 = smp.next1D();
+    const float g = m.phase_g;
+    float sp, cp;
+    if (m.phase == 0 || g == 0.0f) {
+        float phi = xi0*TWO_PI; // SampleWarp::uniformSphere
+        float z = xi1*2.0f - 1.0f;
+        float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
+        tgpu_sincosf(phi, &sp, &cp);
+        pdf = INV_FOUR_PI;
+        return V3(cp*r, sp*r, z);
+    }
+    float phi = xi0*TWO_PI;
+    float q = (1.0f - g*g)/(1.0f + g*(xi1*2.0f - 1.0f));
+    float cosTheta = (1.0f + g*g - q*q)/(2.0f*g);
+    float sinTheta = __builtin_sqrtf(fmax2(1.0f - cosTheta*cosTheta, 0.0f));
+    tgpu_sincosf(phi, &sp, &cp);
+    Frame f = duffFrame(wi);
+    float term = 1.0f + g*g - 2.0f*g*cosTheta;
+    pdf = INV_FOUR_PI*(1.0f - g*g)/(term*__builtin_sqrtf(term));
+    return f.toGlobal(V3(cp*sinTheta, sp*sinTheta, cosTheta));
+}
+
 // One step of a path whose ray runs inside a medium: PathTracer.cpp:54-63 (HomogeneousMedium::sampleDistance,
 // HomogeneousMedium.cpp:65-108), then either the surface / miss code with the attenuated throughput or
 // TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect (:323-381, :402-414, :470-481) and the loop
@@ -1297,7 +1330,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                 LightSample ls;
                 bool okL = isEnv ? envSampleDirect(sc, smp, ls) : quadSampleDirect(sc.quads[light.index], p, smp, ls);
                 if (okL) {
-                    V3 f(INV_FOUR_PI); // IsotropicPhaseFunction::eval
+                    V3 f(phaseEval(m, D, ls.d)); // phase->eval(parentRay.dir(), lightSample.d)
                     V3 E(0.0f);
                     float farT = TG_INF;
                     bool lit = true;
@@ -1317,7 +1350,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                     if (!fwdScene) E = neeTransmittance(sc, medium, farT, false)*E;
                     if (lit && shadowPasses && !E.isZero()) {
                         V3 lightF = f*E/ls.pdf;
-                        const float mis = powerHeuristic(ls.pdf, INV_FOUR_PI);
+                        const float mis = powerHeuristic(ls.pdf, phaseEval(m, D, ls.d)); // phase->pdf
                         lightF *= mis;
                         L = lightF;
                         dL = ls.d;
@@ -1327,13 +1360,8 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                 }
             }
             { // volumePhaseSample (the lights in scope are never Dirac)
-                float xi0 = smp.next1D(), xi1 = smp.next1D();
-                float phi = xi0*TWO_PI; // SampleWarp::uniformSphere
-                float z = xi1*2.0f - 1.0f;
-                float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
-                float sp, cp;
-                tgpu_sincosf(phi, &sp, &cp);
-                V3 w(cp*r, sp*r, z);
+                float phasePdf;
+                V3 w = phaseSample(m, smp, D, phasePdf);
                 V3 E(0.0f);
                 float farT = TG_INF, lightPdf = 0.0f;
                 bool lit = true;
@@ -1357,7 +1385,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                 if (!fwdScene) E = neeTransmittance(sc, medium, farT, false)*E;
                 if (lit && shadowPasses && !E.isZero()) {
                     V3 phaseF = E*V3(1.0f);
-                    const float mis = powerHeuristic(INV_FOUR_PI, lightPdf);
+                    const float mis = powerHeuristic(phasePdf, lightPdf);
                     phaseF *= mis;
                     B = phaseF;
                     dB = w;
@@ -1369,14 +1397,9 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     }
     const bool pushShadow = tfarL >= 0.0f || tfarB >= 0.0f;
 
-    // IsotropicPhaseFunction::sample -> the continuation ray (nearT = 0)
-    float xi0 = smp.next1D(), xi1 = smp.next1D();
-    float phi = xi0*TWO_PI;
-    float z = xi1*2.0f - 1.0f;
-    float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
-    float sp, cp;
-    tgpu_sincosf(phi, &sp, &cp);
-    const V3 wo(cp*r, sp*r, z);
+    // phase->sample(sampler, ray.dir(), phaseSample) -> the continuation ray (nearT = 0)
+    float contPdf;
+    const V3 wo = phaseSample(m, smp, D, contPdf);
     tp *= V3(1.0f);
 
     // PathTracer.cpp:108-126

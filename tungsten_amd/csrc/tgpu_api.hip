@@ -221,7 +221,8 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         if ((m.transmittance == TGPU_TRANS_LINEAR || m.transmittance == TGPU_TRANS_QUADRATIC) && !(m.param[0] > 0.0f)) ok = false;
         if (m.transmittance == TGPU_TRANS_DOUBLE_EXPONENTIAL && !(m.param[0] > 0.0f && m.param[1] > 0.0f)) ok = false;
         if (m.transmittance == TGPU_TRANS_PULSE && !(m.param[1] > m.param[0] && m.param[2] >= 1.0f && m.param[2] <= 4096.0f)) ok = false;
-        if (!ok) { fail(ctx, "medium %u: bad transmittance model / parameters", i); return TGPU_ERR_INVALID; }
+        if (m.phase < 0 || m.phase > 1 || !(m.phase_g > -1.0f && m.phase_g < 1.0f)) ok = false;
+        if (!ok) { fail(ctx, "medium %u: bad transmittance / phase model or parameters", i); return TGPU_ERR_INVALID; }
     }
     for (uint32_t i = 0; i < s->n_media; ++i)
         if (s->media[i].max_bounce < 0 || s->media[i].max_bounce >= (1 << 22)) { fail(ctx, "medium %u: max_bounces out of range", i); return TGPU_ERR_UNSUPPORTED; }

@@ -632,9 +632,16 @@ int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp
 {
     std::string type = v["type"].asString();
     if (type != "homogeneous") throw std::runtime_error("Medium type '" + type + "' is outside the hot-path scope (SURVEY.md section 8 a26: homogeneous only)");
-    if (const Json &ph = v["phase_function"]) {
+    int phaseType = 0;
+    float phaseG = 0.0f;
+    if (const Json &ph = v["phase_function"]) { // PhaseFunctionFactory.cpp
         std::string pt = ph.isObject() ? ph["type"].asString() : ph.asString();
-        if (pt != "isotropic") throw std::runtime_error("phase function '" + pt + "' is outside the hot-path scope");
+        if (pt == "henyey_greenstein") {
+            phaseType = 1;
+            if (ph.isObject()) ph.getField("g", phaseG);
+        } else if (pt != "isotropic") {
+            throw std::runtime_error("phase function '" + pt + "' is outside the hot-path scope");
+        }
     }
     int transType = TGPU_TRANS_EXPONENTIAL;
     float transParam[3] = {0, 0, 0};
@@ -675,6 +682,8 @@ int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp
         m.sigma_t[i] = m.sigma_a[i] + m.sigma_s[i];
     }
     m.absorption_only = m.sigma_s[0] == 0.0f && m.sigma_s[1] == 0.0f && m.sigma_s[2] == 0.0f;
+    m.phase = phaseType;
+    m.phase_g = phaseG;
     m.transmittance = transType;
     for (int i = 0; i < 3; ++i) m.param[i] = transParam[i];
     _media.push_back(m);

@@ -76,17 +76,25 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, n_dev)  # == local_rank on a full node; rehearsals may have fewer GPUs than ranks
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        # nccl == RCCL on ROCm.  TGPU_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (the ranks
+        # then share GPUs and the collectives run on host copies): it exercises launch, sharding, timing and gather, not RCCL.
+        backend = os.environ.get("TGPU_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     scene = ta.HostScene(args.scene or SCENE)
     shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank, world)
-    ctx = ta.Context(local_rank)
+    ctx = ta.Context(dev_index)
     ctx.upload(scene, shard)
     out = torch.zeros((shard.n_pixels, 3), dtype=torch.float32, device=device)
     spp_step = args.spp_step
@@ -116,7 +124,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

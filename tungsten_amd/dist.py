@@ -28,8 +28,10 @@ def gather_framebuffer(local_rgb, shard, world, rank, dist=None, device=None):
         return shard.scatter(local_rgb.detach().cpu().numpy())
     sizes = shard_sizes(res_x, res_y, world)
     n_max = max(sizes)
-    padded = torch.zeros((n_max, 3), dtype=torch.float32, device=local_rgb.device)
-    padded[: local_rgb.shape[0]] = local_rgb
+    # RCCL gathers device tensors in place; gloo (CPU tests, rehearsals) works on host copies
+    where = local_rgb.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    padded = torch.zeros((n_max, 3), dtype=torch.float32, device=where)
+    padded[: local_rgb.shape[0]] = local_rgb.to(where)
     gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
     dist.gather(padded, gather_list=gathered, dst=0)
     if rank != 0:

@@ -60,12 +60,16 @@ def main():
     ap.add_argument("--scene", default=None, help="another scene file (measurement of the other configs; the default "
                     "and the only bench line the contract asks for is configs[1])")
     ap.add_argument("--workload", default=None, help="label for --scene")
+    ap.add_argument("--pools", type=int, default=int(os.environ.get("TGPU_BENCH_POOLS", "1")),
+                    help="contexts (path pools, each on its own stream) per GPU; the image tiles are dealt over all of them. "
+                         "2 pools fill each other's kernel tails (+5..10 %% Msamples/s measured) but their launches overlap, so "
+                         "the per-launch roofline of k_extend no longer describes the kernel alone: the default stays 1")
     args = ap.parse_args()
 
     import torch  # device memory, streams and torch.distributed: plumbing only
     import numpy as np
     import tungsten_amd as ta
-    from tungsten_amd.dist import gather_framebuffer
+    from tungsten_amd.dist import gather_framebuffers
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,10 +97,13 @@ def main():
             dist.init_process_group(backend=backend)
 
     scene = ta.HostScene(args.scene or SCENE)
-    shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank, world)
-    ctx = ta.Context(dev_index)
-    ctx.upload(scene, shard)
-    out = torch.zeros((shard.n_pixels, 3), dtype=torch.float32, device=device)
+    K = max(1, args.pools)
+    shards = [ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank*K + j, world*K) for j in range(K)]
+    ctxs = [ta.Context(dev_index) for _ in range(K)]
+    for c, sh in zip(ctxs, shards):
+        c.upload(scene, sh)
+    outs = [torch.zeros((sh.n_pixels, 3), dtype=torch.float32, device=device) for sh in shards]
+    ctx, shard = ctxs[0], shards[0]
     spp_step = args.spp_step
 
     def sync_all():
@@ -107,20 +114,26 @@ def main():
 
     done = 0
     for _ in range(args.warmup):
-        ctx.render_pass(done, spp_step)
+        for c in ctxs:
+            c.render_pass(done, spp_step)
         done += spp_step
-    ctx.wait()
+    for c in ctxs:
+        c.wait()
     if dist is not None:  # warm the communicator outside the timed region
-        gather_framebuffer(out, shard, world, rank, dist)
+        gather_framebuffers(outs, shards, world, rank, K, dist)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.render_pass(done, spp_step)
+        for c in ctxs:
+            c.render_pass(done, spp_step)
         done += spp_step
-    ctx.wait()
-    ctx.resolve_to_device(out.data_ptr())
-    ctx.wait()
-    image = gather_framebuffer(out, shard, world, rank, dist)
+    for c in ctxs:
+        c.wait()
+    for c, o in zip(ctxs, outs):
+        c.resolve_to_device(o.data_ptr())
+    for c in ctxs:
+        c.wait()
+    image = gather_framebuffers(outs, shards, world, rank, K, dist)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -146,7 +159,7 @@ def main():
         "data": "synthetic camera paths on the vendored materialtest scene (assets/materialtest/c2.json)",
         "config": {"workload": "materialtest 1280x720, Lambert+RoughConductor only, 1xMI355X wavefront (BASELINE configs[1])",
                    "spp": spp_step*args.steps, "spp_step": spp_step, "sampler": "sobol", "adaptive": False,
-                   "max_bounces": scene.max_bounces, "parallelism": f"tile-shard x{world}"},
+                   "max_bounces": scene.max_bounces, "parallelism": f"tile-shard x{world}" + (f", {K} pools/GPU" if K > 1 else "")},
     }
 
     if args.scene:
@@ -161,20 +174,25 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's shard) -------------------------------------
     if not args.no_roofline and rank == 0:
-        rsteps = max(1, min(args.steps, 8))  # same pipelined regime as the timed region
-        ctx.set_profiling(1)  # visit counters (k_extend<true,..>)
-        ctx.reset_stats()
-        for i in range(rsteps):
-            ctx.render_pass(done + spp_step*i, spp_step)
-        ctx.wait()
-        c = ctx.stats()
-        ctx.set_profiling(2)  # HIP-event timing of the production kernels
-        ctx.reset_stats()
-        for i in range(rsteps):
-            ctx.render_pass(done + spp_step*(rsteps + i), spp_step)
-        ctx.wait()
-        t = ctx.stats()
-        ctx.set_profiling(0)
+        rsteps = max(1, min(args.steps, 8))  # same pipelined regime as the timed region: every pool of this rank renders
+        def phase(flags, base):
+            for cx in ctxs:
+                cx.set_profiling(flags)
+                cx.reset_stats()
+            for i in range(rsteps):
+                for cx in ctxs:
+                    cx.render_pass(base + spp_step*i, spp_step)
+            for cx in ctxs:
+                cx.wait()
+            tot = {}
+            for cx in ctxs:
+                for k, v in cx.stats().items():
+                    tot[k] = tot.get(k, 0) + v
+            for cx in ctxs:
+                cx.set_profiling(0)
+            return tot
+        c = phase(1, done)                       # visit counters (k_extend<true,..>)
+        t = phase(2, done + spp_step*rsteps)     # HIP-event timing of the production kernels, each on its own stream
         launches = max(1, c["extend_launches"])
         bytes_per_launch = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES +
                             c["extend_rays"]*RAY_QUEUE_BYTES)/launches
@@ -191,7 +209,7 @@ def main():
             "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "avg_launch_ms": round(avg_ms, 5),
-            "launches_per_step": round(launches/rsteps, 2),
+            "launches_per_step": round(launches/rsteps, 2), "pools": K,
             "per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
                         "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)},
             "per_sample": {"extend_rays": round(c["extend_rays"]/max(1, c["samples"]), 3),

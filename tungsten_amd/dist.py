@@ -43,6 +43,33 @@ def gather_framebuffer(local_rgb, shard, world, rank, dist=None, device=None):
     return image.reshape(res_y, res_x, 3)
 
 
+def gather_framebuffers(local_rgbs, shards, world, rank, sub, dist=None):
+    """Like gather_framebuffer for `sub` image-plane shards per rank (one context each: two pools on separate streams
+    fill each other's launch gaps and kernel tails).  Shard j of rank r is shard r*sub + j of world*sub.
+    Returns the (H, W, 3) image on rank 0, None elsewhere."""
+    import torch
+
+    res_x, res_y = shards[0].res_x, shards[0].res_y
+    image = np.zeros((res_y*res_x, 3), np.float32) if rank == 0 else None
+    for j in range(sub):
+        local = local_rgbs[j]
+        if world == 1:
+            image[shards[j].pixel_index] = local.detach().cpu().numpy()
+            continue
+        sizes = [Shard(res_x, res_y, 0xBA5EBA11, r*sub + j, world*sub).n_pixels for r in range(world)]
+        n_max = max(sizes)
+        where = local.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        padded = torch.zeros((n_max, 3), dtype=torch.float32, device=where)
+        padded[: local.shape[0]] = local.to(where)
+        gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+        dist.gather(padded, gather_list=gathered, dst=0)
+        if rank == 0:
+            for r in range(world):
+                sh = Shard(res_x, res_y, 0xBA5EBA11, r*sub + j, world*sub)
+                image[sh.pixel_index] = gathered[r][: sizes[r]].cpu().numpy()
+    return image.reshape(res_y, res_x, 3) if rank == 0 else None
+
+
 def exchange_records(table, dist, device=None):
     """Adaptive sampling's one exchange step: every rank needs the SampleRecord statistics of ALL variance
     tiles to compute the next pass' sample distribution (PathTraceIntegrator.cpp:44-108 reads the whole

@@ -57,6 +57,7 @@ typedef struct tgpu_bitmap {
     int32_t      linear;   /* bilinear interpolation                       */
     float        scale;
     const float *texels;   /* w*h*3 RGB f32, row 0 = top (ImageIO.cpp:340) */
+    float        average[3]; /* BitmapTexture::_avg: sum of texel/(w*h) in row-major order (BitmapTexture.cpp:183-193) */
 } tgpu_bitmap;
 
 /* ---- BSDFs (src/core/bsdfs) -------------------------------------------- */
@@ -142,6 +143,28 @@ typedef struct tgpu_cube {
     int32_t int_medium, ext_medium;
 } tgpu_cube;
 
+/* Sphere after prepareForRender (src/core/primitives/Sphere.cpp:285-295).      */
+typedef struct tgpu_sphere {
+    float   pos[3];
+    float   radius;
+    float   rot[9], inv_rot[9];
+    int32_t bsdf;
+    int32_t emission_tex;
+    int32_t int_medium, ext_medium;
+} tgpu_sphere;
+
+/* Disk after prepareForRender (src/core/primitives/Disk.cpp:315-327).          */
+typedef struct tgpu_disk {
+    float   center[3];
+    float   r;
+    float   n[3], tangent[3], bitangent[3]; /* _n, TangentFrame(_n)           */
+    float   cos_apex;      /* cos(cone_angle)                                */
+    float   cone_base[3];  /* _center - _n/sin(cone_angle)                   */
+    int32_t bsdf;
+    int32_t emission_tex;
+    int32_t int_medium, ext_medium;
+} tgpu_disk;
+
 /* Infinite sphere / environment light (InfiniteSphere.cpp:27-50,161-244) and
  * the Distribution2D of its emission bitmap (Distribution2D.hpp:18-83,
  * BitmapTexture.cpp:400-455).  Tables are NULL for a constant emission.      */
@@ -187,7 +210,7 @@ typedef struct tgpu_settings {
 
 /* A light is an emissive, samplable primitive, in scene order
  * (TraceableScene.hpp:86-102).                                              */
-enum { TGPU_LIGHT_ENV = 0, TGPU_LIGHT_QUAD = 1 };
+enum { TGPU_LIGHT_ENV = 0, TGPU_LIGHT_QUAD = 1, TGPU_LIGHT_SPHERE = 2, TGPU_LIGHT_DISK = 3 };
 typedef struct tgpu_light { int32_t kind; int32_t index; } tgpu_light;
 
 /* ---- "instances" primitives (src/core/primitives/Instance.cpp) -------------
@@ -235,6 +258,8 @@ typedef struct tgpu_scene_desc {
 
     uint32_t         n_quads;   const tgpu_quad    *quads;
     uint32_t         n_cubes;   const tgpu_cube    *cubes;
+    uint32_t         n_spheres; const tgpu_sphere  *spheres;
+    uint32_t         n_disks;   const tgpu_disk    *disks;
     uint32_t         n_bsdfs;   const tgpu_bsdf    *bsdfs;
     uint32_t         n_textures;const tgpu_texture *textures;
     uint32_t         n_bitmaps; const tgpu_bitmap  *bitmaps;

@@ -173,12 +173,13 @@ inline Pcg32 pathLocalPcg(uint32_t scramble, uint32_t sampleIndex)
 
 // ---- records ---------------------------------------------------------------------------
 struct Ray { V3 pos, dir; float nearT, farT; };
-enum PrimKind : int { PRIM_NONE = 0, PRIM_TRI = 1, PRIM_QUAD = 2, PRIM_CUBE = 3, PRIM_ENV = 4, PRIM_INSTANCE = 5 };
+enum PrimKind : int { PRIM_NONE = 0, PRIM_TRI = 1, PRIM_QUAD = 2, PRIM_CUBE = 3, PRIM_ENV = 4, PRIM_INSTANCE = 5, PRIM_SPHERE = 6, PRIM_DISK = 7 };
 struct Temp { // IntersectionTemporary
     int kind = PRIM_NONE;
     uint32_t index = 0;
     float u = 0, v = 0;
-    V3 p, w, Ng; // quad hit point / env origin ; env direction ; mesh unnormalised geometric normal
+    V3 p, w, Ng; // quad / disk hit point, env origin ; env direction ; mesh unnormalised geometric normal
+    float rSq = 0; // DiskIntersection::rSq
     bool backSide = false;
     int32_t inst = -1, instSet = -1; // IntersectionTemporary::flags / primitive == an Instance (Instance.cpp:305-308)
 };
@@ -266,6 +267,8 @@ struct oracle_ctx {
     // ---- primitives / lights -----------------------------------------------------------
     bool quadIntersect(const tgpu_quad &q, uint32_t idx, Ray &ray, Temp &data) const;
     bool cubeIntersect(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const;
+    bool sphereIntersect(const tgpu_sphere &sp, uint32_t idx, Ray &ray, Temp &data) const;
+    bool diskIntersect(const tgpu_disk &dk, uint32_t idx, Ray &ray, Temp &data) const;
     void intersectionInfo(const Temp &data, Info &info) const;
     bool intersect(Ray &ray, Temp &data, Info &info, Counters &c) const;
     void directionToUV(const V3 &wi, float &ux, float &uy, float *sinTheta) const;
@@ -675,6 +678,48 @@ bool oracle_ctx::cubeIntersect(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp
     return false;
 }
 
+bool oracle_ctx::sphereIntersect(const tgpu_sphere &sp, uint32_t idx, Ray &ray, Temp &data) const // primitives/Sphere.cpp:68-92
+{
+    V3 p = ray.pos - V3(sp.pos);
+    float B = p.dot(ray.dir);
+    float C = p.lengthSq() - sp.radius*sp.radius;
+    float detSq = B*B - C;
+    if (detSq >= 0.0f) {
+        float det = std::sqrt(detSq);
+        float t = -B - det;
+        if (t < ray.farT && t > ray.nearT) {
+            ray.farT = t;
+            data.kind = PRIM_SPHERE; data.index = idx; data.backSide = false;
+            return true;
+        }
+        t = -B + det;
+        if (t < ray.farT && t > ray.nearT) {
+            ray.farT = t;
+            data.kind = PRIM_SPHERE; data.index = idx; data.backSide = true;
+            return true;
+        }
+    }
+    return false;
+}
+
+bool oracle_ctx::diskIntersect(const tgpu_disk &dk, uint32_t idx, Ray &ray, Temp &data) const // primitives/Disk.cpp:64-86
+{
+    V3 n(dk.n), center(dk.center);
+    float nDotW = ray.dir.dot(n);
+    float t = n.dot(center - ray.pos)/nDotW;
+    if (t < ray.nearT || t > ray.farT) return false;
+    V3 q = ray.pos + t*ray.dir;
+    V3 v = q - center;
+    float rSq = v.lengthSq();
+    if (rSq > dk.r*dk.r) return false;
+    ray.farT = t;
+    data.kind = PRIM_DISK; data.index = idx;
+    data.p = q;
+    data.rSq = rSq;
+    data.backSide = -nDotW < dk.cos_apex;
+    return true;
+}
+
 void oracle_ctx::intersectionInfo(const Temp &data, Info &info) const
 {
     info.kind = data.kind;
@@ -719,6 +764,29 @@ void oracle_ctx::intersectionInfo(const Temp &data, Info &info) const
         info.uvx = uvw[(dim + 1) % 3];
         info.uvy = uvw[(dim + 2) % 3];
         info.bsdf = cb.bsdf;
+        break;
+    }
+    case PRIM_SPHERE: { // primitives/Sphere.cpp:119-128
+        const tgpu_sphere &sp = sc.spheres[data.index];
+        info.Ns = info.Ng = (info.p - V3(sp.pos))/sp.radius;
+        V3 localN = mulVector(sp.inv_rot, info.Ng);
+        info.uvx = matan2(localN.y, localN.x)*INV_TWO_PI + 0.5f;
+        info.uvy = macos(clampf(localN.z, -1.0f, 1.0f))*INV_PI;
+        if (std::isnan(info.uvx)) info.uvx = 0.0f;
+        info.bsdf = sp.bsdf;
+        break;
+    }
+    case PRIM_DISK: { // primitives/Disk.cpp:107-120
+        const tgpu_disk &dk = sc.disks[data.index];
+        info.Ng = info.Ns = V3(dk.n);
+        info.p = data.p;
+        V3 d = data.p - V3(dk.center);
+        float x = d.dot(V3(dk.bitangent));
+        float y = d.dot(V3(dk.tangent));
+        float v = std::sqrt(data.rSq)/dk.r;
+        float u = (x == 0.0f && y == 0.0f) ? 0.0f : (matan2(y, x)*INV_TWO_PI + 0.5f);
+        info.uvx = u; info.uvy = v;
+        info.bsdf = dk.bsdf;
         break;
     }
     case PRIM_ENV: { // primitives/InfiniteSphere.cpp:96-104
@@ -1165,6 +1233,10 @@ bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const 
         cubeIntersect(sc.cubes[i], i, ray, data);
         if (ray.farT != before) data.inst = data.instSet = -1;
     }
+    for (uint32_t i = 0; i < sc.n_spheres; ++i)
+        if (sphereIntersect(sc.spheres[i], i, ray, data)) data.inst = data.instSet = -1;
+    for (uint32_t i = 0; i < sc.n_disks; ++i)
+        if (diskIntersect(sc.disks[i], i, ray, data)) data.inst = data.instSet = -1;
     float t = ray.farT, u = 0, v = 0;
     uint32_t prim = 0xFFFFFFFFu;
     intersectTris(sceneBvh, ray, t, u, v, prim, c);
@@ -1219,6 +1291,8 @@ bool oracle_ctx::primEmissive(int kind, uint32_t index) const
 {
     if (kind == PRIM_QUAD) return sc.quads[index].emission_tex >= 0;
     if (kind == PRIM_CUBE) return sc.cubes[index].emission_tex >= 0;
+    if (kind == PRIM_SPHERE) return sc.spheres[index].emission_tex >= 0;
+    if (kind == PRIM_DISK) return sc.disks[index].emission_tex >= 0;
     if (kind == PRIM_ENV) return true;
     return false;
 }
@@ -1236,6 +1310,16 @@ V3 oracle_ctx::primEvalDirect(const Temp &data, const Info &info) const
         const tgpu_quad &q = sc.quads[data.index];
         if (q.emission_tex < 0 || data.backSide) return V3(0.0f);
         return texEval(q.emission_tex, info.uvx, info.uvy);
+    }
+    case PRIM_SPHERE: { // Sphere.cpp:242-245
+        const tgpu_sphere &sp = sc.spheres[data.index];
+        if (sp.emission_tex < 0 || data.backSide) return V3(0.0f);
+        return texEval(sp.emission_tex, info.uvx, info.uvy);
+    }
+    case PRIM_DISK: { // Disk.cpp:245-248
+        const tgpu_disk &dk = sc.disks[data.index];
+        if (dk.emission_tex < 0 || data.backSide) return V3(0.0f);
+        return texEval(dk.emission_tex, info.uvx, info.uvy);
     }
     case PRIM_ENV: return texEval(sc.env.emission_tex, info.uvx, info.uvy); // InfiniteSphere.cpp:241-244
     default: return V3(0.0f); // Primitive::evalDirect with no emission (Primitive.cpp:104-111)
@@ -1273,6 +1357,44 @@ bool oracle_ctx::lightSampleDirect(const tgpu_light &l, const V3 &p, Sampler &s,
         out.dist = INF;
         return out.pdf != 0.0f;
     }
+    if (l.kind == TGPU_LIGHT_SPHERE) { // Sphere.cpp:173-194
+        const tgpu_sphere &sp = sc.spheres[l.index];
+        V3 L = V3(sp.pos) - p;
+        float d = L.length();
+        float C = d*d - sp.radius*sp.radius;
+        if (C <= 0.0f) return false;
+        L = L.normalized(); // L.normalize(): *= 1/length
+        float cosTheta = std::sqrt(C)/d;
+        float xi0 = s.next1D(), xi1 = s.next1D();
+        float phi = xi0*TWO_PI; // SampleWarp::uniformSphericalCap (SampleWarp.hpp:119-129)
+        float z = xi1*(1.0f - cosTheta) + cosTheta;
+        float r = std::sqrt(fmax2(1.0f - z*z, 0.0f));
+        V3 dl(mcos(phi)*r, msin(phi)*r, z);
+        float B = d*dl.z;
+        float det = std::sqrt(fmax2(B*B - C, 0.0f));
+        out.dist = B - det;
+        out.d = duffFrame(L).toGlobal(dl);
+        out.pdf = INV_TWO_PI/(1.0f - cosTheta); // uniformSphericalCapPdf
+        return true;
+    }
+    if (l.kind == TGPU_LIGHT_DISK) { // Disk.cpp:177-193
+        const tgpu_disk &dk = sc.disks[l.index];
+        V3 n(dk.n), center(dk.center);
+        if (n.dot(p - center) < 0.0f) return false;
+        float xi0 = s.next1D(), xi1 = s.next1D();
+        float phi = xi0*TWO_PI; // SampleWarp::uniformDisk (:64-69)
+        float rr = std::sqrt(xi1);
+        float lqx = (mcos(phi)*rr)*dk.r, lqy = (msin(phi)*rr)*dk.r;
+        V3 q = center + lqx*V3(dk.bitangent) + lqy*V3(dk.tangent);
+        out.d = q - p;
+        float rSq = out.d.lengthSq();
+        out.dist = std::sqrt(rSq);
+        out.d /= out.dist;
+        if (-out.d.dot(n) < dk.cos_apex) return false;
+        float cosTheta = -n.dot(out.d);
+        out.pdf = rSq/(cosTheta*dk.r*dk.r*PI);
+        return true;
+    }
     // Quad.cpp:172-187
     const tgpu_quad &q = sc.quads[l.index];
     V3 normal(q.normal), base(q.base);
@@ -1297,6 +1419,8 @@ bool oracle_ctx::lightIntersect(const tgpu_light &l, Ray &ray, Temp &data) const
         data.w = ray.dir;
         return true;
     }
+    if (l.kind == TGPU_LIGHT_SPHERE) return sphereIntersect(sc.spheres[l.index], uint32_t(l.index), ray, data);
+    if (l.kind == TGPU_LIGHT_DISK) return diskIntersect(sc.disks[l.index], uint32_t(l.index), ray, data);
     return quadIntersect(sc.quads[l.index], uint32_t(l.index), ray, data);
 }
 
@@ -1308,6 +1432,19 @@ float oracle_ctx::lightDirectPdf(const tgpu_light &l, const Temp &data, const In
         directionToUV(data.w, ux, uy, &sinTheta);
         return INV_PI*INV_TWO_PI*envPdf(ux, uy)/sinTheta;
     }
+    if (l.kind == TGPU_LIGHT_SPHERE) { // Sphere.cpp:224-230
+        const tgpu_sphere &sp = sc.spheres[l.index];
+        float dist = (V3(sp.pos) - p).length();
+        float cosTheta = std::sqrt(fmax2(dist*dist - sp.radius*sp.radius, 0.0f))/dist;
+        return INV_TWO_PI/(1.0f - cosTheta);
+    }
+    if (l.kind == TGPU_LIGHT_DISK) { // Disk.cpp:225-232
+        const tgpu_disk &dk = sc.disks[l.index];
+        V3 n(dk.n);
+        float cosTheta = std::abs(n.dot(info.w));
+        float t = n.dot(V3(dk.center) - p)/n.dot(info.w);
+        return t*t/(cosTheta*dk.r*dk.r*PI);
+    }
     const tgpu_quad &q = sc.quads[l.index]; // Quad.cpp:216-223
     V3 normal(q.normal);
     float cosTheta = std::abs(normal.dot(info.w));
@@ -1317,16 +1454,44 @@ float oracle_ctx::lightDirectPdf(const tgpu_light &l, const Temp &data, const In
 
 float oracle_ctx::lightApproximateRadiance(const tgpu_light &l, const V3 &p) const
 {
-    if (l.kind == TGPU_LIGHT_ENV) return -1.0f; // only reached with > 1 light; see chooseLight
+    auto avgMax = [&](int tex) { // Texture::average().max(): ConstantTexture.cpp:35-38, CheckerTexture.cpp:49-52, BitmapTexture.cpp:283-286
+        const tgpu_texture &t = sc.textures[tex];
+        V3 a;
+        if (t.type == TGPU_TEX_CONSTANT) a = V3(t.value);
+        else if (t.type == TGPU_TEX_CHECKER) a = (V3(t.on_color) + V3(t.off_color))*0.5f;
+        else a = sc.bitmaps[t.bitmap].scale*V3(sc.bitmaps[t.bitmap].average);
+        return a.max();
+    };
+    if (l.kind == TGPU_LIGHT_ENV) return TWO_PI*avgMax(sc.env.emission_tex); // InfiniteSphere.cpp:261-266 (listed lights are samplable)
+    if (l.kind == TGPU_LIGHT_SPHERE) { // Sphere.cpp:33-40,266-271
+        const tgpu_sphere &sp = sc.spheres[l.index];
+        V3 L = V3(sp.pos) - p;
+        float d = L.length();
+        float cosTheta = std::sqrt(fmax2(d*d - sp.radius*sp.radius, 0.0f))/d;
+        return (TWO_PI*(1.0f - cosTheta))*avgMax(sp.emission_tex);
+    }
+    if (l.kind == TGPU_LIGHT_DISK) { // Disk.cpp:268-296
+        const tgpu_disk &dk = sc.disks[l.index];
+        V3 n(dk.n);
+        V3 coneD = p - V3(dk.cone_base);
+        if (coneD.dot(n)/coneD.length() < dk.cos_apex) return 0.0f;
+        V3 d = V3(dk.center) - p;
+        V3 edge0 = V3(dk.tangent)*dk.r, edge1 = V3(dk.bitangent)*dk.r;
+        V3 R0 = d - edge0 - edge1;
+        V3 R1 = R0 + 2.0f*edge0;
+        V3 R2 = R1 + 2.0f*edge1;
+        V3 R3 = R0 + 2.0f*edge1;
+        V3 n0 = R0.cross(R1).normalized(), n1 = R1.cross(R2).normalized(), n2 = R2.cross(R3).normalized(), n3 = R3.cross(R0).normalized();
+        float Q = macos(n0.dot(n1)) + macos(n1.dot(n2)) + macos(n2.dot(n3)) + macos(n3.dot(n0));
+        return (TWO_PI - std::abs(Q))*avgMax(dk.emission_tex);
+    }
     const tgpu_quad &q = sc.quads[l.index]; // Quad.cpp:256-279
     V3 R0 = V3(q.base) - p;
     if (R0.dot(V3(q.normal)) >= 0.0f) return 0.0f;
     V3 R1 = R0 + V3(q.edge0), R2 = R1 + V3(q.edge1), R3 = R0 + V3(q.edge1);
     V3 n0 = R0.cross(R1).normalized(), n1 = R1.cross(R2).normalized(), n2 = R2.cross(R3).normalized(), n3 = R3.cross(R0).normalized();
     float Q = macos(n0.dot(n1)) + macos(n1.dot(n2)) + macos(n2.dot(n3)) + macos(n3.dot(n0));
-    const tgpu_texture &t = sc.textures[q.emission_tex];
-    V3 avg = t.type == TGPU_TEX_CONSTANT ? V3(t.value) : V3(0.5f);
-    return (TWO_PI - std::abs(Q))*avg.max();
+    return (TWO_PI - std::abs(Q))*avgMax(q.emission_tex);
 }
 
 // ========================================================================================
@@ -2200,7 +2365,7 @@ V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, int medium, float expecte
     info.p = ray.pos + ray.dir*ray.farT;
     info.w = ray.dir;
     intersectionInfo(data, info);
-    int endKind = l.kind == TGPU_LIGHT_ENV ? PRIM_ENV : PRIM_QUAD;
+    int endKind = l.kind == TGPU_LIGHT_ENV ? PRIM_ENV : (l.kind == TGPU_LIGHT_SPHERE ? PRIM_SPHERE : (l.kind == TGPU_LIGHT_DISK ? PRIM_DISK : PRIM_QUAD));
     V3 shadow = shadowRay(ray, medium, endKind, uint32_t(l.index), bounce, startsOnSurface, true, c);
     if (shadow == 0.0f) return V3(0.0f);
     return shadow*primEvalDirect(data, info);
@@ -2592,6 +2757,8 @@ int oracle_ctx::selectMedium(const Info &info, int current, bool geometricBacksi
     if (info.kind == PRIM_TRI && sc.tri_media) { im = sc.tri_media[size_t(info.index)*2]; em = sc.tri_media[size_t(info.index)*2 + 1]; }
     else if (info.kind == PRIM_QUAD) { im = sc.quads[info.index].int_medium; em = sc.quads[info.index].ext_medium; }
     else if (info.kind == PRIM_CUBE) { im = sc.cubes[info.index].int_medium; em = sc.cubes[info.index].ext_medium; }
+    else if (info.kind == PRIM_SPHERE) { im = sc.spheres[info.index].int_medium; em = sc.spheres[info.index].ext_medium; }
+    else if (info.kind == PRIM_DISK) { im = sc.disks[info.index].int_medium; em = sc.disks[info.index].ext_medium; }
     if (im >= 0 || em >= 0) return geometricBackside ? im : em;
     return current;
 }

@@ -19,7 +19,7 @@ class Texture(C.Structure):
 
 
 class Bitmap(C.Structure):
-    _fields_ = [("w", i32), ("h", i32), ("clamp", i32), ("linear", i32), ("scale", f32), ("texels", pf32)]
+    _fields_ = [("w", i32), ("h", i32), ("clamp", i32), ("linear", i32), ("scale", f32), ("texels", pf32), ("average", f32*3)]
 
 
 class Bsdf(C.Structure):
@@ -43,6 +43,16 @@ class Quad(C.Structure):
 class Cube(C.Structure):
     _fields_ = [("rot", f32*9), ("inv_rot", f32*9), ("pos", f32*3), ("scale", f32*3), ("bsdf", i32),
                 ("emission_tex", i32), ("int_medium", i32), ("ext_medium", i32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("pos", f32*3), ("radius", f32), ("rot", f32*9), ("inv_rot", f32*9), ("bsdf", i32), ("emission_tex", i32),
+                ("int_medium", i32), ("ext_medium", i32)]
+
+
+class Disk(C.Structure):
+    _fields_ = [("center", f32*3), ("r", f32), ("n", f32*3), ("tangent", f32*3), ("bitangent", f32*3), ("cos_apex", f32),
+                ("cone_base", f32*3), ("bsdf", i32), ("emission_tex", i32), ("int_medium", i32), ("ext_medium", i32)]
 
 
 class Env(C.Structure):
@@ -82,6 +92,8 @@ class SceneDesc(C.Structure):
                 ("tri_smooth", pu8), ("tri_media", C.POINTER(C.c_int16)),
                 ("n_quads", u32), ("quads", C.POINTER(Quad)),
                 ("n_cubes", u32), ("cubes", C.POINTER(Cube)),
+                ("n_spheres", u32), ("spheres", C.POINTER(Sphere)),
+                ("n_disks", u32), ("disks", C.POINTER(Disk)),
                 ("n_bsdfs", u32), ("bsdfs", C.POINTER(Bsdf)),
                 ("n_textures", u32), ("textures", C.POINTER(Texture)),
                 ("n_bitmaps", u32), ("bitmaps", C.POINTER(Bitmap)),

@@ -417,6 +417,13 @@ int Scene::fetchTexture(const Json &v, bool /*scalarAverage*/) // Scene.cpp:127-
             throw std::runtime_error("Unable to load texture at '" + full + "' (only Radiance .hdr bitmaps are in scope)");
         tgpu_bitmap bm{};
         bm.w = w; bm.h = h; bm.clamp = 0; bm.linear = 1; bm.scale = 1.0f; bm.texels = nullptr;
+        { // BitmapTexture::init (:183-193): _avg += getRgb(x, y)/float(_w*_h), rows top to bottom
+            float avg[3] = {0.0f, 0.0f, 0.0f};
+            const float n = float(w*h);
+            for (size_t i = 0; i < size_t(w)*h; ++i)
+                for (int k = 0; k < 3; ++k) avg[k] += texels[i*3 + k]/n;
+            for (int k = 0; k < 3; ++k) bm.average[k] = avg[k];
+        }
         _bitmaps.push_back(bm);
         _bitmapTexels.push_back(std::move(texels));
         _bitmapPaths.push_back(full);
@@ -859,6 +866,15 @@ void Scene::parsePrimitive(const Json &v)
         CubeSrc c{transform, fetchBsdf(v["bsdf"]), emissionTex, intMedium, extMedium};
         _cubeSrc.push_back(c);
         _primOrder.push_back({PrimCube, int(_cubeSrc.size()) - 1});
+    } else if (type == "sphere") {
+        SphereSrc sp{transform, fetchBsdf(v["bsdf"]), emissionTex, intMedium, extMedium};
+        _sphereSrc.push_back(sp);
+        _primOrder.push_back({PrimSphere, int(_sphereSrc.size()) - 1});
+    } else if (type == "disk") {
+        DiskSrc dk{transform, fetchBsdf(v["bsdf"]), emissionTex, 90.0f, intMedium, extMedium};
+        v.getField("cone_angle", dk.coneAngle);
+        _diskSrc.push_back(dk);
+        _primOrder.push_back({PrimDisk, int(_diskSrc.size()) - 1});
     } else if (type == "instances") { // Instance::fromJson (Instance.cpp:60-93)
         if (emissionTex >= 0) throw std::runtime_error("emissive 'instances' primitives are outside the hot-path scope");
         if (intMedium >= 0 || extMedium >= 0) throw std::runtime_error("media on 'instances' primitives are outside the hot-path scope");
@@ -1172,6 +1188,48 @@ void Scene::flatten()
     for (const CubeSrc &c : _cubeSrc) _cubes.push_back(bakeCube(c));
     _desc.n_cubes = uint32_t(_cubes.size());
 
+    // ---- spheres (Sphere.cpp:285-295), disks (Disk.cpp:315-327) ----
+    _spheres.clear();
+    for (const SphereSrc &sp : _sphereSrc) {
+        tgpu_sphere o{};
+        Vec3 p = sp.transform*Vec3(0.0f);
+        Vec3 sc3 = sp.transform.extractScale()*Vec3(1.0f);
+        float radius = sc3.x; if (sc3.y > radius) radius = sc3.y; if (sc3.z > radius) radius = sc3.z; // Vec::max()
+        Mat4 rot = sp.transform.extractRotation();
+        Mat4 inv = rot.transpose();
+        storeMat3(rot, o.rot);
+        storeMat3(inv, o.inv_rot);
+        for (int i = 0; i < 3; ++i) o.pos[i] = p[i];
+        o.radius = radius;
+        o.bsdf = sp.bsdf; o.emission_tex = sp.emissionTex; o.int_medium = sp.intMedium; o.ext_medium = sp.extMedium;
+        _spheres.push_back(o);
+    }
+    _desc.n_spheres = uint32_t(_spheres.size());
+    _desc.spheres = _spheres.data();
+    _disks.clear();
+    for (const DiskSrc &dk : _diskSrc) {
+        tgpu_disk o{};
+        Vec3 c = dk.transform*Vec3(0.0f);
+        Vec3 sc3 = dk.transform.extractScale()*Vec3(1.0f, 0.0f, 1.0f);
+        float r = sc3.x; if (sc3.y > r) r = sc3.y; if (sc3.z > r) r = sc3.z;
+        Vec3 n = dk.transform.transformVector(Vec3(0.0f, 1.0f, 0.0f)).normalized();
+        // TangentFrame(n) (math/TangentFrame.hpp:22-31, Duff et al.)
+        float sign = std::copysign(1.0f, n.z);
+        const float a = -1.0f/(sign + n.z);
+        const float b = n.x*n.y*a;
+        Vec3 tangent(1.0f + sign*n.x*n.x*a, sign*b, -sign*n.x);
+        Vec3 bitangent(b, sign + n.y*n.y*a, -n.y);
+        float coneRad = dk.coneAngle*(PI/180.0f); // Angle::degToRad (Angle.hpp:26-29)
+        Vec3 coneBase = c - n/std::sin(coneRad);
+        for (int i = 0; i < 3; ++i) { o.center[i] = c[i]; o.n[i] = n[i]; o.tangent[i] = tangent[i]; o.bitangent[i] = bitangent[i]; o.cone_base[i] = coneBase[i]; }
+        o.r = r;
+        o.cos_apex = std::cos(coneRad);
+        o.bsdf = dk.bsdf; o.emission_tex = dk.emissionTex; o.int_medium = dk.intMedium; o.ext_medium = dk.extMedium;
+        _disks.push_back(o);
+    }
+    _desc.n_disks = uint32_t(_disks.size());
+    _desc.disks = _disks.data();
+
     // ---- "instances": masters go to the tail of the geometry arrays; Instance::prepareForRender :392-403 ----
     _instanceFlat.clear();
     _instanceSets.clear();
@@ -1258,6 +1316,12 @@ void Scene::flatten()
     for (const PrimRef &pr : _primOrder) {
         if (pr.kind == PrimQuad && _quadSrc[size_t(pr.index)].emissionTex >= 0) {
             _lights.push_back({TGPU_LIGHT_QUAD, pr.index});
+            ++lightCount;
+        } else if (pr.kind == PrimSphere && _sphereSrc[size_t(pr.index)].emissionTex >= 0) {
+            _lights.push_back({TGPU_LIGHT_SPHERE, pr.index});
+            ++lightCount;
+        } else if (pr.kind == PrimDisk && _diskSrc[size_t(pr.index)].emissionTex >= 0) {
+            _lights.push_back({TGPU_LIGHT_DISK, pr.index});
             ++lightCount;
         } else if (pr.kind == PrimCube && _cubeSrc[size_t(pr.index)].emissionTex >= 0) {
             throw std::runtime_error("emissive cubes are outside the hot-path scope");

@@ -90,7 +90,13 @@ private:
     struct MasterSrc { int kind; MeshData mesh; QuadSrc quad; CubeSrc cube; };
     struct InstanceSrc { Mat4 transform; std::vector<MasterSrc> masters; std::vector<float> pos, rot; std::vector<uint8_t> id; };
     struct EnvSrc { bool present = false; Mat4 transform; int emissionTex = -1; bool sample = true; };
-    enum PrimKind { PrimMesh, PrimQuad, PrimCube, PrimEnv };
+    enum PrimKind { PrimMesh, PrimQuad, PrimCube, PrimEnv, PrimSphere, PrimDisk };
+    struct SphereSrc { Mat4 transform; int bsdf; int emissionTex; int intMedium = -1, extMedium = -1; };
+    struct DiskSrc { Mat4 transform; int bsdf; int emissionTex; float coneAngle = 90.0f; int intMedium = -1, extMedium = -1; };
+    std::vector<SphereSrc> _sphereSrc;
+    std::vector<DiskSrc> _diskSrc;
+    std::vector<tgpu_sphere> _spheres;
+    std::vector<tgpu_disk> _disks;
     struct PrimRef { PrimKind kind; int index; };
 
     std::vector<std::pair<std::string, int>> _namedBsdfs;

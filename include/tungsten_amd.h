@@ -356,7 +356,9 @@ int tgpu_upload_framebuffer(tgpu_ctx *ctx, const float *rgb_mean, const uint32_t
 /* Ray-level entry points used by the parity tests (TraceableScene::intersect /
  * generalizedShadowRay on dumped ray batches).  rays: n*8 floats
  * (ox,oy,oz,tnear,dx,dy,dz,tfar) in host memory; hits: n*4 floats
- * (t,u,v,bitcast prim id; prim id 0xFFFFFFFF = miss); occluded: n bytes.     */
+ * (t,u,v,bitcast prim id; prim id 0xFFFFFFFF = miss); occluded: n bytes.
+ * prim id = kind << 29 | index, kind: 0 triangle (scene soup index), 1 quad, 2 cube,
+ * 3 instance (index = instance number; u,v of the master hit), 4 sphere, 5 disk (u = r^2). */
 int tgpu_trace_closest(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits);
 int tgpu_trace_occluded(tgpu_ctx *ctx, const float *rays, uint32_t n, uint8_t *occluded);
 

@@ -3075,10 +3075,11 @@ int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *
         uint32_t prim = 0xFFFFFFFFu;
         float u = 0, v = 0;
         if (hit) {
-            uint32_t kind = data.kind == PRIM_TRI ? 0u : data.kind == PRIM_QUAD ? 1u : 2u;
-            prim = (kind << 30) | data.index;
-            if (data.kind != PRIM_CUBE) { u = data.u; v = data.v; }
-            if (data.inst >= 0) prim = (3u << 30) | uint32_t(data.inst); // same convention as tgpu_trace_closest
+            uint32_t kind = data.kind == PRIM_TRI ? 0u : data.kind == PRIM_QUAD ? 1u : data.kind == PRIM_SPHERE ? 4u : data.kind == PRIM_DISK ? 5u : 2u;
+            prim = (kind << 29) | data.index; // tgpu_trace_closest's encoding: kind << 29 | index
+            if (data.kind == PRIM_TRI || data.kind == PRIM_QUAD) { u = data.u; v = data.v; }
+            if (data.kind == PRIM_DISK) u = data.rSq;
+            if (data.inst >= 0) prim = (3u << 29) | uint32_t(data.inst); // same convention as tgpu_trace_closest
         }
         float *h = hits + size_t(i)*4;
         h[0] = hit ? ray.farT : r[7];

@@ -49,6 +49,7 @@ def assert_bit_exact(got, ref, what):
     ("next/plastic.json", (128, 72), 8, 8),
     ("next/rough_plastic.json", (128, 72), 8, 8),
     ("next/dielectric_hg_medium.json", (128, 72), 8, 8),   # Henyey-Greenstein phase function
+    ("next/sphere_disk.json", (128, 72), 8, 8),            # spheres, a disk, a sphere light next to the env light
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)
@@ -59,7 +60,7 @@ def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
 
 
 def test_instance_rays_bit_exact(ta, oracle_py, gpu_ctx):
-    """Ray level: closest hits (t, u, v; instance hits report kind 3 << 30 | instance) and any-hit against the oracle."""
+    """Ray level: closest hits (t, u, v; instance hits report kind 3 << 29 | instance) and any-hit against the oracle."""
     hs = ta.HostScene(scene_path("instances/inst_mesh.json"), resolution=(64, 36))
     gpu_ctx.upload(hs, ta.Shard(hs.res_x, hs.res_y))
     o = oracle_py.Oracle(hs, **oracle_py.GPU)
@@ -73,7 +74,7 @@ def test_instance_rays_bit_exact(ta, oracle_py, gpu_ctx):
     rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d.astype(np.float32), np.full((n, 1), np.inf, np.float32)], axis=1)
     got, ref = gpu_ctx.trace_closest(rays), o.trace_closest(rays)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-    kinds = got[:, 3].view(np.uint32) >> 30
+    kinds = got[:, 3].view(np.uint32) >> 29
     assert (kinds == 3).sum() > 1000 and (got[:, 3].view(np.uint32) == 0xFFFFFFFF).sum() > 100
     rays[:, 7] = rng.uniform(0.5, 6.0, n).astype(np.float32)
     assert np.array_equal(gpu_ctx.trace_occluded(rays), o.trace_occluded(rays))

@@ -90,10 +90,10 @@ def test_abi_struct_sizes_match_the_c_header(ta):
     src = r'''
 #include "tungsten_amd.h"
 #include <stdio.h>
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tgpu_texture), sizeof(tgpu_bitmap),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tgpu_texture), sizeof(tgpu_bitmap),
  sizeof(tgpu_bsdf), sizeof(tgpu_quad), sizeof(tgpu_cube), sizeof(tgpu_env), sizeof(tgpu_camera), sizeof(tgpu_settings),
  sizeof(tgpu_light), sizeof(tgpu_scene_desc), sizeof(tgpu_shard_desc), sizeof(tgpu_stats), sizeof(tgpu_medium),
- sizeof(tgpu_master), sizeof(tgpu_instances), sizeof(tgpu_sample_record));return 0;}'''
+ sizeof(tgpu_master), sizeof(tgpu_instances), sizeof(tgpu_sample_record), sizeof(tgpu_sphere), sizeof(tgpu_disk));return 0;}'''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
         open(c, "w").write(src)
@@ -102,7 +102,7 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %
         sizes = [int(t) for t in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     mirrors = [_abi.Texture, _abi.Bitmap, _abi.Bsdf, _abi.Quad, _abi.Cube, _abi.Env, _abi.Camera, _abi.Settings,
                _abi.Light, _abi.SceneDesc, _abi.ShardDesc, _abi.Stats, _abi.Medium, _abi.Master, _abi.Instances,
-               _abi.SampleRecord]
+               _abi.SampleRecord, _abi.Sphere, _abi.Disk]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

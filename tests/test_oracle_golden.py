@@ -29,6 +29,7 @@ CASES = [
     ("plastic_128x72_4spp", "next/plastic.json", (128, 72), 4),
     ("rough_plastic_128x72_4spp", "next/rough_plastic.json", (128, 72), 4),
     ("dielectric_hg_medium_128x72_4spp", "next/dielectric_hg_medium.json", (128, 72), 4),
+    ("sphere_disk_128x72_4spp", "next/sphere_disk.json", (128, 72), 4),  # spheres, disk, sphere light + env light selection
 ]
 
 

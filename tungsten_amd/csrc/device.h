@@ -83,7 +83,7 @@ enum : uint32_t {
 };
 
 // ---- device scene -----------------------------------------------------------------------------
-struct DBitmap { int32_t w, h, clamp, linear; float scale; const float4 *texels; }; // RGB padded to 16 B: one load per texel
+struct DBitmap { int32_t w, h, clamp, linear; float scale; const float4 *texels; float average[3]; }; // RGB padded to 16 B: one load per texel
 
 // "instances" primitives (primitives/Instance.cpp; host build in instance_bvh.h).
 // BVH2 node = 4 x float4: x-, y-, z-boxes of both children as (lMin, rMin, lMax, rMax) -- the lanes of
@@ -117,6 +117,8 @@ struct DScene {
     const uint8_t *triClass; // BSDF class of each triangle (queue selection in the extend kernel)
     const tgpu_quad *quads; uint32_t nQuads;
     const tgpu_cube *cubes; uint32_t nCubes;
+    const tgpu_sphere *spheres; uint32_t nSpheres;
+    const tgpu_disk *disks; uint32_t nDisks;
     const tgpu_bsdf *bsdfs;
     const tgpu_texture *textures;
     const DBitmap *bitmaps;
@@ -136,12 +138,15 @@ struct DScene {
     int32_t hasForward;       // some BSDF has a ForwardLobe: shadow rays may pass through surfaces (TraceBase.cpp:62-125)
 };
 
-// prim id encoding shared with the C ABI: kind << 30 | index; 0xFFFFFFFF = miss
+// prim id encoding shared with the C ABI: kind << 29 | index; 0xFFFFFFFF = miss
 constexpr uint32_t PRIM_MISS = 0xFFFFFFFFu;
-constexpr uint32_t KIND_TRI = 0u, KIND_QUAD = 1u, KIND_CUBE = 2u, KIND_ENV = 3u;
+constexpr uint32_t KIND_TRI = 0u, KIND_QUAD = 1u, KIND_CUBE = 2u, KIND_ENV = 3u /* also: instance index in ray-level results */,
+                   KIND_SPHERE = 4u, KIND_DISK = 5u;
+constexpr uint32_t PRIM_SHIFT = 29u;
 constexpr uint32_t INST_NONE = 0xFFFFFFFFu; // hitInst: set << 24 | instance, or none
-TG_DEV uint32_t primKind(uint32_t p) { return p >> 30; }
-TG_DEV uint32_t primIndex(uint32_t p) { return p & 0x3FFFFFFFu; }
+TG_DEV uint32_t primKind(uint32_t p) { return p >> PRIM_SHIFT; }
+TG_DEV uint32_t mkPrim(uint32_t kind, uint32_t index) { return (kind << PRIM_SHIFT) | index; }
+TG_DEV uint32_t primIndex(uint32_t p) { return p & 0x1FFFFFFFu; }
 
 // ---- sampler (sampling/SobolPathSampler.hpp:20-84, UniformSampler.hpp:40-52) --------------------
 TG_DEV uint32_t hash32(uint32_t x) // math/MathUtil.hpp:120-128
@@ -378,6 +383,120 @@ TG_DEV bool quadSampleDirect(const tgpu_quad &q, const V3 &p, Sampler &s, LightS
     return true;
 }
 
+// ---- tangent frame (math/TangentFrame.hpp:22-45) ---------------------------------------------------
+struct Frame {
+    V3 normal, tangent, bitangent;
+    TG_DEV V3 toLocal(const V3 &p) const { return V3(tangent.dot(p), bitangent.dot(p), normal.dot(p)); }
+    TG_DEV V3 toGlobal(const V3 &p) const { return tangent*p.x + bitangent*p.y + normal*p.z; }
+};
+TG_DEV Frame duffFrame(const V3 &n)
+{
+    Frame f;
+    f.normal = n;
+    float sign = __builtin_copysignf(1.0f, n.z);
+    const float a = -1.0f/(sign + n.z);
+    const float b = n.x*n.y*a;
+    f.tangent = V3(1.0f + sign*n.x*n.x*a, sign*b, -sign*n.x);
+    f.bitangent = V3(b, sign + n.y*n.y*a, -n.y);
+    return f;
+}
+
+// ---- spheres (primitives/Sphere.cpp:68-92,173-194,224-230) -------------------------------------------
+TG_DEV bool sphereIntersect(const tgpu_sphere &sp, const V3 &pos, const V3 &dir, float nearT, float farT, float &tHit, bool &backSide)
+{
+    V3 p = pos - V3(sp.pos);
+    float B = p.dot(dir);
+    float C = p.lengthSq() - sp.radius*sp.radius;
+    float detSq = B*B - C;
+    if (detSq >= 0.0f) {
+        float det = __builtin_sqrtf(detSq);
+        float t = -B - det;
+        if (t < farT && t > nearT) { tHit = t; backSide = false; return true; }
+        t = -B + det;
+        if (t < farT && t > nearT) { tHit = t; backSide = true; return true; }
+    }
+    return false;
+}
+TG_DEV bool sphereSampleDirect(const tgpu_sphere &sp, const V3 &p, Sampler &s, LightSample &out)
+{
+    V3 L = V3(sp.pos) - p;
+    float d = L.length();
+    float C = d*d - sp.radius*sp.radius;
+    if (C <= 0.0f) return false;
+    L = L.normalized();
+    float cosTheta = __builtin_sqrtf(C)/d;
+    float xi0 = s.next1D(), xi1 = s.next1D();
+    float phi = xi0*TWO_PI; // SampleWarp::uniformSphericalCap (sampling/SampleWarp.hpp:119-129)
+    float z = xi1*(1.0f - cosTheta) + cosTheta;
+    float r = __builtin_sqrtf(fmax2(1.0f - z*z, 0.0f));
+    float sphi, cphi;
+    tgpu_sincosf(phi, &sphi, &cphi);
+    V3 dl(cphi*r, sphi*r, z);
+    float B = d*dl.z;
+    float det = __builtin_sqrtf(fmax2(B*B - C, 0.0f));
+    out.dist = B - det;
+    out.d = duffFrame(L).toGlobal(dl);
+    out.pdf = INV_TWO_PI/(1.0f - cosTheta);
+    return true;
+}
+TG_DEV float sphereDirectPdf(const tgpu_sphere &sp, const V3 &p)
+{
+    float dist = (V3(sp.pos) - p).length();
+    float cosTheta = __builtin_sqrtf(fmax2(dist*dist - sp.radius*sp.radius, 0.0f))/dist;
+    return INV_TWO_PI/(1.0f - cosTheta);
+}
+TG_DEV void sphereUv(const tgpu_sphere &sp, const V3 &Ng, float &u, float &v) // Sphere.cpp:121-125
+{
+    V3 localN = mulVector(sp.inv_rot, Ng);
+    u = tgpu_atan2f(localN.y, localN.x)*INV_TWO_PI + 0.5f;
+    v = tgpu_acosf(clampf(localN.z, -1.0f, 1.0f))*INV_PI;
+    if (isnanf_(u)) u = 0.0f;
+}
+
+// ---- disks (primitives/Disk.cpp:64-86,107-120,177-193,225-232) ---------------------------------------
+struct DiskHit { float t, rSq; V3 p; bool backSide; };
+TG_DEV bool diskIntersect(const tgpu_disk &dk, const V3 &pos, const V3 &dir, float nearT, float farT, DiskHit &h)
+{
+    V3 n(dk.n), center(dk.center);
+    float nDotW = dir.dot(n);
+    float t = n.dot(center - pos)/nDotW;
+    if (t < nearT || t > farT) return false;
+    V3 q = pos + t*dir;
+    V3 v = q - center;
+    float rSq = v.lengthSq();
+    if (rSq > dk.r*dk.r) return false;
+    h.t = t; h.rSq = rSq; h.p = q; h.backSide = -nDotW < dk.cos_apex;
+    return true;
+}
+TG_DEV void diskUv(const tgpu_disk &dk, const V3 &p, float rSq, float &u, float &v)
+{
+    V3 d = p - V3(dk.center);
+    float x = d.dot(V3(dk.bitangent));
+    float y = d.dot(V3(dk.tangent));
+    v = __builtin_sqrtf(rSq)/dk.r;
+    u = (x == 0.0f && y == 0.0f) ? 0.0f : (tgpu_atan2f(y, x)*INV_TWO_PI + 0.5f);
+}
+TG_DEV bool diskSampleDirect(const tgpu_disk &dk, const V3 &p, Sampler &s, LightSample &out)
+{
+    V3 n(dk.n), center(dk.center);
+    if (n.dot(p - center) < 0.0f) return false;
+    float xi0 = s.next1D(), xi1 = s.next1D();
+    float phi = xi0*TWO_PI; // SampleWarp::uniformDisk (:64-69)
+    float rr = __builtin_sqrtf(xi1);
+    float sphi, cphi;
+    tgpu_sincosf(phi, &sphi, &cphi);
+    float lqx = (cphi*rr)*dk.r, lqy = (sphi*rr)*dk.r;
+    V3 q = center + lqx*V3(dk.bitangent) + lqy*V3(dk.tangent);
+    out.d = q - p;
+    float rSq = out.d.lengthSq();
+    out.dist = __builtin_sqrtf(rSq);
+    out.d /= out.dist;
+    if (-out.d.dot(n) < dk.cos_apex) return false;
+    float cosTheta = -n.dot(out.d);
+    out.pdf = rSq/(cosTheta*dk.r*dk.r*PI);
+    return true;
+}
+
 // ---- cubes (primitives/Cube.cpp:94-127) ------------------------------------------------------------
 TG_DEV bool cubeIntersect(const tgpu_cube &cb, const V3 &pos, const V3 &dir, float nearT, float farT, float &tHit, bool &backSide)
 {
@@ -404,23 +523,6 @@ TG_DEV bool cubeIntersect(const tgpu_cube &cb, const V3 &pos, const V3 &dir, flo
     return false;
 }
 
-// ---- tangent frame (math/TangentFrame.hpp:22-45) ---------------------------------------------------
-struct Frame {
-    V3 normal, tangent, bitangent;
-    TG_DEV V3 toLocal(const V3 &p) const { return V3(tangent.dot(p), bitangent.dot(p), normal.dot(p)); }
-    TG_DEV V3 toGlobal(const V3 &p) const { return tangent*p.x + bitangent*p.y + normal*p.z; }
-};
-TG_DEV Frame duffFrame(const V3 &n)
-{
-    Frame f;
-    f.normal = n;
-    float sign = __builtin_copysignf(1.0f, n.z);
-    const float a = -1.0f/(sign + n.z);
-    const float b = n.x*n.y*a;
-    f.tangent = V3(1.0f + sign*n.x*n.x*a, sign*b, -sign*n.x);
-    f.bitangent = V3(b, sign + n.y*n.y*a, -n.y);
-    return f;
-}
 
 // ---- BSDFs ---------------------------------------------------------------------------------------------
 struct Event { // samplerecords/SurfaceScatterEvent.hpp:14-66 (info fields folded in)

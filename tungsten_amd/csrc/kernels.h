@@ -584,12 +584,12 @@ TG_DEV bool instanceIntersect(const DScene &sc, const DInstSet &is, uint32_t set
                 } else if (m.kind == TGPU_MASTER_QUAD) {
                     QuadHit h;
                     if (quadIntersect(sc.quads[m.ref], lo, ld, tMin, TG_INF, h)) {
-                        hitI = true; localFarT = h.t; prim = (KIND_QUAD << 30) | m.ref; u = h.u; v = h.v;
+                        hitI = true; localFarT = h.t; prim = mkPrim(KIND_QUAD, m.ref); u = h.u; v = h.v;
                     }
                 } else {
                     float t = 0.0f;
                     int r = cubeMasterIntersect(sc.cubes[m.ref], lo, ld, tMin, TG_INF, t);
-                    if (r == 2) { localFarT = t; prim = (KIND_CUBE << 30) | m.ref; u = 0.0f; v = 0.0f; }
+                    if (r == 2) { localFarT = t; prim = mkPrim(KIND_CUBE, m.ref); u = 0.0f; v = 0.0f; }
                     hitI = r != 0;
                 }
                 if (hitI) {
@@ -636,7 +636,7 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
         QuadHit h;
         if (quadIntersect(sc.quads[i], O, D, tnear, tfar, h)) {
             tfar = h.t; u = h.u; v = h.v;
-            prim = (KIND_QUAD << 30) | i;
+            prim = mkPrim(KIND_QUAD, i);
             inst = INST_NONE;
         }
     }
@@ -645,7 +645,24 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
         bool back;
         if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, t, back)) {
             tfar = t; u = 0.0f; v = 0.0f;
-            prim = (KIND_CUBE << 30) | i;
+            prim = mkPrim(KIND_CUBE, i);
+            inst = INST_NONE;
+        }
+    }
+    for (uint32_t i = 0; i < sc.nSpheres; ++i) {
+        float t;
+        bool back;
+        if (sphereIntersect(sc.spheres[i], O, D, tnear, tfar, t, back)) {
+            tfar = t; u = 0.0f; v = 0.0f;
+            prim = mkPrim(KIND_SPHERE, i);
+            inst = INST_NONE;
+        }
+    }
+    for (uint32_t i = 0; i < sc.nDisks; ++i) {
+        DiskHit h;
+        if (diskIntersect(sc.disks[i], O, D, tnear, tfar, h)) {
+            tfar = h.t; u = h.rSq; v = 0.0f; // u carries DiskIntersection::rSq
+            prim = mkPrim(KIND_DISK, i);
             inst = INST_NONE;
         }
     }
@@ -668,7 +685,7 @@ template <bool COUNT, bool INST>
 TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D, float tnear, float tfar, uint32_t endCap, TraceCounters &tc)
 {
     if (INST) {
-        if (primKind(endCap) == KIND_QUAD && endCap != PRIM_MISS) {
+        if (endCap != PRIM_MISS && primKind(endCap) != KIND_ENV) {
             // finite end cap: an instance may leave farT BEYOND the light (its local rays run to infinity), in which case
             // the light quad itself becomes the final hit and the ray counts as unblocked -- only the full
             // closest-hit query of generalizedShadowRay (TraceBase.cpp:79) reproduces that
@@ -684,7 +701,7 @@ TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
         }
     }
     for (uint32_t i = 0; i < sc.nQuads; ++i) {
-        if (((KIND_QUAD << 30) | i) == endCap) continue;
+        if (mkPrim(KIND_QUAD, i) == endCap) continue;
         QuadHit h;
         if (quadIntersect(sc.quads[i], O, D, tnear, tfar, h)) return true;
     }
@@ -692,6 +709,17 @@ TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
         float t;
         bool back;
         if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, t, back)) return true;
+    }
+    for (uint32_t i = 0; i < sc.nSpheres; ++i) {
+        if (mkPrim(KIND_SPHERE, i) == endCap) continue;
+        float t;
+        bool back;
+        if (sphereIntersect(sc.spheres[i], O, D, tnear, tfar, t, back)) return true;
+    }
+    for (uint32_t i = 0; i < sc.nDisks; ++i) {
+        if (mkPrim(KIND_DISK, i) == endCap) continue;
+        DiskHit h;
+        if (diskIntersect(sc.disks[i], O, D, tnear, tfar, h)) return true;
     }
     if (sc.nTris) {
         float t = tfar, u, v;
@@ -721,6 +749,8 @@ TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
     uint32_t kind = primKind(prim), idx = primIndex(prim), type;
     if (kind == KIND_TRI) type = sc.triClass[idx];
     else if (kind == KIND_QUAD) type = uint32_t(sc.bsdfs[sc.quads[idx].bsdf].type);
+    else if (kind == KIND_SPHERE) type = uint32_t(sc.bsdfs[sc.spheres[idx].bsdf].type);
+    else if (kind == KIND_DISK) type = uint32_t(sc.bsdfs[sc.disks[idx].bsdf].type);
     else type = uint32_t(sc.bsdfs[sc.cubes[idx].bsdf].type);
     return type < uint32_t(TG_CLASS_OTHER) ? type : uint32_t(TG_CLASS_OTHER);
 }
@@ -773,7 +803,7 @@ __global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, u
                     uint32_t inst;
                     uint32_t prim = closestHit<COUNT, INST>(sc, stack, O, D, ro.w, tfar, u, v, inst, tc);
                     if (INST) {
-                        if (RAW) { if (inst != INST_NONE) prim = (3u << 30) | (inst & 0xFFFFFFu); } // ray-level ABI: kind 3 = instance index
+                        if (RAW) { if (inst != INST_NONE) prim = mkPrim(KIND_ENV, inst & 0xFFFFFFu); } // ray-level ABI: kind 3 = instance index
                         else stStream(&st.hitInst[path], inst);
                     }
                     stStream(&st.hit[path], make_float4(tfar, u, v, __uint_as_float(prim)));
@@ -899,6 +929,34 @@ TG_DEV void fetchHitInfo(const DScene &sc, uint32_t prim, const V3 &O, const V3 
         info.backSide = D.dot(V3(q.normal)) >= 0.0f;
         info.intMedium = q.int_medium;
         info.extMedium = q.ext_medium;
+    } else if (kind == KIND_SPHERE) { // primitives/Sphere.cpp:119-128
+        const tgpu_sphere &sp = sc.spheres[idx];
+        info.p = O + D*t;
+        info.Ns = info.Ng = (info.p - V3(sp.pos))/sp.radius;
+        sphereUv(sp, info.Ng, info.uvx, info.uvy);
+        info.bsdf = sp.bsdf;
+        info.emissive = sp.emission_tex >= 0;
+        info.emissionTex = sp.emission_tex;
+        { // SphereIntersection::backSide: which root was taken (Sphere.cpp:74-90)
+            V3 pp = O - V3(sp.pos);
+            float B = pp.dot(D);
+            float C = pp.lengthSq() - sp.radius*sp.radius;
+            float det = __builtin_sqrtf(B*B - C);
+            info.backSide = t != -B - det;
+        }
+        info.intMedium = sp.int_medium;
+        info.extMedium = sp.ext_medium;
+    } else if (kind == KIND_DISK) { // primitives/Disk.cpp:64-86,107-120
+        const tgpu_disk &dk = sc.disks[idx];
+        info.p = O + t*D;
+        info.Ng = info.Ns = V3(dk.n);
+        diskUv(dk, info.p, u, info.uvx, info.uvy); // u carries rSq
+        info.bsdf = dk.bsdf;
+        info.emissive = dk.emission_tex >= 0;
+        info.emissionTex = dk.emission_tex;
+        info.backSide = -D.dot(V3(dk.n)) < dk.cos_apex;
+        info.intMedium = dk.int_medium;
+        info.extMedium = dk.ext_medium;
     } else { // primitives/Cube.cpp:157-170
         const tgpu_cube &cb = sc.cubes[idx];
         info.p = O + D*t;
@@ -957,18 +1015,115 @@ TG_DEV float envDirectPdf(const DScene &sc, const V3 &w, float &ux, float &uy)
 TG_DEV float powerHeuristic(float pdf0, float pdf1) { return (pdf0*pdf0)/(pdf0*pdf0 + pdf1*pdf1); } // SampleWarp.hpp:189-192
 
 // Quad::approximateRadiance (Quad.cpp:256-279); env returns "unknown" (-1), see chooseLight
+// ---- lights: environment, quad, sphere, disk -----------------------------------------------------------
+TG_DEV uint32_t lightPrim(const tgpu_light &l)
+{
+    const uint32_t kind = l.kind == TGPU_LIGHT_ENV ? KIND_ENV : (l.kind == TGPU_LIGHT_SPHERE ? KIND_SPHERE : (l.kind == TGPU_LIGHT_DISK ? KIND_DISK : KIND_QUAD));
+    return mkPrim(kind, l.kind == TGPU_LIGHT_ENV ? 0u : uint32_t(l.index));
+}
+TG_DEV bool lightSampleDirect(const DScene &sc, const tgpu_light &l, const V3 &p, Sampler &smp, LightSample &ls)
+{
+    if (l.kind == TGPU_LIGHT_ENV) return envSampleDirect(sc, smp, ls);
+    if (l.kind == TGPU_LIGHT_SPHERE) return sphereSampleDirect(sc.spheres[l.index], p, smp, ls);
+    if (l.kind == TGPU_LIGHT_DISK) return diskSampleDirect(sc.disks[l.index], p, smp, ls);
+    return quadSampleDirect(sc.quads[l.index], p, smp, ls);
+}
+// attenuatedEmission (TraceBase.cpp:144-174) for a finite light, up to the shadow test: light.intersect(ray) with the
+// 1.001 fudge against the expected distance (none when < 0), evalDirect at the hit, directPdf seen from the ray origin
+TG_DEV bool finiteLightHit(const DScene &sc, const tgpu_light &l, const V3 &O, const V3 &D, float nearT, float expectedDist, float &farT, V3 &E,
+                           float &pdf)
+{
+    if (l.kind == TGPU_LIGHT_SPHERE) {
+        const tgpu_sphere &sp = sc.spheres[l.index];
+        float t;
+        bool back;
+        if (!sphereIntersect(sp, O, D, nearT, TG_INF, t, back)) return false;
+        if (t*(1.0f + 1e-3f) < expectedDist) return false;
+        farT = t;
+        if (back) {
+            E = V3(0.0f);
+        } else {
+            V3 Ng = ((O + D*t) - V3(sp.pos))/sp.radius;
+            float u, v;
+            sphereUv(sp, Ng, u, v);
+            E = texEval(sc, sp.emission_tex, u, v);
+        }
+        pdf = sphereDirectPdf(sp, O);
+        return true;
+    }
+    if (l.kind == TGPU_LIGHT_DISK) {
+        const tgpu_disk &dk = sc.disks[l.index];
+        DiskHit h;
+        if (!diskIntersect(dk, O, D, nearT, TG_INF, h)) return false;
+        if (h.t*(1.0f + 1e-3f) < expectedDist) return false;
+        farT = h.t;
+        if (h.backSide) {
+            E = V3(0.0f);
+        } else {
+            float u, v;
+            diskUv(dk, h.p, h.rSq, u, v);
+            E = texEval(sc, dk.emission_tex, u, v);
+        }
+        V3 n(dk.n); // Disk::directPdf :225-232
+        float cosTheta = __builtin_fabsf(n.dot(D));
+        float td = n.dot(V3(dk.center) - O)/n.dot(D);
+        pdf = td*td/(cosTheta*dk.r*dk.r*PI);
+        return true;
+    }
+    const tgpu_quad &lq = sc.quads[l.index];
+    QuadHit qh;
+    if (!quadIntersect(lq, O, D, nearT, TG_INF, qh)) return false;
+    if (qh.t*(1.0f + 1e-3f) < expectedDist) return false;
+    farT = qh.t;
+    E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
+    V3 normal(lq.normal); // Quad::directPdf :216-223
+    float cosTheta = __builtin_fabsf(normal.dot(D));
+    float tq = normal.dot(V3(lq.base) - O)/normal.dot(D);
+    pdf = tq*tq/(cosTheta*lq.area);
+    return true;
+}
+TG_DEV float texAverageMax(const DScene &sc, int tex) // Texture::average().max()
+{
+    const tgpu_texture &t = sc.textures[tex];
+    V3 a;
+    if (t.type == TGPU_TEX_CONSTANT) a = V3(t.value);
+    else if (t.type == TGPU_TEX_CHECKER) a = (V3(t.on_color) + V3(t.off_color))*0.5f;
+    else a = sc.bitmaps[t.bitmap].scale*V3(sc.bitmaps[t.bitmap].average);
+    return a.max();
+}
+
 TG_DEV float lightApproximateRadiance(const DScene &sc, const tgpu_light &l, const V3 &p)
 {
-    if (l.kind == TGPU_LIGHT_ENV) return -1.0f;
-    const tgpu_quad &q = sc.quads[l.index];
+    if (l.kind == TGPU_LIGHT_ENV) return TWO_PI*texAverageMax(sc, sc.env.emission_tex); // InfiniteSphere.cpp:261-266
+    if (l.kind == TGPU_LIGHT_SPHERE) { // Sphere.cpp:33-40,266-271
+        const tgpu_sphere &sp = sc.spheres[l.index];
+        V3 L = V3(sp.pos) - p;
+        float d = L.length();
+        float cosTheta = __builtin_sqrtf(fmax2(d*d - sp.radius*sp.radius, 0.0f))/d;
+        return (TWO_PI*(1.0f - cosTheta))*texAverageMax(sc, sp.emission_tex);
+    }
+    if (l.kind == TGPU_LIGHT_DISK) { // Disk.cpp:268-296
+        const tgpu_disk &dk = sc.disks[l.index];
+        V3 n(dk.n);
+        V3 coneD = p - V3(dk.cone_base);
+        if (coneD.dot(n)/coneD.length() < dk.cos_apex) return 0.0f;
+        V3 d = V3(dk.center) - p;
+        V3 edge0 = V3(dk.tangent)*dk.r, edge1 = V3(dk.bitangent)*dk.r;
+        V3 R0 = d - edge0 - edge1;
+        V3 R1 = R0 + 2.0f*edge0;
+        V3 R2 = R1 + 2.0f*edge1;
+        V3 R3 = R0 + 2.0f*edge1;
+        V3 n0 = R0.cross(R1).normalized(), n1 = R1.cross(R2).normalized(), n2 = R2.cross(R3).normalized(), n3 = R3.cross(R0).normalized();
+        float Q = tgpu_acosf(n0.dot(n1)) + tgpu_acosf(n1.dot(n2)) + tgpu_acosf(n2.dot(n3)) + tgpu_acosf(n3.dot(n0));
+        return (TWO_PI - __builtin_fabsf(Q))*texAverageMax(sc, dk.emission_tex);
+    }
+    const tgpu_quad &q = sc.quads[l.index]; // Quad.cpp:256-279
     V3 R0 = V3(q.base) - p;
     if (R0.dot(V3(q.normal)) >= 0.0f) return 0.0f;
     V3 R1 = R0 + V3(q.edge0), R2 = R1 + V3(q.edge1), R3 = R0 + V3(q.edge1);
     V3 n0 = R0.cross(R1).normalized(), n1 = R1.cross(R2).normalized(), n2 = R2.cross(R3).normalized(), n3 = R3.cross(R0).normalized();
     float Q = tgpu_acosf(n0.dot(n1)) + tgpu_acosf(n1.dot(n2)) + tgpu_acosf(n2.dot(n3)) + tgpu_acosf(n3.dot(n0));
-    const tgpu_texture &t = sc.textures[q.emission_tex];
-    V3 avg = t.type == TGPU_TEX_CONSTANT ? V3(t.value) : V3(0.5f);
-    return (TWO_PI - __builtin_fabsf(Q))*avg.max();
+    return (TWO_PI - __builtin_fabsf(Q))*texAverageMax(sc, q.emission_tex);
 }
 
 // TraceBase::chooseLight (TraceBase.cpp:416-459); up to TG_MAX_LIGHTS samplable lights
@@ -1324,11 +1479,11 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
         if (lightIdx >= 0) {
             const tgpu_light light = sc.lights[lightIdx];
             const bool isEnv = light.kind == TGPU_LIGHT_ENV;
-            endCap = isEnv ? ((KIND_ENV << 30) | 0u) : ((KIND_QUAD << 30) | uint32_t(light.index));
+            endCap = lightPrim(light);
             const bool shadowPasses = bounce + 1 >= minBounces;
             { // volumeLightSample
                 LightSample ls;
-                bool okL = isEnv ? envSampleDirect(sc, smp, ls) : quadSampleDirect(sc.quads[light.index], p, smp, ls);
+                bool okL = lightSampleDirect(sc, light, p, smp, ls);
                 if (okL) {
                     V3 f(phaseEval(m, D, ls.d)); // phase->eval(parentRay.dir(), lightSample.d)
                     V3 E(0.0f);
@@ -1339,13 +1494,8 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                         if (sc.envConstant) E = V3(sc.textures[sc.env.emission_tex].value);
                         else { directionToUV(sc, ls.d, ux, uy, nullptr); E = texEval(sc, sc.env.emission_tex, ux, uy); }
                     } else {
-                        QuadHit qh;
-                        const tgpu_quad &lq = sc.quads[light.index];
-                        lit = quadIntersect(lq, p, ls.d, 0.0f, TG_INF, qh) && !(qh.t*(1.0f + 1e-3f) < ls.dist);
-                        if (lit) {
-                            farT = qh.t;
-                            E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
-                        }
+                        float lightPdfUnused;
+                        lit = finiteLightHit(sc, light, p, ls.d, 0.0f, ls.dist, farT, E, lightPdfUnused);
                     }
                     if (!fwdScene) E = neeTransmittance(sc, medium, farT, false)*E;
                     if (lit && shadowPasses && !E.isZero()) {
@@ -1370,17 +1520,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
                     lightPdf = envDirectPdf(sc, w, ux, uy);
                     E = sc.envConstant ? V3(sc.textures[sc.env.emission_tex].value) : texEval(sc, sc.env.emission_tex, ux, uy);
                 } else {
-                    QuadHit qh;
-                    const tgpu_quad &lq = sc.quads[light.index];
-                    lit = quadIntersect(lq, p, w, 0.0f, TG_INF, qh);
-                    if (lit) {
-                        farT = qh.t;
-                        E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
-                        V3 normal(lq.normal);
-                        float cosTheta = __builtin_fabsf(normal.dot(w));
-                        float tq = normal.dot(V3(lq.base) - p)/normal.dot(w);
-                        lightPdf = tq*tq/(cosTheta*lq.area);
-                    }
+                    lit = finiteLightHit(sc, light, p, w, 0.0f, -1.0f, farT, E, lightPdf); // expectedDist = -1 never rejects
                 }
                 if (!fwdScene) E = neeTransmittance(sc, medium, farT, false)*E;
                 if (lit && shadowPasses && !E.isZero()) {
@@ -1534,13 +1674,13 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
             if (haveLight && !pureSpecular && lobes != ForwardLobe) { // sampleDirect (TraceBase.cpp:383-400)
                 const tgpu_light light = sc.lights[lightIdx];
                 const bool isEnv = light.kind == TGPU_LIGHT_ENV;
-                endCap = isEnv ? ((KIND_ENV << 30) | 0u) : ((KIND_QUAD << 30) | uint32_t(light.index));
+                endCap = lightPrim(light);
                 const bool shadowPasses = bounce + 1 >= minBounces; // generalizedShadowRay's minBounces rule
 
                 // ---- lightSample (TraceBase.cpp:246-285) ----
                 {
                     LightSample ls;
-                    bool ok = isEnv ? envSampleDirect(sc, smp, ls) : quadSampleDirect(sc.quads[light.index], info.p, smp, ls);
+                    bool ok = lightSampleDirect(sc, light, info.p, smp, ls);
                     if (ok) {
                         ev.wo = ev.frame.toLocal(ls.d);
                         bool consistent = true;
@@ -1561,13 +1701,8 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
                                 if (sc.envConstant) E = V3(sc.textures[sc.env.emission_tex].value);
                                 else { directionToUV(sc, ls.d, ux, uy, nullptr); E = texEval(sc, sc.env.emission_tex, ux, uy); }
                             } else {
-                                QuadHit qh;
-                                const tgpu_quad &lq = sc.quads[light.index];
-                                lit = quadIntersect(lq, info.p, ls.d, eps, TG_INF, qh) && !(qh.t*(1.0f + 1e-3f) < ls.dist);
-                                if (lit) {
-                                    farT = qh.t;
-                                    E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
-                                }
+                                float lightPdfUnused;
+                                lit = finiteLightHit(sc, light, info.p, ls.d, eps, ls.dist, farT, E, lightPdfUnused);
                             }
                             // generalizedShadowRay: the medium on the light's side attenuates the unoccluded segment (:261-262, :100-108)
                             if (media) {
@@ -1606,17 +1741,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
                                 lightPdf = envDirectPdf(sc, wo, ux, uy);
                                 E = sc.envConstant ? V3(sc.textures[sc.env.emission_tex].value) : texEval(sc, sc.env.emission_tex, ux, uy);
                             } else {
-                                QuadHit qh;
-                                const tgpu_quad &lq = sc.quads[light.index];
-                                lit = quadIntersect(lq, info.p, wo, eps, TG_INF, qh); // expectedDist = -1 never rejects
-                                if (lit) {
-                                    farT = qh.t;
-                                    E = qh.backSide ? V3(0.0f) : texEval(sc, lq.emission_tex, qh.u, qh.v);
-                                    V3 normal(lq.normal);
-                                    float cosTheta = __builtin_fabsf(normal.dot(wo));
-                                    float tq = normal.dot(V3(lq.base) - info.p)/normal.dot(wo);
-                                    lightPdf = tq*tq/(cosTheta*lq.area);
-                                }
+                                lit = finiteLightHit(sc, light, info.p, wo, eps, -1.0f, farT, E, lightPdf); // expectedDist = -1 never rejects
                             }
                             if (media) { // :301-302
                                 mediumB = overridesMedia ? (wo.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium;
@@ -1787,6 +1912,16 @@ TG_DEV V3 shadowWalk(const DScene &sc, uint32_t *stack, V3 O, const V3 &D, float
                 const tgpu_quad &q = sc.quads[idx];
                 bsdf = q.bsdf; intMedium = q.int_medium; extMedium = q.ext_medium;
                 backSide = D.dot(V3(q.normal)) >= 0.0f;        // Quad.cpp:93
+            } else if (kind == KIND_SPHERE) {
+                const tgpu_sphere &sp = sc.spheres[idx];
+                bsdf = sp.bsdf; intMedium = sp.int_medium; extMedium = sp.ext_medium;
+                float ts = 0.0f; // Sphere.cpp:74-90: the near root if it lies inside (nearT, farT), else the far one
+                bool front = sphereIntersect(sp, O, D, tnear, TG_INF, ts, backSide);
+                if (!front || ts != t) backSide = true;
+            } else if (kind == KIND_DISK) {
+                const tgpu_disk &dk = sc.disks[idx];
+                bsdf = dk.bsdf; intMedium = dk.int_medium; extMedium = dk.ext_medium;
+                backSide = -D.dot(V3(dk.n)) < dk.cos_apex;       // Disk.cpp:82
             } else {
                 const tgpu_cube &cb = sc.cubes[idx];
                 bsdf = cb.bsdf; intMedium = cb.int_medium; extMedium = cb.ext_medium;

@@ -195,12 +195,24 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         if (!bsdfOk(s->cubes[i].bsdf)) { fail(ctx, "cube %u references bsdf %d", i, s->cubes[i].bsdf); return TGPU_ERR_INVALID; }
         if (s->cubes[i].emission_tex >= 0) { fail(ctx, "emissive cubes are outside the hot-path scope"); return TGPU_ERR_UNSUPPORTED; }
     }
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const tgpu_sphere &sp = s->spheres[i];
+        if (!bsdfOk(sp.bsdf) || (sp.emission_tex >= 0 && !texOk(sp.emission_tex)) || !(sp.radius > 0.0f)) { fail(ctx, "sphere %u: bad bsdf / emission / radius", i); return TGPU_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < s->n_disks; ++i) {
+        const tgpu_disk &dk = s->disks[i];
+        if (!bsdfOk(dk.bsdf) || (dk.emission_tex >= 0 && !texOk(dk.emission_tex)) || !(dk.r > 0.0f)) { fail(ctx, "disk %u: bad bsdf / emission / radius", i); return TGPU_ERR_INVALID; }
+    }
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const tgpu_light &l = s->lights[i];
         if (l.kind == TGPU_LIGHT_ENV) {
             if (!s->env.present) { fail(ctx, "light %u is the environment but env.present is 0", i); return TGPU_ERR_INVALID; }
         } else if (l.kind == TGPU_LIGHT_QUAD) {
             if (l.index < 0 || uint32_t(l.index) >= s->n_quads || s->quads[l.index].emission_tex < 0) { fail(ctx, "light %u: bad quad", i); return TGPU_ERR_INVALID; }
+        } else if (l.kind == TGPU_LIGHT_SPHERE) {
+            if (l.index < 0 || uint32_t(l.index) >= s->n_spheres || s->spheres[l.index].emission_tex < 0) { fail(ctx, "light %u: bad sphere", i); return TGPU_ERR_INVALID; }
+        } else if (l.kind == TGPU_LIGHT_DISK) {
+            if (l.index < 0 || uint32_t(l.index) >= s->n_disks || s->disks[l.index].emission_tex < 0) { fail(ctx, "light %u: bad disk", i); return TGPU_ERR_INVALID; }
         } else { fail(ctx, "light %u has unknown kind", i); return TGPU_ERR_INVALID; }
     }
     // participating media
@@ -212,6 +224,10 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         if (!mediumOk(s->quads[i].int_medium) || !mediumOk(s->quads[i].ext_medium)) { fail(ctx, "quad %u: bad medium", i); return TGPU_ERR_INVALID; }
     for (uint32_t i = 0; i < s->n_cubes + s->n_master_cubes; ++i)
         if (!mediumOk(s->cubes[i].int_medium) || !mediumOk(s->cubes[i].ext_medium)) { fail(ctx, "cube %u: bad medium", i); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_spheres; ++i)
+        if (!mediumOk(s->spheres[i].int_medium) || !mediumOk(s->spheres[i].ext_medium)) { fail(ctx, "sphere %u: bad medium", i); return TGPU_ERR_INVALID; }
+    for (uint32_t i = 0; i < s->n_disks; ++i)
+        if (!mediumOk(s->disks[i].int_medium) || !mediumOk(s->disks[i].ext_medium)) { fail(ctx, "disk %u: bad medium", i); return TGPU_ERR_INVALID; }
     if (s->tri_media)
         for (uint32_t i = 0; i < s->n_tris + s->n_master_tris; ++i)
             if (!mediumOk(s->tri_media[size_t(i)*2]) || !mediumOk(s->tri_media[size_t(i)*2 + 1])) { fail(ctx, "triangle %u: bad medium", i); return TGPU_ERR_INVALID; }
@@ -494,6 +510,13 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if ((rc = upload(ctx, ctx->allocs, s->lights, s->n_lights, &dLights))) return rc;
     sc.quads = dQuads; sc.nQuads = s->n_quads;
     sc.cubes = dCubes; sc.nCubes = s->n_cubes;
+    {
+        tgpu_sphere *dSpheres; tgpu_disk *dDisks;
+        if ((rc = upload(ctx, ctx->allocs, s->spheres, s->n_spheres, &dSpheres))) return rc;
+        if ((rc = upload(ctx, ctx->allocs, s->disks, s->n_disks, &dDisks))) return rc;
+        sc.spheres = dSpheres; sc.nSpheres = s->n_spheres;
+        sc.disks = dDisks; sc.nDisks = s->n_disks;
+    }
     sc.bsdfs = dBsdfs;
     sc.hasForward = 0;
     ctx->classMask = 0;
@@ -526,7 +549,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         for (size_t t = 0; t < padded.size(); ++t) padded[t] = make_float4(b.texels[t*3], b.texels[t*3 + 1], b.texels[t*3 + 2], 0.0f);
         float4 *dTexels;
         if ((rc = upload(ctx, ctx->allocs, padded.data(), padded.size(), &dTexels))) return rc;
-        bitmaps[i] = DBitmap{b.w, b.h, b.clamp, b.linear, b.scale, dTexels};
+        bitmaps[i] = DBitmap{b.w, b.h, b.clamp, b.linear, b.scale, dTexels, {b.average[0], b.average[1], b.average[2]}};
     }
     DBitmap *dBitmaps;
     if ((rc = upload(ctx, ctx->allocs, bitmaps.data(), bitmaps.size(), &dBitmaps))) return rc;

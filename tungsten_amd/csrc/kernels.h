@@ -649,7 +649,8 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
             inst = INST_NONE;
         }
     }
-    for (uint32_t i = 0; i < sc.nSpheres; ++i) {
+    // spheres and disks: only in the general-geometry (INST) instantiation, so that scenes without them keep the lean kernels
+    for (uint32_t i = 0; INST && i < sc.nSpheres; ++i) {
         float t;
         bool back;
         if (sphereIntersect(sc.spheres[i], O, D, tnear, tfar, t, back)) {
@@ -658,7 +659,7 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
             inst = INST_NONE;
         }
     }
-    for (uint32_t i = 0; i < sc.nDisks; ++i) {
+    for (uint32_t i = 0; INST && i < sc.nDisks; ++i) {
         DiskHit h;
         if (diskIntersect(sc.disks[i], O, D, tnear, tfar, h)) {
             tfar = h.t; u = h.rSq; v = 0.0f; // u carries DiskIntersection::rSq
@@ -684,7 +685,7 @@ TG_DEV uint32_t closestHit(const DScene &sc, uint32_t *stack, const V3 &O, const
 template <bool COUNT, bool INST>
 TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D, float tnear, float tfar, uint32_t endCap, TraceCounters &tc)
 {
-    if (INST) {
+    if (INST && sc.nInstSets) {
         if (endCap != PRIM_MISS && primKind(endCap) != KIND_ENV) {
             // finite end cap: an instance may leave farT BEYOND the light (its local rays run to infinity), in which case
             // the light quad itself becomes the final hit and the ray counts as unblocked -- only the full
@@ -710,13 +711,13 @@ TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
         bool back;
         if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, t, back)) return true;
     }
-    for (uint32_t i = 0; i < sc.nSpheres; ++i) {
+    for (uint32_t i = 0; INST && i < sc.nSpheres; ++i) {
         if (mkPrim(KIND_SPHERE, i) == endCap) continue;
         float t;
         bool back;
         if (sphereIntersect(sc.spheres[i], O, D, tnear, tfar, t, back)) return true;
     }
-    for (uint32_t i = 0; i < sc.nDisks; ++i) {
+    for (uint32_t i = 0; INST && i < sc.nDisks; ++i) {
         if (mkPrim(KIND_DISK, i) == endCap) continue;
         DiskHit h;
         if (diskIntersect(sc.disks[i], O, D, tnear, tfar, h)) return true;
@@ -1092,8 +1093,10 @@ TG_DEV float texAverageMax(const DScene &sc, int tex) // Texture::average().max(
     return a.max();
 }
 
+template <bool LEAN>
 TG_DEV float lightApproximateRadiance(const DScene &sc, const tgpu_light &l, const V3 &p)
 {
+    if (LEAN) __builtin_assume(l.kind == TGPU_LIGHT_ENV || l.kind == TGPU_LIGHT_QUAD);
     if (l.kind == TGPU_LIGHT_ENV) return TWO_PI*texAverageMax(sc, sc.env.emission_tex); // InfiniteSphere.cpp:261-266
     if (l.kind == TGPU_LIGHT_SPHERE) { // Sphere.cpp:33-40,266-271
         const tgpu_sphere &sp = sc.spheres[l.index];
@@ -1128,6 +1131,7 @@ TG_DEV float lightApproximateRadiance(const DScene &sc, const tgpu_light &l, con
 
 // TraceBase::chooseLight (TraceBase.cpp:416-459); up to TG_MAX_LIGHTS samplable lights
 #define TG_MAX_LIGHTS 8
+template <bool LEAN>
 TG_DEV int chooseLight(const DScene &sc, const V3 &p, Sampler &smp, float &weight)
 {
     if (sc.nLights == 0) return -1;
@@ -1143,7 +1147,7 @@ TG_DEV int chooseLight(const DScene &sc, const V3 &p, Sampler &smp, float &weigh
     for (uint32_t i = 0; i < TG_MAX_LIGHTS; ++i) {
         lightPdf[i] = 0.0f;
         if (i < n) {
-            lightPdf[i] = lightApproximateRadiance(sc, sc.lights[i], p);
+            lightPdf[i] = lightApproximateRadiance<LEAN>(sc, sc.lights[i], p);
             if (lightPdf[i] >= 0.0f) {
                 total += lightPdf[i];
                 numNonNegative++;
@@ -1475,7 +1479,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     uint32_t endCap = PRIM_MISS;
     const V3 tpVertex = tp;
     if (volumeNee && bounce < maxBounces - 1 && sc.nLights > 0) {
-        int lightIdx = chooseLight(sc, p, smp, pickWeight);
+        int lightIdx = chooseLight<false>(sc, p, smp, pickWeight);
         if (lightIdx >= 0) {
             const tgpu_light light = sc.lights[lightIdx];
             const bool isEnv = light.kind == TGPU_LIGHT_ENV;
@@ -1590,7 +1594,8 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
 // One surface vertex of one path (the body of the shade kernels; the tail kernel calls it too):
 // TraceBase::handleSurface + the loop tail of PathTracer::traceSample.
 // CLASS >= 0: the caller guarantees the hit BSDF's type (the per-class shade kernels), which lets the compiler drop the
-// code of the other BSDFs; MEDIA = false compiles the medium bookkeeping out.
+// code of the other BSDFs; MEDIA = false is the lean instantiation: no medium bookkeeping, only environment and quad
+// lights (the launcher picks the general one for scenes with media or sphere / disk lights).
 template <int CLASS, bool MEDIA>
 TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium)
 {
@@ -1619,6 +1624,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
 
         uint32_t prim = __float_as_uint(hw.w);
         HitInfo info;
+        if (!MEDIA) __builtin_assume(primKind(prim) <= KIND_CUBE); // lean instantiation: no spheres / disks in the scene
         fetchHitInfo(sc, prim, O, D, hw.x, hw.y, hw.z, info);
         if (sc.nInstSets) {
             const uint32_t inst = st.hitInst[path];
@@ -1653,7 +1659,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         // hit.  transparency = bsdf.eval(forward event): (1,1,1) for a ForwardBsdf (ForwardBsdf.cpp:26-29; avg() == 1.0f),
         // zero for every other BSDF in scope
         const bool passThrough = smp.nextBoolean((lobes & ForwardLobe) ? 1.0f : 0.0f);
-        const bool fwdScene = sc.hasForward != 0; // shadow rays may cross surfaces: the shadow kernel applies the media
+        const bool fwdScene = MEDIA && sc.hasForward != 0; // shadow rays may cross surfaces: the shadow kernel applies the media
         int mediumL = -1, mediumB = -1;
 
         const float eps = 5e-4f; // TraceableScene.hpp:39
@@ -1668,11 +1674,12 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
 
         if (!passThrough && neeEnabled && bounce < maxBounces - 1 && sc.nLights > 0) {
             // estimateDirect -> chooseLight (TraceBase.cpp:416-459)
-            int lightIdx = chooseLight(sc, info.p, smp, pickWeight);
+            int lightIdx = chooseLight<!MEDIA>(sc, info.p, smp, pickWeight);
             bool haveLight = lightIdx >= 0;
             bool pureSpecular = lobes != 0 && (lobes & ~uint32_t(SpecularLobe)) == 0;
             if (haveLight && !pureSpecular && lobes != ForwardLobe) { // sampleDirect (TraceBase.cpp:383-400)
                 const tgpu_light light = sc.lights[lightIdx];
+                if (!MEDIA) __builtin_assume(light.kind == TGPU_LIGHT_ENV || light.kind == TGPU_LIGHT_QUAD); // lean instantiation
                 const bool isEnv = light.kind == TGPU_LIGHT_ENV;
                 endCap = lightPrim(light);
                 const bool shadowPasses = bounce + 1 >= minBounces; // generalizedShadowRay's minBounces rule

@@ -57,6 +57,8 @@ struct tgpu_ctx {
         std::vector<uint32_t> offsets, vtIndex; // adaptive jobs: per-pixel sample offsets, per-tile sample index
     };
     uint32_t classMask = 0;               // BSDF classes (shade kernels) the uploaded scene can hit
+    bool generalGeometry = false;         // instances, spheres or disks: INST instantiation of the traversal kernels
+    bool generalShading = false;          // media, spheres or disks (also as lights): general instantiation of the shade kernels
     bool trackRecords = false;            // settings.adaptive_sampling
     uint32_t varW = 0, varH = 0;
     std::vector<uint32_t> vtGlobal;       // local variance tile -> whole-image variance tile
@@ -519,9 +521,13 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     }
     sc.bsdfs = dBsdfs;
     sc.hasForward = 0;
+    ctx->generalGeometry = s->n_instance_sets || s->n_spheres || s->n_disks;
+    ctx->generalShading = s->n_media != 0 || s->n_spheres || s->n_disks;
+    for (uint32_t i = 0; i < s->n_lights; ++i) if (s->lights[i].kind == TGPU_LIGHT_SPHERE || s->lights[i].kind == TGPU_LIGHT_DISK) ctx->generalShading = true;
     ctx->classMask = 0;
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) ctx->classMask |= 1u << std::min<uint32_t>(uint32_t(s->bsdfs[i].type), uint32_t(TG_CLASS_OTHER));
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type == TGPU_BSDF_FORWARD) sc.hasForward = 1;
+    if (sc.hasForward) ctx->generalShading = true; // the shadow walk needs the NEE factors the general shade kernels store
     sc.textures = dTex;
     sc.lights = dLights; sc.nLights = s->n_lights;
     {   // media + the table of fmath::exp_ps (fmath.hpp:106-126: a = n/logf(2), b = logf(2)/n, tbl[i] = mantissa(pow(2.0f, i/n)))
@@ -656,7 +662,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (float4 **pp : f4)
         if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
-    if (sc.nInstSets && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.hitInst))) return rc;
+    if (ctx->generalGeometry && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.hitInst))) return rc; // written by the INST kernels
     if (sc.nMedia && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.med))) return rc;
     if (sc.hasForward) {
         float4 **fw[] = {&st.shG, &st.shH, &st.shI};
@@ -794,7 +800,7 @@ static int driveIteration(tgpu_ctx *ctx)
         Timer t(ctx, &ctx->stats.other_ms);
         int grid = gridFor(ctx, nCur);
         // variants: COUNT (visit counters), INST ("instances" in the scene), FWD (forward-scattering surfaces: shadow walk)
-        const int variant = (count ? 4 : 0) | (sc.nInstSets ? 2 : 0) | (sc.hasForward ? 1 : 0);
+        const int variant = (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
 #define TG_LAUNCH_TAIL(C, I, F) hipLaunchKernelGGL((k_tail<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur)
         switch (variant) {
         case 0: TG_LAUNCH_TAIL(false, false, false); break;
@@ -814,7 +820,7 @@ static int driveIteration(tgpu_ctx *ctx)
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
-            if (sc.nInstSets) {
+            if (ctx->generalGeometry) {
                 if (count) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
                 else hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
             } else {
@@ -828,7 +834,7 @@ static int driveIteration(tgpu_ctx *ctx)
             hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st, out);
             // one launch per BSDF class that occurs in the scene (ctx->classMask, set at upload)
 #define TG_LAUNCH_SHADE(C) if (ctx->classMask & (1u << (C))) { \
-                if (sc.nMedia) hipLaunchKernelGGL((k_shade<C, true>), dim3(grid), dim3(256), 0, stream, sc, st, out); \
+                if (ctx->generalShading) hipLaunchKernelGGL((k_shade<C, true>), dim3(grid), dim3(256), 0, stream, sc, st, out); \
                 else hipLaunchKernelGGL((k_shade<C, false>), dim3(grid), dim3(256), 0, stream, sc, st, out); }
             TG_LAUNCH_SHADE(0) TG_LAUNCH_SHADE(1) TG_LAUNCH_SHADE(2) TG_LAUNCH_SHADE(3) TG_LAUNCH_SHADE(4) TG_LAUNCH_SHADE(5) TG_LAUNCH_SHADE(TG_CLASS_OTHER)
 #undef TG_LAUNCH_SHADE
@@ -836,7 +842,7 @@ static int driveIteration(tgpu_ctx *ctx)
         }
         {
             Timer t(ctx, &ctx->stats.shadow_ms);
-            const int variant = (count ? 4 : 0) | (sc.nInstSets ? 2 : 0) | (sc.hasForward ? 1 : 0);
+            const int variant = (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
 #define TG_LAUNCH_SHADOW(C, I, F) hipLaunchKernelGGL((k_shadow<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out)
             switch (variant) {
             case 0: TG_LAUNCH_SHADOW(false, false, false); break;
@@ -1143,11 +1149,11 @@ static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, u
         if (e == hipSuccess) e = hipMemsetAsync(st.counters + CNT(CNT_HEAD_EXT), 0, 3*TG_CNT_STRIDE*sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) {
             if (hits) {
-                if (ctx->sc.nInstSets) hipLaunchKernelGGL((k_extend<false, true, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
+                if (ctx->generalGeometry) hipLaunchKernelGGL((k_extend<false, true, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
                 else hipLaunchKernelGGL((k_extend<false, true, false>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
                 e = hipMemcpyAsync(hits + base*4, st.hit, size_t(m)*16, hipMemcpyDeviceToHost, ctx->stream);
             } else {
-                if (ctx->sc.nInstSets) hipLaunchKernelGGL(k_occluded_raw<true>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
+                if (ctx->generalGeometry) hipLaunchKernelGGL(k_occluded_raw<true>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
                 else hipLaunchKernelGGL(k_occluded_raw<false>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
                 e = hipMemcpyAsync(occ + base, dOcc, m, hipMemcpyDeviceToHost, ctx->stream);
             }

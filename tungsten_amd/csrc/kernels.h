@@ -60,31 +60,47 @@ TG_DEV int flagsBounce(uint32_t f) { return int(f & 0xFFFFu); }
 TG_DEV bool flagsSpecular(uint32_t f) { return (f >> 16) & 1u; }
 TG_DEV int flagsEnd(uint32_t f) { return int((f >> 24) & 0xFu); }
 
+// Path state lives in two 128-byte records per slot (array of structures): the lists hand the kernels slot numbers in
+// an order that decorrelates from memory order after a few bounces, so every field access of a lane is a random access.
+// With one array per field (16-byte elements) each of them costs a 64-byte HBM sector; with records the fields a
+// kernel needs share one or two sectors.  Strided<> keeps the `st.field[slot]` spelling.
+//   path record   : [0] rayO [1] rayD [2] tp [3] hit | [4] em [5] samp [6] med, hitInst, shFlag, sampleRef [7] -
+//   shadow record : [0] shA  [1] shB  [2] shC [3] shD | [4] shE [5] shF [6..7] -
+template <class T, int STRIDE>
+struct Strided {
+    T *base;
+    TG_DEV T &operator[](size_t i) const { return base[i*STRIDE]; }
+};
+typedef Strided<float4, 8> RecF4;
+typedef Strided<uint4, 8> RecU4;
+typedef Strided<uint32_t, 32> RecU1;
+#define TG_REC_F4 8 /* float4 slots per record */
+
 struct DState {
-    float4 *rayO;   // origin.xyz, tnear
-    float4 *rayD;   // dir.xyz, tfar
-    float4 *hit;                // t, u, v, bits(prim)
+    RecF4 rayO;     // origin.xyz, tnear
+    RecF4 rayD;     // dir.xyz, tfar
+    RecF4 hit;                  // t, u, v, bits(prim)
     // only with forward-scattering surfaces (sc.hasForward): the factors of the two NEE terms, so that the shadow kernel can
     // apply the transmittance where the reference does (e = shadow*E before f*e/pdf): shG = (E_L, pdf_L), shH = (mis_L, mis_B),
     // shI = (weight_B); shC then holds f_L and shD E_B
     float4 *shG, *shH, *shI;
-    uint32_t *med;              // medium state: [7:0] medium + 1, [8] MediumState::firstScatter, [31:9] MediumState::bounce; only with media
-    uint32_t *hitInst;          // instance of the hit (set << 24 | index) or INST_NONE; only with "instances" in the scene
-    float4 *tp;     // throughput.xyz, bits(flags)
-    float4 *em;     // emission (radiance so far).xyz, bits(Sobol scramble)
-    uint4 *samp;    // sobol dimension, pcg lo, pcg hi, sample index
+    RecU1 med;                  // medium state: [7:0] medium + 1, [8] MediumState::firstScatter, [31:9] MediumState::bounce; only with media
+    RecU1 hitInst;              // instance of the hit (set << 24 | index) or INST_NONE; only with "instances" in the scene
+    RecF4 tp;       // throughput.xyz, bits(flags)
+    RecF4 em;       // emission (radiance so far).xyz, bits(Sobol scramble)
+    RecU4 samp;     // sobol dimension, pcg lo, pcg hi, sample index
     // NEE records of the path's current vertex (origin = rayO.xyz, tnear = epsilon)
-    float4 *shA;    // light-sample dir.xyz, tfar (< 0: no ray)
-    float4 *shB;    // bsdf-sample dir.xyz, tfar (< 0: no ray)
-    float4 *shC;    // L.xyz (unoccluded light-sample term), light-pick weight
-    float4 *shD;    // B.xyz (unoccluded bsdf-sample term), bits(end cap prim | postAdd flag << 31 hmm)
-    float4 *shE;    // throughput at the vertex.xyz, bits(has post-add)
-    float4 *shF;    // emitter term to add after the NEE term.xyz
-    uint32_t *sampleRef; // per slot: index into `results` of the sample the slot is tracing
+    RecF4 shA;      // light-sample dir.xyz, tfar (< 0: no ray)
+    RecF4 shB;      // bsdf-sample dir.xyz, tfar (< 0: no ray)
+    RecF4 shC;      // L.xyz (unoccluded light-sample term), light-pick weight
+    RecF4 shD;      // B.xyz (unoccluded bsdf-sample term), bits(end cap prim | postAdd flag << 31 hmm)
+    RecF4 shE;      // throughput at the vertex.xyz, bits(has post-add)
+    RecF4 shF;      // emitter term to add after the NEE term.xyz
+    RecU1 sampleRef;     // per slot: index into `results` of the sample the slot is tracing
     float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w unused)
     uint32_t *lists[2][TG_LISTS];
     uint32_t *freeQ;     // idle slots that were dropped from the lists (no sample admitted / end of render)
-    uint32_t *shFlag;    // per slot: 1 when the current vertex queued NEE rays (shA..shF valid)
+    RecU1 shFlag;        // per slot: 1 when the current vertex queued NEE rays (shA..shF valid)
     uint32_t *counters;
     uint32_t nPixels;
     uint32_t resultSlice; // samples per ring slot = nPixels * resultSpp

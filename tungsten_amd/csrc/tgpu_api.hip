@@ -658,12 +658,17 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if (cap < 64) cap = 64;
     if (cap > (1ull << 30)) { fail(ctx, "max_paths_in_flight too large"); return TGPU_ERR_INVALID; }
     ctx->capacity = cap;
-    float4 **f4[] = {&st.rayO, &st.rayD, &st.hit, &st.tp, &st.em, &st.shA, &st.shB, &st.shC, &st.shD, &st.shE, &st.shF};
-    for (float4 **pp : f4)
-        if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
-    if ((rc = upload<uint4>(ctx, ctx->stateAllocs, nullptr, cap, &st.samp))) return rc;
-    if (ctx->generalGeometry && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.hitInst))) return rc; // written by the INST kernels
-    if (sc.nMedia && (rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.med))) return rc;
+    {
+        // two 128-byte records per slot (kernels.h, DState)
+        float4 *rec, *shrec;
+        if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap*TG_REC_F4, &rec))) return rc;
+        if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, cap*TG_REC_F4, &shrec))) return rc;
+        st.rayO.base = rec; st.rayD.base = rec + 1; st.tp.base = rec + 2; st.hit.base = rec + 3; st.em.base = rec + 4;
+        st.samp.base = reinterpret_cast<uint4 *>(rec + 5);
+        uint32_t *misc = reinterpret_cast<uint32_t *>(rec + 6);
+        st.med.base = misc; st.hitInst.base = misc + 1; st.shFlag.base = misc + 2; st.sampleRef.base = misc + 3;
+        st.shA.base = shrec; st.shB.base = shrec + 1; st.shC.base = shrec + 2; st.shD.base = shrec + 3; st.shE.base = shrec + 4; st.shF.base = shrec + 5;
+    }
     if (sc.hasForward) {
         float4 **fw[] = {&st.shG, &st.shH, &st.shI};
         for (float4 **pp : fw)
@@ -674,9 +679,6 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         for (uint64_t i = 0; i < cap; ++i) ident[i] = uint32_t(i);
         if ((rc = upload(ctx, ctx->stateAllocs, ident.data(), ident.size(), &st.freeQ))) return rc;
     }
-    uint32_t **qs[] = {&st.sampleRef, &st.shFlag};
-    for (uint32_t **pp : qs)
-        if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, pp))) return rc;
     for (int set = 0; set < 2; ++set)
         for (int l = 0; l < TG_LISTS; ++l)
             if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.lists[set][l]))) return rc;
@@ -1144,14 +1146,14 @@ static int traceRaw(tgpu_ctx *ctx, const float *rays, uint32_t n, float *hits, u
             o[size_t(i)*4 + 0] = r[0]; o[size_t(i)*4 + 1] = r[1]; o[size_t(i)*4 + 2] = r[2]; o[size_t(i)*4 + 3] = r[3];
             d[size_t(i)*4 + 0] = r[4]; d[size_t(i)*4 + 1] = r[5]; d[size_t(i)*4 + 2] = r[6]; d[size_t(i)*4 + 3] = r[7];
         }
-        hipError_t e = hipMemcpyAsync(st.rayO, o.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(st.rayD, d.data(), size_t(m)*16, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpy2DAsync(st.rayO.base, TG_REC_F4*16, o.data(), 16, 16, m, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(st.rayD.base, TG_REC_F4*16, d.data(), 16, 16, m, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(st.counters + CNT(CNT_HEAD_EXT), 0, 3*TG_CNT_STRIDE*sizeof(uint32_t), ctx->stream);
         if (e == hipSuccess) {
             if (hits) {
                 if (ctx->generalGeometry) hipLaunchKernelGGL((k_extend<false, true, true>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
                 else hipLaunchKernelGGL((k_extend<false, true, false>), dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, 0, m);
-                e = hipMemcpyAsync(hits + base*4, st.hit, size_t(m)*16, hipMemcpyDeviceToHost, ctx->stream);
+                e = hipMemcpy2DAsync(hits + base*4, 16, st.hit.base, TG_REC_F4*16, 16, m, hipMemcpyDeviceToHost, ctx->stream);
             } else {
                 if (ctx->generalGeometry) hipLaunchKernelGGL(k_occluded_raw<true>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);
                 else hipLaunchKernelGGL(k_occluded_raw<false>, dim3(gridFor(ctx, m)), dim3(256), ctx->ldsBytes, ctx->stream, ctx->sc, st, m, dOcc);

@@ -10,8 +10,9 @@ HOST_SRC  := tungsten_amd/host/scene.cpp tungsten_amd/host/capi.cpp
 CLI_SRC   := tungsten_amd/host/scene.cpp tungsten_amd/host/integrator.cpp tungsten_amd/host/tungsten_cli.cpp
 CLI_BIN   := tungsten_amd/tungsten_amd_cli
 HOST_LIB  := tungsten_amd/libtungsten_host.so
-CORE_SRC  := tungsten_amd/csrc/tgpu_api.hip
-CORE_DEPS := $(wildcard tungsten_amd/csrc/*.h tungsten_amd/csrc/*.hip include/*.h)
+CORE_SRC  := $(wildcard tungsten_amd/csrc/*.hip)
+CORE_OBJ  := $(patsubst tungsten_amd/csrc/%.hip,build/core/%.o,$(CORE_SRC))
+CORE_DEPS := $(wildcard tungsten_amd/csrc/*.h include/*.h)
 CORE_LIB  := tungsten_amd/libtungsten_amd.so
 ORACLE_LIB:= oracle/liboracle.so
 
@@ -28,8 +29,13 @@ $(HOST_LIB): $(HOST_SRC) $(wildcard tungsten_amd/host/*.hpp) include/tungsten_am
 $(CLI_BIN): $(CLI_SRC) $(wildcard tungsten_amd/host/*.hpp) $(CORE_LIB)
 	$(CXX) $(CXXFLAGS) -o $@ $(CLI_SRC) -Ltungsten_amd -ltungsten_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -lpthread
 
-$(CORE_LIB): $(CORE_DEPS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CORE_SRC)
+# one object per translation unit (the kernel families of kernels.h are split over tu_*.hip): `make -j` builds them in parallel
+build/core/%.o: tungsten_amd/csrc/%.hip $(CORE_DEPS)
+	@mkdir -p build/core
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(CORE_LIB): $(CORE_OBJ)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CORE_OBJ)
 
 # the oracle uses explicit fmaf in include/tgpu_math.h: -mfma keeps it a single instruction
 $(ORACLE_LIB): oracle/oracle.cpp oracle/oracle.h include/tungsten_amd.h include/tgpu_math.h

@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _abi
 
-_CORE_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtungsten_amd.so")
+_CORE_LIB_PATH = os.environ.get("TGPU_CORE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtungsten_amd.so")  # env: A/B builds
 _lib = None
 
 

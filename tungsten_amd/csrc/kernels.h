@@ -65,7 +65,7 @@ TG_DEV int flagsEnd(uint32_t f) { return int((f >> 24) & 0xFu); }
 // With one array per field (16-byte elements) each of them costs a 64-byte HBM sector; with records the fields a
 // kernel needs share one or two sectors.  Strided<> keeps the `st.field[slot]` spelling.
 //   path record   : [0] rayO [1] rayD [2] tp [3] hit | [4] em [5] samp [6] med, hitInst, shFlag, sampleRef [7] -
-//   shadow record : [0] shA  [1] shB  [2] shC [3] shD | [4] shE [5] shF [6..7] -
+//   shadow record : [0] shA  [1] shB  [2] shC [3] shD | [4] shE [5] shF [6] shO [7] -
 template <class T, int STRIDE>
 struct Strided {
     T *base;
@@ -96,6 +96,7 @@ struct DState {
     RecF4 shD;      // B.xyz (unoccluded bsdf-sample term), bits(end cap prim | postAdd flag << 31 hmm)
     RecF4 shE;      // throughput at the vertex.xyz, bits(has post-add)
     RecF4 shF;      // emitter term to add after the NEE term.xyz
+    RecF4 shO;      // origin of the NEE rays.xyz (info.p), tnear -- a copy, so that the shadow kernel leaves the path record's first half alone
     RecU1 sampleRef;     // per slot: index into `results` of the sample the slot is tracing
     float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w unused)
     uint32_t *lists[2][TG_LISTS];
@@ -123,18 +124,43 @@ struct DState {
 // Streaming accesses to the path state: non-temporal, so that the 4 MB L2 of each XCD keeps the BVH
 // and triangle data the traversal re-reads instead of state that is touched once per iteration.
 typedef float tg_f4 __attribute__((ext_vector_type(4)));
+#ifndef TG_STATE_NT
+#define TG_STATE_NT 3 /* bit 0: loads, bit 1: stores (A/B switch, profiles/r01_ab_notes.txt) */
+#endif
 TG_DEV float4 ldStream(const float4 *p)
 {
+#if TG_STATE_NT & 1
     tg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const tg_f4 *>(p));
     return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
 }
-TG_DEV uint32_t ldStream(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+TG_DEV uint32_t ldStream(const uint32_t *p)
+{
+#if TG_STATE_NT & 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 TG_DEV void stStream(float4 *p, const float4 &v)
 {
+#if TG_STATE_NT & 2
     tg_f4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<tg_f4 *>(p));
+#else
+    *p = v;
+#endif
 }
-TG_DEV void stStream(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+TG_DEV void stStream(uint32_t *p, uint32_t v)
+{
+#if TG_STATE_NT & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 TG_DEV float4 mk4(const V3 &v, float w) { return make_float4(v.x, v.y, v.z, w); }
 TG_DEV float4 mk4u(const V3 &v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 TG_DEV V3 xyz(const float4 &f) { return V3(f.x, f.y, f.z); }
@@ -281,7 +307,7 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
 //    slot is marked idle and the next extend drops it onto the free list.
 // Claims are aggregated per 1024-thread block (one global atomic per 1024 entries), job counters per block
 // in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
-__global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
+static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
                                                             unsigned long long limit)
 {
     __shared__ uint32_t sWave[16];
@@ -345,7 +371,7 @@ __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st
 
 // Refill from the free list: the host knows how many samples are admitted, so slot freeQ[freeBase + q]
 // takes sample sampleBase + q and is appended to list 0 of the current set at listBase + q.
-__global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase, uint32_t nStart,
+static __global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase, uint32_t nStart,
                                                 uint32_t freeBase, uint32_t listBase)
 {
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < nStart; q += gridDim.x*blockDim.x) {
@@ -896,7 +922,7 @@ TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
 }
 
-__global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
+static __global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS)];
     const uint32_t *list = st.lists[set][0];
@@ -1589,6 +1615,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
     st.med[path] = uint32_t(medium + 1) | (firstScatter ? 1u << 8 : 0u) | (stateBounce << 9);
     if (pushShadow) {
+        st.shO[path] = mk4(p, 0.0f);
         st.shA[path] = mk4(dL, tfarL);
         st.shB[path] = mk4(dB, tfarB);
         st.shC[path] = mk4(fwdScene ? fL : L, pickWeight);
@@ -1849,13 +1876,13 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
             }
         }
         // NEE rays start at info.p.  For scene primitives that has the bits of the scatter origin (ray.hitpoint());
-        // for a hit on an "instances" primitive it does not (applyInstance), so the shadow kernel gets it through shF --
-        // free here, because an instance hit is never emissive
+        // for a hit on an "instances" primitive it does not (applyInstance)
         const bool neeOriginMoved = sc.nInstSets && st.hitInst[path] != INST_NONE;
         st.rayO[path] = mk4(hitpoint, eps);
         st.rayD[path] = mk4(wo, TG_INF);
         st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
         if (pushShadow) {
+            st.shO[path] = mk4(neeOriginMoved ? info.p : hitpoint, eps);
             st.shA[path] = mk4(dL, tfarL);
             st.shB[path] = mk4(dB, tfarB);
             st.shC[path] = mk4(fwdScene ? fL : L, pickWeight);
@@ -1868,10 +1895,9 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
             // with forward-scattering surfaces in the scene the shadow kernel walks the segments itself and needs the
             // media the two rays start in, startsOnSurface (bit 2) and the bounce argument (shF.w)
             const uint32_t fwdBits = fwdScene ? (4u | (uint32_t(mediumL + 1) << 8) | (uint32_t(mediumB + 1) << 16)) : 0u;
-            st.shE[path] = mk4u(tpVertex, (hasPostAdd ? 1u : 0u) | (neeOriginMoved ? 2u : 0u) | fwdBits);
+            st.shE[path] = mk4u(tpVertex, (hasPostAdd ? 1u : 0u) | fwdBits);
             const float bounceBits = __uint_as_float(uint32_t(neeBounce));
             if (hasPostAdd) st.shF[path] = mk4(postAdd, bounceBits);
-            else if (neeOriginMoved) st.shF[path] = mk4(info.p, bounceBits);
             else if (fwdScene) st.shF[path] = mk4(V3(0.0f), bounceBits);
         }
         st.em[path] = mk4u(em, smp.scramble);
@@ -1892,7 +1918,7 @@ __global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
 }
 
 // K3v: the slots whose ray runs inside a medium (list 1 + TG_CLASS_VOLUME)
-__global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, int set)
+static __global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + TG_CLASS_VOLUME)];
     const uint32_t *list = st.lists[set][1 + TG_CLASS_VOLUME];
@@ -1972,9 +1998,8 @@ TG_DEV V3 shadowWalk(const DScene &sc, uint32_t *stack, V3 O, const V3 &D, float
 template <bool COUNT, bool INST, bool FWD>
 TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint32_t path, TraceCounters &tc, uint32_t &rays)
 {
-    float4 ro = ldStream(&st.rayO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
+    float4 ro = ldStream(&st.shO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
     V3 O = xyz(ro);
-    if (INST && (__float_as_uint(e.w) & 2u)) O = xyz(ldStream(&st.shF[path])); // info.p of an instance hit (shadePath)
     uint32_t endCap = __float_as_uint(d.w);
     V3 result(0.0f);
     if (FWD) {
@@ -2138,7 +2163,7 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
 // =================================================================================================
 // K7 accumulate: OutputBuffer::addSample in sample order (cameras/OutputBuffer.hpp:104-132)
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot, uint32_t sppCount)
+static __global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot, uint32_t sppCount)
 {
     const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
     for (uint32_t k = blockIdx.x*blockDim.x + threadIdx.x; k < st.nPixels; k += gridDim.x*blockDim.x) {
@@ -2161,7 +2186,7 @@ __global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot
 // pixels of the 4x4 block row-major, the pixel's samples in sequence -- so that the Welford statistics of
 // SampleRecord::addSample (SampleRecord.hpp:44-55) and the per-pixel means come out with the reference's bits.
 // Uniform jobs (offset == nullptr) hold sample s of pixel k at s*nPixels + k, adaptive jobs at offset[k] + s.
-__global__ void __launch_bounds__(256) k_accumulate_records(DState st, uint32_t ringSlot, uint32_t sppCount, uint32_t adaptive)
+static __global__ void __launch_bounds__(256) k_accumulate_records(DState st, uint32_t ringSlot, uint32_t sppCount, uint32_t adaptive)
 {
     const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
     const uint32_t *off = st.jobOffset + size_t(ringSlot)*(st.nPixels + 1u);
@@ -2197,7 +2222,7 @@ __global__ void __launch_bounds__(256) k_accumulate_records(DState st, uint32_t 
 }
 
 // device evaluation of include/tgpu_math.h for the bit-exactness test
-__global__ void k_eval_math(int kind, const float *a, const float *b, uint32_t n, float *out)
+static __global__ void k_eval_math(int kind, const float *a, const float *b, uint32_t n, float *out)
 {
     for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += gridDim.x*blockDim.x) {
         float x = a[i], y = b[i], r;
@@ -2215,5 +2240,32 @@ __global__ void k_eval_math(int kind, const float *a, const float *b, uint32_t n
         out[i] = r;
     }
 }
+
+// =================================================================================================
+// Translation units.  The big kernel families are instantiated in files of their own (tu_*.hip) so that the library
+// builds in parallel; tgpu_api.hip sees them as `extern template`.  PFX is `extern` or empty.
+// =================================================================================================
+#define TG_KERNELS_SHADE(PFX, M) \
+    PFX template __global__ void k_shade<0, M>(DScene, DState, int); \
+    PFX template __global__ void k_shade<1, M>(DScene, DState, int); \
+    PFX template __global__ void k_shade<2, M>(DScene, DState, int); \
+    PFX template __global__ void k_shade<3, M>(DScene, DState, int); \
+    PFX template __global__ void k_shade<4, M>(DScene, DState, int); \
+    PFX template __global__ void k_shade<5, M>(DScene, DState, int); \
+    PFX template __global__ void k_shade<TG_CLASS_OTHER, M>(DScene, DState, int);
+#define TG_KERNELS_SHADOW(PFX) \
+    PFX template __global__ void k_shadow<false, false, false>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<false, false, true>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<false, true, false>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<false, true, true>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<true, false, false>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<true, false, true>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<true, true, false>(DScene, DState, int); \
+    PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
+#define TG_KERNELS_TAIL(PFX, I) \
+    PFX template __global__ void k_tail<false, I, false>(DScene, DState, int); \
+    PFX template __global__ void k_tail<false, I, true>(DScene, DState, int); \
+    PFX template __global__ void k_tail<true, I, false>(DScene, DState, int); \
+    PFX template __global__ void k_tail<true, I, true>(DScene, DState, int);
 
 } // namespace tg

@@ -22,6 +22,15 @@
 
 using namespace tg;
 
+// instantiated in tu_*.hip
+namespace tg {
+TG_KERNELS_SHADE(extern, false)
+TG_KERNELS_SHADE(extern, true)
+TG_KERNELS_SHADOW(extern)
+TG_KERNELS_TAIL(extern, false)
+TG_KERNELS_TAIL(extern, true)
+}
+
 namespace {
 
 struct DevBuf {
@@ -667,7 +676,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         st.samp.base = reinterpret_cast<uint4 *>(rec + 5);
         uint32_t *misc = reinterpret_cast<uint32_t *>(rec + 6);
         st.med.base = misc; st.hitInst.base = misc + 1; st.shFlag.base = misc + 2; st.sampleRef.base = misc + 3;
-        st.shA.base = shrec; st.shB.base = shrec + 1; st.shC.base = shrec + 2; st.shD.base = shrec + 3; st.shE.base = shrec + 4; st.shF.base = shrec + 5;
+        st.shA.base = shrec; st.shB.base = shrec + 1; st.shC.base = shrec + 2; st.shD.base = shrec + 3; st.shE.base = shrec + 4; st.shF.base = shrec + 5; st.shO.base = shrec + 6;
     }
     if (sc.hasForward) {
         float4 **fw[] = {&st.shG, &st.shH, &st.shI};

@@ -370,6 +370,27 @@ def test_cpp_host_integrator_cli_adaptive(ta, oracle_py, tmp_path):
     assert np.array_equal(img, ref)
 
 
+@pytest.mark.parametrize("tail_max", ["0", None])
+@pytest.mark.parametrize("scene", ["materialtest/c2.json", "instances/inst_mesh.json"])
+def test_traversal_stack_spill_path(ta, oracle_py, scene, tail_max, monkeypatch):
+    """Only the first levels of the traversal stack live in LDS; TGPU_STACK_LDS=2 pushes nearly every entry through
+    the global spill area (wavefront kernels and the tail kernel), and the image must not change."""
+    monkeypatch.setenv("TGPU_STACK_LDS", "2")
+    if tail_max is not None:
+        monkeypatch.setenv("TGPU_TAIL_MAX", tail_max)
+    hs = ta.HostScene(scene_path(scene), resolution=(96, 54))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    ctx = ta.Context(0)
+    try:
+        ctx.upload(hs, shard, 2048)
+        ctx.render(4, spp_step=4)
+        got = ctx.download()
+    finally:
+        ctx.close()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 4, spp_step=4)
+    assert_bit_exact(got, ref, f"{scene} with the stack spilled")
+
+
 @pytest.mark.parametrize("scene,res,spp", [
     ("materialtest/c5.json", (128, 72), 8),            # volume list + k_volume + class-specialised shade kernels
     ("cornell-box/scene_fog.json", (96, 54), 8),

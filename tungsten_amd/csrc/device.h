@@ -109,7 +109,10 @@ struct DScene {
     const uint32_t *triId;
     uint32_t rootChild;
     uint32_t nTris;
-    int32_t stackEntries;
+    int32_t stackEntries;       // worst-case traversal stack depth (3 pushes per BVH4 level)
+    int32_t stackLds;           // levels kept in LDS; the rest spills to stackSpill[level - stackLds][global thread]
+    uint32_t spillStride;       // threads of the largest grid
+    uint32_t *stackSpill;
     // per-triangle shading records, soup order: 5 x float4
     //   s0 = (n0.xyz, n1.x) s1 = (n1.yz, n2.xy) s2 = (n2.z, uv0.xy, uv1.x) s3 = (uv1.y, uv2.xy, bits(bsdf | smooth<<31))
     //   s4 = (unnormalised Ng = (p1-p0)x(p2-p0), 0)

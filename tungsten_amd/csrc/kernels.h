@@ -307,6 +307,7 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
 //    slot is marked idle and the next extend drops it onto the free list.
 // Claims are aggregated per 1024-thread block (one global atomic per 1024 entries), job counters per block
 // in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
+#ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
                                                             unsigned long long limit)
 {
@@ -368,9 +369,11 @@ static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DS
     }
     if (threadIdx.x < TG_RING && sHist[threadIdx.x]) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + threadIdx.x)], sHist[threadIdx.x]);
 }
+#endif
 
 // Refill from the free list: the host knows how many samples are admitted, so slot freeQ[freeBase + q]
 // takes sample sampleBase + q and is appended to list 0 of the current set at listBase + q.
+#ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase, uint32_t nStart,
                                                 uint32_t freeBase, uint32_t listBase)
 {
@@ -384,6 +387,7 @@ static __global__ void __launch_bounds__(256) k_refill(DScene sc, DState st, Job
         st.counters[CNT(CNT_LIST0 + set*TG_LISTS)] = listBase + nStart;
     }
 }
+#endif
 
 // =================================================================================================
 // BVH traversal (K2 / K4 core)
@@ -412,6 +416,27 @@ TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, const 
     u = U/absDen;
     v = V/absDen;
     return true;
+}
+
+// waves per SIMD the lean traversal kernels are compiled for (second __launch_bounds__ argument: 6 -> at most 80 VGPRs)
+#ifndef TG_EXTEND_WAVES
+#define TG_EXTEND_WAVES 6
+#endif
+
+// Traversal stack: the first sc.stackLds levels live in LDS (stack[level][thread], bank = lane), deeper ones -- the
+// worst case is 3 pushes per tree level, real rays stay far below it -- in a per-thread global spill area, so that
+// the LDS footprint (and with it the number of resident waves) does not grow with the depth of the tree.
+TG_DEV void stackPush(const DScene &sc, uint32_t *stack, int &sp, uint32_t value)
+{
+    if (sp < sc.stackLds) stack[sp*256] = value;
+    else sc.stackSpill[size_t(sp - sc.stackLds)*sc.spillStride + blockIdx.x*256u + threadIdx.x] = value;
+    ++sp;
+}
+TG_DEV uint32_t stackPop(const DScene &sc, uint32_t *stack, int &sp)
+{
+    --sp;
+    if (sp < sc.stackLds) return stack[sp*256];
+    return sc.stackSpill[size_t(sp - sc.stackLds)*sc.spillStride + blockIdx.x*256u + threadIdx.x];
 }
 
 // Traversal of the quantised BVH4 (bvh_build.h).
@@ -470,9 +495,9 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
 #define TG_CHILD(k) (((k) & 3u) == 0u ? c0 : (((k) & 3u) == 1u ? c1 : (((k) & 3u) == 2u ? c2 : c3)))
             if (key[0] != 0xFFFFFFFFu) {
                 // push the farther hits, farthest first, so that the nearest of them pops first
-                if (key[3] != 0xFFFFFFFFu && sp < maxSp) stack[(sp++)*256] = TG_CHILD(key[3]);
-                if (key[2] != 0xFFFFFFFFu && sp < maxSp) stack[(sp++)*256] = TG_CHILD(key[2]);
-                if (key[1] != 0xFFFFFFFFu && sp < maxSp) stack[(sp++)*256] = TG_CHILD(key[1]);
+                if (key[3] != 0xFFFFFFFFu && sp < maxSp) stackPush(sc, stack, sp, TG_CHILD(key[3]));
+                if (key[2] != 0xFFFFFFFFu && sp < maxSp) stackPush(sc, stack, sp, TG_CHILD(key[2]));
+                if (key[1] != 0xFFFFFFFFu && sp < maxSp) stackPush(sc, stack, sp, TG_CHILD(key[1]));
                 node = TG_CHILD(key[0]);
                 continue;
             }
@@ -495,7 +520,7 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
             }
         }
         if (sp == 0) break;
-        node = stack[(--sp)*256];
+        node = stackPop(sc, stack, sp);
     }
     return false;
 }
@@ -806,7 +831,7 @@ TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
 // no classification.
 // =================================================================================================
 template <bool COUNT, bool RAW, bool INST>
-__global__ void __launch_bounds__(256) k_extend(DScene sc, DState st, int set, uint32_t rawCount)
+__global__ void __launch_bounds__(256, (INST ? 1 : TG_EXTEND_WAVES)) k_extend(DScene sc, DState st, int set, uint32_t rawCount)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
@@ -922,12 +947,14 @@ TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
 }
 
+#ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS)];
     const uint32_t *list = st.lists[set][0];
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) missPath(sc, st, list[q]);
 }
+#endif
 
 // =================================================================================================
 // K3 shade
@@ -1918,12 +1945,14 @@ __global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
 }
 
 // K3v: the slots whose ray runs inside a medium (list 1 + TG_CLASS_VOLUME)
+#ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + TG_CLASS_VOLUME)];
     const uint32_t *list = st.lists[set][1 + TG_CLASS_VOLUME];
     for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) volumePath(sc, st, list[q]);
 }
+#endif
 
 // =================================================================================================
 // K4 shadow: both NEE rays of a vertex are traced by one lane, then resolved in the reference's order
@@ -2042,7 +2071,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
 }
 
 template <bool COUNT, bool INST, bool FWD>
-__global__ void __launch_bounds__(256) k_shadow(DScene sc, DState st, int set)
+__global__ void __launch_bounds__(256, ((INST || FWD) ? 1 : 6)) k_shadow(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
@@ -2163,6 +2192,7 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
 // =================================================================================================
 // K7 accumulate: OutputBuffer::addSample in sample order (cameras/OutputBuffer.hpp:104-132)
 // =================================================================================================
+#ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot, uint32_t sppCount)
 {
     const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
@@ -2181,11 +2211,13 @@ static __global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t r
         st.fbCount[k] = n;
     }
 }
+#endif
 
 // Accumulate with SampleRecords (adaptive_sampling): one lane per variance tile replays renderTile's order --
 // pixels of the 4x4 block row-major, the pixel's samples in sequence -- so that the Welford statistics of
 // SampleRecord::addSample (SampleRecord.hpp:44-55) and the per-pixel means come out with the reference's bits.
 // Uniform jobs (offset == nullptr) hold sample s of pixel k at s*nPixels + k, adaptive jobs at offset[k] + s.
+#ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(256) k_accumulate_records(DState st, uint32_t ringSlot, uint32_t sppCount, uint32_t adaptive)
 {
     const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
@@ -2220,8 +2252,10 @@ static __global__ void __launch_bounds__(256) k_accumulate_records(DState st, ui
         st.recVar[vt] = runningVariance;
     }
 }
+#endif
 
 // device evaluation of include/tgpu_math.h for the bit-exactness test
+#ifdef TG_TU_MAIN
 static __global__ void k_eval_math(int kind, const float *a, const float *b, uint32_t n, float *out)
 {
     for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += gridDim.x*blockDim.x) {
@@ -2240,6 +2274,7 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
         out[i] = r;
     }
 }
+#endif
 
 // =================================================================================================
 // Translation units.  The big kernel families are instantiated in files of their own (tu_*.hip) so that the library

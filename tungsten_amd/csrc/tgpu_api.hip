@@ -1,6 +1,7 @@
 // C ABI of the MI355X path-tracing core (include/tungsten_amd.h): context, scene upload,
 // wavefront pass driver, downloads.  Host code only orchestrates; all path work runs in the
 // kernels of kernels.h.  No CPU fallback exists: every entry point fails loudly without a GPU.
+#define TG_TU_MAIN
 #include "kernels.h"
 #include "bvh_build.h"
 #include "instance_bvh.h"
@@ -479,8 +480,19 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.nodes = dNodes;
     sc.tris = dTris;
     sc.triId = dTriId;
-    ctx->ldsBytes = size_t(sc.stackEntries)*256*sizeof(uint32_t);
-    if (ctx->ldsBytes > 160*1024) { fail(ctx, "BVH depth %d needs more LDS than a CU has", maxDepth4); return TGPU_ERR_UNSUPPORTED; }
+    // 20 levels of LDS stack = 20 KB per block: 8 blocks (32 waves) fit a CU, so registers, not LDS, set the occupancy
+    // (profiles/r01_ab_notes.txt); deeper levels spill to global memory
+    sc.stackLds = 20;
+    if (const char *e = getenv("TGPU_STACK_LDS")) sc.stackLds = std::max(1, atoi(e));
+    sc.stackLds = std::min(sc.stackLds, sc.stackEntries);
+    sc.spillStride = uint32_t(ctx->maxGrid)*256u;
+    sc.stackSpill = nullptr;
+    if (sc.stackEntries > sc.stackLds) {
+        uint32_t *dSpill;
+        if ((rc = upload<uint32_t>(ctx, ctx->allocs, nullptr, size_t(sc.stackEntries - sc.stackLds)*sc.spillStride, &dSpill))) return rc;
+        sc.stackSpill = dSpill;
+    }
+    ctx->ldsBytes = size_t(sc.stackLds)*256*sizeof(uint32_t);
 
     // ---- shading records ----
     std::vector<tgpu_bvh::Float4> shade(size_t(nAllTris)*5);

@@ -105,8 +105,7 @@ struct DScene {
     tgpu_settings settings;
     // BVH (bvh_build.h layout)
     const float4 *nodes;
-    const float4 *tris;
-    const uint32_t *triId;
+    const float4 *tris;         // BVH-order triangle records, 4 x float4 each: v0 e1 e2 Ng + soup triangle id (64 B, like a node)
     uint32_t rootChild;
     uint32_t nTris;
     int32_t stackEntries;       // worst-case traversal stack depth (3 pushes per BVH4 level)

@@ -418,9 +418,12 @@ TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, const 
     return true;
 }
 
-// waves per SIMD the lean traversal kernels are compiled for (second __launch_bounds__ argument: 6 -> at most 80 VGPRs)
+// waves per SIMD the lean traversal kernels are compiled for (second __launch_bounds__ argument: 7 -> at most 72 VGPRs; A/B in profiles/r01_ab_notes.txt)
 #ifndef TG_EXTEND_WAVES
-#define TG_EXTEND_WAVES 6
+#define TG_EXTEND_WAVES 7
+#endif
+#ifndef TG_SHADOW_WAVES
+#define TG_SHADOW_WAVES 7
 #endif
 
 // Traversal stack: the first sc.stackLds levels live in LDS (stack[level][thread], bank = lane), deeper ones -- the
@@ -459,10 +462,15 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
     // per-axis choice of the near/far byte plane (bvh_build.h, Bvh4): for a negative direction the near
     // plane of the box is HI
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    // One BVH item per iteration and lane -- an inner node or ONE triangle of a leaf, both 64-byte records -- fetched by
+    // the same four loads at the top: every iteration costs a single memory round trip whichever mix of nodes and
+    // triangles the lanes hold (a per-leaf triangle loop cost the wave one round trip per triangle of its largest leaf).
     while (true) {
-        if (!(node & 0x80000000u)) {
-            const float4 *n = sc.nodes + size_t(node)*4;
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+        const bool leaf = (node & 0x80000000u) != 0;
+        const uint32_t payload = node & 0x7FFFFFFFu; // leaf: first << 3 | count - 1
+        const float4 *n = leaf ? sc.tris + size_t(payload >> 3)*4 : sc.nodes + size_t(node)*4;
+        float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+        if (!leaf) {
             if (COUNT) tc.nodes++;
             const uint32_t eb = __float_as_uint(q0.w);
             // t = q*(scale*inv) + (origin - O)*inv, one fma per plane
@@ -503,20 +511,18 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
             }
 #undef TG_CHILD
         } else {
-            uint32_t payload = node & 0x7FFFFFFFu;
-            uint32_t first = payload >> 3, cnt = (payload & 7u) + 1u;
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 *tp = sc.tris + size_t(first + j)*3;
-                float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                if (COUNT) tc.tris++;
-                float t, u, v;
-                if (triTest(t0, t1, t2, O, D, tnear, tfar0, t, u, v)) {
-                    if (ANY) return true;
-                    uint32_t id = sc.triId[first + j];
-                    if (t < bestT || (t == bestT && id < bestPrim)) {
-                        bestT = t; bestU = u; bestV = v; bestPrim = id;
-                    }
+            if (COUNT) tc.tris++;
+            float t, u, v;
+            if (triTest(q0, q1, q2, O, D, tnear, tfar0, t, u, v)) {
+                if (ANY) return true;
+                const uint32_t id = __float_as_uint(q3.x);
+                if (t < bestT || (t == bestT && id < bestPrim)) {
+                    bestT = t; bestU = u; bestV = v; bestPrim = id;
                 }
+            }
+            if (payload & 7u) { // next triangle of the leaf: first + 1, count - 1
+                node += 7u;
+                continue;
             }
         }
         if (sp == 0) break;
@@ -2071,7 +2077,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
 }
 
 template <bool COUNT, bool INST, bool FWD>
-__global__ void __launch_bounds__(256, ((INST || FWD) ? 1 : 6)) k_shadow(DScene sc, DState st, int set)
+__global__ void __launch_bounds__(256, ((INST || FWD) ? 1 : TG_SHADOW_WAVES)) k_shadow(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;

@@ -387,14 +387,13 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     // ---- BVHs: the scene's triangles, then one per mesh master of the "instances" primitives ----
     const uint32_t nAllTris = s->n_tris + s->n_master_tris;
     std::vector<tgpu_bvh::Float4> allNodes, allTris;
-    std::vector<uint32_t> allTriId;
     int maxDepth4 = 0;
     // appends one BVH over triangles [first, first + count) and returns its root child reference
     auto appendBvh = [&](uint32_t first, uint32_t count, const char *what) -> uint32_t {
         tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count);
         tgpu_bvh::Bvh bvh = builder.build();
         tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run(); // the quantised BVH4 the kernels traverse (bvh_build.h)
-        const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/3);
+        const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/4);
         auto rebase = [&](uint32_t ref) -> uint32_t {
             if (ref == 0xFFFFFFFFu) return ref;                               // empty slot
             if (ref & 0x80000000u) {                                          // leaf: first << 3 | count - 1
@@ -414,8 +413,14 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
             }
             allNodes.push_back(bvh4.nodes[i]); allNodes.push_back(bvh4.nodes[i + 1]); allNodes.push_back(bvh4.nodes[i + 2]); allNodes.push_back(q3);
         }
-        allTris.insert(allTris.end(), bvh.tris.begin(), bvh.tris.end());
-        for (uint32_t id : bvh.triId) allTriId.push_back(id + first);
+        // 64-byte triangle records, the size of a node: v0 e1 e2 Ng (3 x float4) + the soup triangle id
+        for (size_t i = 0; i < bvh.triId.size(); ++i) {
+            allTris.push_back(bvh.tris[i*3]); allTris.push_back(bvh.tris[i*3 + 1]); allTris.push_back(bvh.tris[i*3 + 2]);
+            tgpu_bvh::Float4 tail{0.0f, 0.0f, 0.0f, 0.0f};
+            const uint32_t id = bvh.triId[i] + first;
+            std::memcpy(&tail.x, &id, 4);
+            allTris.push_back(tail);
+        }
         maxDepth4 = std::max(maxDepth4, bvh4.maxDepth);
         if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] %s: %u tris, bvh2 %u nodes depth %d -> bvh4 %u nodes depth %d\n", what, count, bvh.nodeCount, bvh.maxDepth, bvh4.nodeCount, bvh4.maxDepth);
         return rebase(bvh4.rootChild);
@@ -473,13 +478,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
     if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
     float4 *dNodes, *dTris;
-    uint32_t *dTriId;
     if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allNodes.data()), allNodes.size(), &dNodes))) return rc;
     if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allTris.data()), allTris.size(), &dTris))) return rc;
-    if ((rc = upload(ctx, ctx->allocs, allTriId.data(), allTriId.size(), &dTriId))) return rc;
     sc.nodes = dNodes;
     sc.tris = dTris;
-    sc.triId = dTriId;
     // 20 levels of LDS stack = 20 KB per block: 8 blocks (32 waves) fit a CU, so registers, not LDS, set the occupancy
     // (profiles/r01_ab_notes.txt); deeper levels spill to global memory
     sc.stackLds = 20;

@@ -445,27 +445,49 @@ TG_DEV uint32_t stackPop(const DScene &sc, uint32_t *stack, int &sp)
 // Traversal of the quantised BVH4 (bvh_build.h).
 // Closest (ANY = false): lexicographic minimum of (t, soup triangle id) over all valid triangles.
 // Any-hit (ANY = true): returns true at the first valid triangle.
-template <bool ANY, bool COUNT>
-TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 &O, const V3 &D, float tnear, float &bestT, float &bestU, float &bestV,
-                     uint32_t &bestPrim, TraceCounters &tc)
+// One ray's traversal state; travStep advances it by one BVH item.
+struct TravState {
+    V3 O, D, inv, noi;
+    float tnear, tfar0, bestT, bestU, bestV;
+    uint32_t bestPrim, node;
+    int sp;
+    bool nx, ny, nz;
+};
+enum { TRAV_MORE = 0, TRAV_DONE = 1, TRAV_ANYHIT = 2 };
+
+TG_DEV void travInit(TravState &r, uint32_t root, const V3 &O, const V3 &D, float tnear, float tfar, uint32_t bestPrim)
 {
-    const float tfar0 = bestT;
+    r.O = O; r.D = D;
+    r.tnear = tnear; r.tfar0 = tfar; r.bestT = tfar; r.bestU = 0.0f; r.bestV = 0.0f; r.bestPrim = bestPrim;
     // keep 1/d finite so that 0*inf never appears in the slab test
     V3 ds(__builtin_fabsf(D.x) < 1e-20f ? __builtin_copysignf(1e-20f, D.x) : D.x,
           __builtin_fabsf(D.y) < 1e-20f ? __builtin_copysignf(1e-20f, D.y) : D.y,
           __builtin_fabsf(D.z) < 1e-20f ? __builtin_copysignf(1e-20f, D.z) : D.z);
-    V3 inv(1.0f/ds.x, 1.0f/ds.y, 1.0f/ds.z);
-    V3 noi(-O.x*inv.x, -O.y*inv.y, -O.z*inv.z);
-    const int maxSp = sc.stackEntries;
-    int sp = 0;
-    uint32_t node = root;
+    r.inv = V3(1.0f/ds.x, 1.0f/ds.y, 1.0f/ds.z);
+    r.noi = V3(-O.x*r.inv.x, -O.y*r.inv.y, -O.z*r.inv.z);
+    r.sp = 0;
+    r.node = root;
     // per-axis choice of the near/far byte plane (bvh_build.h, Bvh4): for a negative direction the near
     // plane of the box is HI
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-    // One BVH item per iteration and lane -- an inner node or ONE triangle of a leaf, both 64-byte records -- fetched by
-    // the same four loads at the top: every iteration costs a single memory round trip whichever mix of nodes and
-    // triangles the lanes hold (a per-leaf triangle loop cost the wave one round trip per triangle of its largest leaf).
-    while (true) {
+    r.nx = r.inv.x < 0.0f; r.ny = r.inv.y < 0.0f; r.nz = r.inv.z < 0.0f;
+}
+
+// One BVH item per step and lane -- an inner node or ONE triangle of a leaf, both 64-byte records -- fetched by
+// the same four loads at the top: every step costs a single memory round trip whichever mix of nodes and
+// triangles the lanes hold (a per-leaf triangle loop cost the wave one round trip per triangle of its largest leaf).
+// Closest (ANY = false): lexicographic minimum of (t, soup triangle id) over all valid triangles.
+template <bool ANY, bool COUNT>
+TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounters &tc)
+{
+    const int maxSp = sc.stackEntries;
+    const V3 &O = r.O, &D = r.D, &inv = r.inv, &noi = r.noi;
+    const float tnear = r.tnear, tfar0 = r.tfar0;
+    const bool nx = r.nx, ny = r.ny, nz = r.nz;
+    uint32_t &node = r.node;
+    int &sp = r.sp;
+    float &bestT = r.bestT, &bestU = r.bestU, &bestV = r.bestV;
+    uint32_t &bestPrim = r.bestPrim;
+    {
         const bool leaf = (node & 0x80000000u) != 0;
         const uint32_t payload = node & 0x7FFFFFFFu; // leaf: first << 3 | count - 1
         const float4 *n = leaf ? sc.tris + size_t(payload >> 3)*4 : sc.nodes + size_t(node)*4;
@@ -507,14 +529,14 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
                 if (key[2] != 0xFFFFFFFFu && sp < maxSp) stackPush(sc, stack, sp, TG_CHILD(key[2]));
                 if (key[1] != 0xFFFFFFFFu && sp < maxSp) stackPush(sc, stack, sp, TG_CHILD(key[1]));
                 node = TG_CHILD(key[0]);
-                continue;
+                return TRAV_MORE;
             }
 #undef TG_CHILD
         } else {
             if (COUNT) tc.tris++;
             float t, u, v;
             if (triTest(q0, q1, q2, O, D, tnear, tfar0, t, u, v)) {
-                if (ANY) return true;
+                if (ANY) return TRAV_ANYHIT;
                 const uint32_t id = __float_as_uint(q3.x);
                 if (t < bestT || (t == bestT && id < bestPrim)) {
                     bestT = t; bestU = u; bestV = v; bestPrim = id;
@@ -522,13 +544,26 @@ TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 
             }
             if (payload & 7u) { // next triangle of the leaf: first + 1, count - 1
                 node += 7u;
-                continue;
+                return TRAV_MORE;
             }
         }
-        if (sp == 0) break;
-        node = stackPop(sc, stack, sp);
     }
-    return false;
+    if (sp == 0) return TRAV_DONE;
+    node = stackPop(sc, stack, sp);
+    return TRAV_MORE;
+}
+
+template <bool ANY, bool COUNT>
+TG_DEV bool traverse(const DScene &sc, uint32_t *stack, uint32_t root, const V3 &O, const V3 &D, float tnear, float &bestT, float &bestU, float &bestV,
+                     uint32_t &bestPrim, TraceCounters &tc)
+{
+    TravState r;
+    travInit(r, root, O, D, tnear, bestT, bestPrim);
+    r.bestU = bestU; r.bestV = bestV;
+    int state;
+    do state = travStep<ANY, COUNT>(sc, stack, r, tc); while (state == TRAV_MORE);
+    bestT = r.bestT; bestU = r.bestU; bestV = r.bestV; bestPrim = r.bestPrim;
+    return state == TRAV_ANYHIT;
 }
 
 // =================================================================================================
@@ -913,6 +948,157 @@ __global__ void __launch_bounds__(256, (INST ? 1 : TG_EXTEND_WAVES)) k_extend(DS
                 if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p2);
                 if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p3);
             }
+        }
+    }
+    if (COUNT) flushCounters(st.stats, 0, tc);
+}
+
+// =================================================================================================
+// K2 extend, queue form (scenes without instances / spheres / disks): a wave claims 256 list entries and every lane
+// owns FOUR of them, traced back to back inside ONE traversal loop.  With one ray per lane a wave runs for as long as
+// its slowest ray (measured: 25 % of the lanes busy per VALU instruction, SQ_THREAD_CYCLES_VALU); with a private
+// queue per lane it runs for the slowest SUM of four, which varies much less.  Finished lanes are re-armed in
+// groups (>= TG_EXTQ_THRESH waiting lanes, or nobody left tracing), so the re-arm code runs a few times per claim,
+// not once per ray, and the next ray of each lane is already in registers (prefetched while the current one is
+// traced), so re-arming never waits for memory.  Per-ray arithmetic is closestHit's, unchanged.
+// =================================================================================================
+#ifndef TG_EXTQ_THRESH
+#define TG_EXTQ_THRESH 16
+#endif
+#ifndef TG_EXTQ_WAVES
+#define TG_EXTQ_WAVES 6
+#endif
+constexpr uint32_t PRIM_IDLE = 0xFFFFFFFDu; // queue entry whose slot holds no live path
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DState st, int set)
+{
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 0);
+    TraceCounters tc{0, 0};
+    while (true) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&st.counters[CNT(CNT_HEAD_EXT)], 256u);
+        base = __shfl(base, 0);
+        if (base >= count) break;
+        // the lane's queue: entries base + lane + 64*b (the b-th rays of the wave are 64 consecutive entries, as before)
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        int n = 0;
+        if (base + lane < count && listFetch(st, lc, set, 0, base + lane, p0)) n = 1;
+        if (n == 1 && base + lane + 64u < count && listFetch(st, lc, set, 0, base + lane + 64u, p1)) n = 2;
+        if (n == 2 && base + lane + 128u < count && listFetch(st, lc, set, 0, base + lane + 128u, p2)) n = 3;
+        if (n == 3 && base + lane + 192u < count && listFetch(st, lc, set, 0, base + lane + 192u, p3)) n = 4;
+        uint32_t h0 = PRIM_IDLE, h1 = PRIM_IDLE, h2 = PRIM_IDLE, h3 = PRIM_IDLE; // prim each ray ended on
+#define TG_SLOT(b) ((b) == 0 ? p0 : ((b) == 1 ? p1 : ((b) == 2 ? p2 : p3)))
+        float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro; // ray b + 1, in flight while ray b is traced
+        uint32_t nflags = 0;
+        if (n > 0) {
+            nro = ldStream(&st.rayO[p0]);
+            nrd = ldStream(&st.rayD[p0]);
+            nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[p0]) + 3);
+        }
+        int b = -1;
+        bool active = false, fin = false;
+        TravState r;
+        r.node = 0; r.sp = 0; r.bestT = 0.0f; r.bestU = 0.0f; r.bestV = 0.0f; r.bestPrim = PRIM_MISS;
+        while (true) {
+            if (active) {
+                if (travStep<false, COUNT>(sc, stack, r, tc) != TRAV_MORE) {
+                    active = false;
+                    fin = true;
+                }
+            }
+            const bool waiting = !active && (fin || b + 1 < n);
+            const unsigned long long w = __ballot(waiting), act = __ballot(active);
+            if (w == 0 && act == 0) break;
+            if (act != 0 && __builtin_popcountll(w) < TG_EXTQ_THRESH) continue;
+            if (waiting) {
+                if (fin) { // retire ray b
+                    const uint32_t slot = TG_SLOT(b);
+                    stStream(&st.hit[slot], make_float4(r.bestT, r.bestU, r.bestV, __uint_as_float(r.bestPrim)));
+                    h0 = b == 0 ? r.bestPrim : h0; h1 = b == 1 ? r.bestPrim : h1; h2 = b == 2 ? r.bestPrim : h2; h3 = b == 3 ? r.bestPrim : h3;
+                    fin = false;
+                }
+                if (b + 1 < n) { // arm ray b + 1 from the prefetch registers
+                    ++b;
+                    const bool dead = flagsEnd(nflags) == END_DEAD;
+                    if (!dead) {
+                        const V3 O = xyz(nro), D = xyz(nrd);
+                        const float tnear = nro.w;
+                        float tfar = nrd.w, u = 0.0f, v = 0.0f;
+                        uint32_t prim = PRIM_MISS;
+                        for (uint32_t i = 0; i < sc.nQuads; ++i) { // closestHit's order: quads, cubes, triangles
+                            QuadHit h;
+                            if (quadIntersect(sc.quads[i], O, D, tnear, tfar, h)) {
+                                tfar = h.t; u = h.u; v = h.v;
+                                prim = mkPrim(KIND_QUAD, i);
+                            }
+                        }
+                        for (uint32_t i = 0; i < sc.nCubes; ++i) {
+                            float t;
+                            bool back;
+                            if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, t, back)) {
+                                tfar = t; u = 0.0f; v = 0.0f;
+                                prim = mkPrim(KIND_CUBE, i);
+                            }
+                        }
+                        // the triangles start from what the quads and cubes left: a triangle wins when it is nearer, or at
+                        // the same distance (its id is below every quad / cube id and below PRIM_MISS, as in traverse())
+                        travInit(r, sc.rootChild, O, D, tnear, tfar, prim);
+                        r.bestU = u; r.bestV = v;
+                        if (sc.nTris) active = true;
+                        else fin = true;
+                    }
+                    if (b + 1 < n) {
+                        const uint32_t next = TG_SLOT(b + 1);
+                        nro = ldStream(&st.rayO[next]);
+                        nrd = ldStream(&st.rayD[next]);
+                        nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[next]) + 3);
+                    }
+                }
+            }
+        }
+#undef TG_SLOT
+        // classification and the list appends of k_extend
+        uint32_t cls4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t prim = q == 0 ? h0 : (q == 1 ? h1 : (q == 2 ? h2 : h3));
+            const uint32_t slot = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
+            uint32_t cls = 0xFEu;
+            if (q < n) {
+                if (prim == PRIM_IDLE) {
+                    cls = 0xFDu;
+                } else {
+                    cls = hitClass(sc, prim);
+                    if (sc.nMedia && (st.med[slot] & 0xFFu)) cls = TG_CLASS_VOLUME;
+                }
+            }
+            cls4 |= cls << (8*q);
+        }
+        const int out = set ^ 1;
+#pragma unroll
+        for (int l = 0; l <= TG_LISTS; ++l) {
+            const uint32_t want = l == 0 ? 0xFFu : (l == TG_LISTS ? 0xFDu : uint32_t(l - 1));
+            unsigned long long m0 = __ballot((cls4 & 0xFFu) == want), m1 = __ballot(((cls4 >> 8) & 0xFFu) == want);
+            unsigned long long m2 = __ballot(((cls4 >> 16) & 0xFFu) == want), m3 = __ballot((cls4 >> 24) == want);
+            uint32_t n0 = uint32_t(__builtin_popcountll(m0)), n1 = uint32_t(__builtin_popcountll(m1));
+            uint32_t n2 = uint32_t(__builtin_popcountll(m2)), n3 = uint32_t(__builtin_popcountll(m3));
+            uint32_t nn = n0 + n1 + n2 + n3;
+            if (nn == 0) continue;
+            uint32_t *dst = l == TG_LISTS ? st.freeQ : st.lists[out][l];
+            uint32_t *ctr = l == TG_LISTS ? &st.counters[CNT(CNT_FREE)] : &st.counters[CNT(CNT_LIST0 + out*TG_LISTS + l)];
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(ctr, nn);
+            wbase = __shfl(wbase, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p0);
+            if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p1);
+            if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p2);
+            if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p3);
         }
     }
     if (COUNT) flushCounters(st.stats, 0, tc);

@@ -14,7 +14,7 @@ here: total work is fixed -> "scaling": "strong"); each rank renders its shard w
 collective and one RCCL gather of the framebuffers to rank 0 closes the timed region.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = k_extend (closest-hit BVH traversal), HBM bound.  achieved =
+  roofline     dominant kernel = k_extend_q (closest-hit BVH traversal, four rays per lane), HBM bound.  achieved =
                algorithmic bytes per launch / average launch duration, both measured live after
                the timed region: bytes from the kernel's own visit counters (64 B per BVH node
                fetch, 48 B per triangle fetch, 56 B of queue traffic per ray), duration from HIP
@@ -191,7 +191,7 @@ def main():
             for cx in ctxs:
                 cx.set_profiling(0)
             return tot
-        c = phase(1, done)                       # visit counters (k_extend<true,..>)
+        c = phase(1, done)                       # visit counters (k_extend_q<true>)
         t = phase(2, done + spp_step*rsteps)     # HIP-event timing of the production kernels, each on its own stream
         launches = max(1, c["extend_launches"])
         bytes_per_launch = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES +
@@ -206,7 +206,7 @@ def main():
             except Exception:
                 traffic = None
         result["roofline"] = {
-            "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "k_extend_q", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "avg_launch_ms": round(avg_ms, 5),
             "launches_per_step": round(launches/rsteps, 2), "pools": K,

@@ -93,7 +93,7 @@ private:
     static uint32_t leafLimit()
     {
         const char *e = std::getenv("TGPU_BVH_LEAF");
-        int v = e ? std::atoi(e) : 4;
+        int v = e ? std::atoi(e) : 2; // 2 is the measured optimum once a triangle costs one traversal step (profiles/r01_ab_notes.txt)
         return uint32_t(v < 1 ? 1 : (v > 8 ? 8 : v));
     }
 

@@ -954,10 +954,10 @@ __global__ void __launch_bounds__(256, (INST ? 1 : TG_EXTEND_WAVES)) k_extend(DS
 }
 
 // =================================================================================================
-// K2 extend, queue form (scenes without instances / spheres / disks): a wave claims 256 list entries and every lane
-// owns FOUR of them, traced back to back inside ONE traversal loop.  With one ray per lane a wave runs for as long as
+// K2 extend, queue form (scenes without instances / spheres / disks): a wave claims 64*DEPTH list entries and every lane
+// owns DEPTH (4 or 8) of them, traced back to back inside ONE traversal loop.  With one ray per lane a wave runs for as long as
 // its slowest ray (measured: 25 % of the lanes busy per VALU instruction, SQ_THREAD_CYCLES_VALU); with a private
-// queue per lane it runs for the slowest SUM of four, which varies much less.  Finished lanes are re-armed in
+// queue per lane it runs for the slowest SUM of DEPTH rays, which varies much less.  Finished lanes are re-armed in
 // groups (>= TG_EXTQ_THRESH waiting lanes, or nobody left tracing), so the re-arm code runs a few times per claim,
 // not once per ray, and the next ray of each lane is already in registers (prefetched while the current one is
 // traced), so re-arming never waits for memory.  Per-ray arithmetic is closestHit's, unchanged.
@@ -968,11 +968,15 @@ __global__ void __launch_bounds__(256, (INST ? 1 : TG_EXTEND_WAVES)) k_extend(DS
 #ifndef TG_EXTQ_WAVES
 #define TG_EXTQ_WAVES 6
 #endif
+#ifndef TG_EXTQ_WAVES_DEEP
+#define TG_EXTQ_WAVES_DEEP 5
+#endif
 constexpr uint32_t PRIM_IDLE = 0xFFFFFFFDu; // queue entry whose slot holds no live path
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DState st, int set)
+template <bool COUNT, int DEPTH>
+__global__ void __launch_bounds__(256, (DEPTH > 4 ? TG_EXTQ_WAVES_DEEP : TG_EXTQ_WAVES)) k_extend_q(DScene sc, DState st, int set)
 {
+    static_assert(DEPTH % 4 == 0, "the list appends work on groups of four entries");
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -981,24 +985,31 @@ __global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DSta
     TraceCounters tc{0, 0};
     while (true) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&st.counters[CNT(CNT_HEAD_EXT)], 256u);
+        if (lane == 0) base = atomicAdd(&st.counters[CNT(CNT_HEAD_EXT)], 64u*DEPTH);
         base = __shfl(base, 0);
         if (base >= count) break;
-        // the lane's queue: entries base + lane + 64*b (the b-th rays of the wave are 64 consecutive entries, as before)
-        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        // the lane's queue: entries base + lane + 64*b (the b-th rays of the wave are 64 consecutive entries, as before);
+        // p[] and h[] are only ever indexed by unrolled loops, so they stay in registers
+        uint32_t p[DEPTH], h[DEPTH]; // slot of each entry, prim each ray ended on
         int n = 0;
-        if (base + lane < count && listFetch(st, lc, set, 0, base + lane, p0)) n = 1;
-        if (n == 1 && base + lane + 64u < count && listFetch(st, lc, set, 0, base + lane + 64u, p1)) n = 2;
-        if (n == 2 && base + lane + 128u < count && listFetch(st, lc, set, 0, base + lane + 128u, p2)) n = 3;
-        if (n == 3 && base + lane + 192u < count && listFetch(st, lc, set, 0, base + lane + 192u, p3)) n = 4;
-        uint32_t h0 = PRIM_IDLE, h1 = PRIM_IDLE, h2 = PRIM_IDLE, h3 = PRIM_IDLE; // prim each ray ended on
-#define TG_SLOT(b) ((b) == 0 ? p0 : ((b) == 1 ? p1 : ((b) == 2 ? p2 : p3)))
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) {
+            p[q] = 0;
+            h[q] = PRIM_IDLE;
+            if (n == q && base + lane + 64u*q < count && listFetch(st, lc, set, 0, base + lane + 64u*q, p[q])) n = q + 1;
+        }
+        auto slotOf = [&](int i) {
+            uint32_t v = p[0];
+#pragma unroll
+            for (int q = 1; q < DEPTH; ++q) v = i == q ? p[q] : v;
+            return v;
+        };
         float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro; // ray b + 1, in flight while ray b is traced
         uint32_t nflags = 0;
         if (n > 0) {
-            nro = ldStream(&st.rayO[p0]);
-            nrd = ldStream(&st.rayD[p0]);
-            nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[p0]) + 3);
+            nro = ldStream(&st.rayO[p[0]]);
+            nrd = ldStream(&st.rayD[p[0]]);
+            nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[p[0]]) + 3);
         }
         int b = -1;
         bool active = false, fin = false;
@@ -1017,9 +1028,9 @@ __global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DSta
             if (act != 0 && __builtin_popcountll(w) < TG_EXTQ_THRESH) continue;
             if (waiting) {
                 if (fin) { // retire ray b
-                    const uint32_t slot = TG_SLOT(b);
-                    stStream(&st.hit[slot], make_float4(r.bestT, r.bestU, r.bestV, __uint_as_float(r.bestPrim)));
-                    h0 = b == 0 ? r.bestPrim : h0; h1 = b == 1 ? r.bestPrim : h1; h2 = b == 2 ? r.bestPrim : h2; h3 = b == 3 ? r.bestPrim : h3;
+                    stStream(&st.hit[slotOf(b)], make_float4(r.bestT, r.bestU, r.bestV, __uint_as_float(r.bestPrim)));
+#pragma unroll
+                    for (int q = 0; q < DEPTH; ++q) h[q] = b == q ? r.bestPrim : h[q];
                     fin = false;
                 }
                 if (b + 1 < n) { // arm ray b + 1 from the prefetch registers
@@ -1031,9 +1042,9 @@ __global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DSta
                         float tfar = nrd.w, u = 0.0f, v = 0.0f;
                         uint32_t prim = PRIM_MISS;
                         for (uint32_t i = 0; i < sc.nQuads; ++i) { // closestHit's order: quads, cubes, triangles
-                            QuadHit h;
-                            if (quadIntersect(sc.quads[i], O, D, tnear, tfar, h)) {
-                                tfar = h.t; u = h.u; v = h.v;
+                            QuadHit qh;
+                            if (quadIntersect(sc.quads[i], O, D, tnear, tfar, qh)) {
+                                tfar = qh.t; u = qh.u; v = qh.v;
                                 prim = mkPrim(KIND_QUAD, i);
                             }
                         }
@@ -1053,7 +1064,7 @@ __global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DSta
                         else fin = true;
                     }
                     if (b + 1 < n) {
-                        const uint32_t next = TG_SLOT(b + 1);
+                        const uint32_t next = slotOf(b + 1);
                         nro = ldStream(&st.rayO[next]);
                         nrd = ldStream(&st.rayD[next]);
                         nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[next]) + 3);
@@ -1061,44 +1072,45 @@ __global__ void __launch_bounds__(256, TG_EXTQ_WAVES) k_extend_q(DScene sc, DSta
                 }
             }
         }
-#undef TG_SLOT
-        // classification and the list appends of k_extend
-        uint32_t cls4 = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t prim = q == 0 ? h0 : (q == 1 ? h1 : (q == 2 ? h2 : h3));
-            const uint32_t slot = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
-            uint32_t cls = 0xFEu;
-            if (q < n) {
-                if (prim == PRIM_IDLE) {
-                    cls = 0xFDu;
-                } else {
-                    cls = hitClass(sc, prim);
-                    if (sc.nMedia && (st.med[slot] & 0xFFu)) cls = TG_CLASS_VOLUME;
-                }
-            }
-            cls4 |= cls << (8*q);
-        }
+        // classification and the list appends of k_extend, four entries at a time
         const int out = set ^ 1;
 #pragma unroll
-        for (int l = 0; l <= TG_LISTS; ++l) {
-            const uint32_t want = l == 0 ? 0xFFu : (l == TG_LISTS ? 0xFDu : uint32_t(l - 1));
-            unsigned long long m0 = __ballot((cls4 & 0xFFu) == want), m1 = __ballot(((cls4 >> 8) & 0xFFu) == want);
-            unsigned long long m2 = __ballot(((cls4 >> 16) & 0xFFu) == want), m3 = __ballot((cls4 >> 24) == want);
-            uint32_t n0 = uint32_t(__builtin_popcountll(m0)), n1 = uint32_t(__builtin_popcountll(m1));
-            uint32_t n2 = uint32_t(__builtin_popcountll(m2)), n3 = uint32_t(__builtin_popcountll(m3));
-            uint32_t nn = n0 + n1 + n2 + n3;
-            if (nn == 0) continue;
-            uint32_t *dst = l == TG_LISTS ? st.freeQ : st.lists[out][l];
-            uint32_t *ctr = l == TG_LISTS ? &st.counters[CNT(CNT_FREE)] : &st.counters[CNT(CNT_LIST0 + out*TG_LISTS + l)];
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(ctr, nn);
-            wbase = __shfl(wbase, 0);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p0);
-            if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p1);
-            if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p2);
-            if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p3);
+        for (int g = 0; g < DEPTH; g += 4) {
+            uint32_t cls4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t cls = 0xFEu;
+                if (g + q < n) {
+                    if (h[g + q] == PRIM_IDLE) {
+                        cls = 0xFDu;
+                    } else {
+                        cls = hitClass(sc, h[g + q]);
+                        if (sc.nMedia && (st.med[p[g + q]] & 0xFFu)) cls = TG_CLASS_VOLUME;
+                    }
+                }
+                cls4 |= cls << (8*q);
+            }
+            if (__ballot(g < n) == 0) break;
+#pragma unroll
+            for (int l = 0; l <= TG_LISTS; ++l) {
+                const uint32_t want = l == 0 ? 0xFFu : (l == TG_LISTS ? 0xFDu : uint32_t(l - 1));
+                unsigned long long m0 = __ballot((cls4 & 0xFFu) == want), m1 = __ballot(((cls4 >> 8) & 0xFFu) == want);
+                unsigned long long m2 = __ballot(((cls4 >> 16) & 0xFFu) == want), m3 = __ballot((cls4 >> 24) == want);
+                uint32_t n0 = uint32_t(__builtin_popcountll(m0)), n1 = uint32_t(__builtin_popcountll(m1));
+                uint32_t n2 = uint32_t(__builtin_popcountll(m2)), n3 = uint32_t(__builtin_popcountll(m3));
+                uint32_t nn = n0 + n1 + n2 + n3;
+                if (nn == 0) continue;
+                uint32_t *dst = l == TG_LISTS ? st.freeQ : st.lists[out][l];
+                uint32_t *ctr = l == TG_LISTS ? &st.counters[CNT(CNT_FREE)] : &st.counters[CNT(CNT_LIST0 + out*TG_LISTS + l)];
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(ctr, nn);
+                wbase = __shfl(wbase, 0);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p[g]);
+                if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p[g + 1]);
+                if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p[g + 2]);
+                if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p[g + 3]);
+            }
         }
     }
     if (COUNT) flushCounters(st.stats, 0, tc);

@@ -88,7 +88,7 @@ struct tgpu_ctx {
     uint32_t ringFree = (1u << TG_RING) - 1u;
     int numCUs = 256;
     int maxGrid = 2048;
-    bool extendQueue = true;    // TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
+    int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
     size_t ldsBytes = 0;
 
     uint32_t profFlags = 0;
@@ -476,7 +476,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.nInstSets = s->n_instance_sets;
 
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
-    if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) != 0;
+    if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
     if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
     float4 *dNodes, *dTris;
@@ -851,9 +851,12 @@ static int driveIteration(tgpu_ctx *ctx)
                 if (count) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
                 else hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
             } else {
-                if (ctx->extendQueue) { // queue form: four rays per lane (kernels.h, k_extend_q)
-                    if (count) hipLaunchKernelGGL(k_extend_q<true>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-                    else hipLaunchKernelGGL(k_extend_q<false>, dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                if (ctx->extendQueue == 8) { // queue form: eight (or four) rays per lane (kernels.h, k_extend_q)
+                    if (count) hipLaunchKernelGGL((k_extend_q<true, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                    else hipLaunchKernelGGL((k_extend_q<false, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                } else if (ctx->extendQueue) {
+                    if (count) hipLaunchKernelGGL((k_extend_q<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                    else hipLaunchKernelGGL((k_extend_q<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
                 } else if (count) hipLaunchKernelGGL((k_extend<true, false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
                 else hipLaunchKernelGGL((k_extend<false, false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
             }

@@ -30,9 +30,9 @@ for k, t in tot.items():
     out[k] = {"launches": calls[k], "fetch_bytes_per_launch": fetch/n, "write_bytes_per_launch": write/n,
               "hbm_bytes_per_launch": (fetch + write)/n, "l2_hit_rate": hit/max(1.0, hit + miss)}
 json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-ext = next((v for k, v in out.items() if k.startswith("k_extend_q<false>")), None)
+ext = next((v for k, v in out.items() if k.startswith("k_extend_q<false")), None)
 if ext:
-    json.dump({"kernel": "k_extend_q<false>", "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+    json.dump({"kernel": "k_extend_q<false, 4>", "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                "hbm_bytes_per_launch": round(ext["hbm_bytes_per_launch"]), "fetch_bytes_per_launch": round(ext["fetch_bytes_per_launch"]),
                "write_bytes_per_launch": round(ext["write_bytes_per_launch"]), "l2_hit_rate": round(ext["l2_hit_rate"], 4),
                "note": "FETCH_SIZE doubled per the gfx950 16-B/lane correction; includes Infinity-Cache hits"},

@@ -307,6 +307,8 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
 //    slot is marked idle and the next extend drops it onto the free list.
 // Claims are aggregated per 1024-thread block (one global atomic per 1024 entries), job counters per block
 // in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
+TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
+
 #ifdef TG_TU_MAIN
 static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
                                                             unsigned long long limit)
@@ -325,6 +327,9 @@ static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DS
         uint32_t slot = 0, ring = 0xFFFFFFFFu;
         bool needs = false;
         if (q < total && listFetch(st, lc, set, 0, q, slot)) {
+            // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so that
+            // their record is read and written once, not by a miss kernel first and by this one again
+            if (q < lc.n[0]) missPath(sc, st, slot);
             float4 tpw = st.tp[slot];
             int end = flagsEnd(__float_as_uint(tpw.w));
             if (end != END_ALIVE) {
@@ -1117,7 +1122,7 @@ __global__ void __launch_bounds__(256, (DEPTH > 4 ? TG_EXTQ_WAVES_DEEP : TG_EXTQ
 }
 
 // =================================================================================================
-// K5 miss: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) + end of traceSample
+// K5 miss (runs inside k_retire_regenerate): TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) + end of traceSample
 // =================================================================================================
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
 {
@@ -1151,14 +1156,6 @@ TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
 }
 
-#ifdef TG_TU_MAIN
-static __global__ void __launch_bounds__(256) k_miss(DScene sc, DState st, int set)
-{
-    const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS)];
-    const uint32_t *list = st.lists[set][0];
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) missPath(sc, st, list[q]);
-}
-#endif
 
 // =================================================================================================
 // K3 shade

@@ -864,7 +864,6 @@ static int driveIteration(tgpu_ctx *ctx)
         ctx->stats.extend_launches++;
         {
             Timer t(ctx, &ctx->stats.shade_ms);
-            hipLaunchKernelGGL(k_miss, dim3(grid), dim3(256), 0, stream, sc, st, out);
             // one launch per BSDF class that occurs in the scene (ctx->classMask, set at upload)
 #define TG_LAUNCH_SHADE(C) if (ctx->classMask & (1u << (C))) { \
                 if (ctx->generalShading) hipLaunchKernelGGL((k_shade<C, true>), dim3(grid), dim3(256), 0, stream, sc, st, out); \

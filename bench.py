@@ -52,7 +52,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--spp-step", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -101,7 +101,7 @@ def main():
     shards = [ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, rank*K + j, world*K) for j in range(K)]
     ctxs = [ta.Context(dev_index) for _ in range(K)]
     for c, sh in zip(ctxs, shards):
-        c.upload(scene, sh)
+        c.upload(scene, sh, int(os.environ.get("TGPU_BENCH_MAX_PATHS", "0")))  # 0 = the core's default pool (A/B knob)
     outs = [torch.zeros((sh.n_pixels, 3), dtype=torch.float32, device=device) for sh in shards]
     ctx, shard = ctxs[0], shards[0]
     spp_step = args.spp_step

@@ -206,6 +206,29 @@ def test_full_size_pass_properties(ta, oracle_py, gpu_ctx):
     assert img.shape == (720, 1280, 3)
 
 
+def test_scheduling_choices_do_not_change_the_image(ta, gpu_ctx, monkeypatch):
+    """How rays are scheduled is a performance choice only: one ray per lane or a queue of 4 / 8 per lane (k_extend /
+    k_extend_q), the BVH leaf limit, the pool size and the LDS share of the traversal stack must all give the bits of
+    the default configuration (640x360, 8 spp of config 2)."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(640, 360))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+
+    def render(env, max_paths=0):
+        for k in ("TGPU_EXTEND_Q", "TGPU_BVH_LEAF", "TGPU_STACK_LDS", "TGPU_TAIL_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu_ctx.upload(hs, shard, max_paths)
+        gpu_ctx.render(8, spp_step=4)
+        return gpu_ctx.download()[0]
+
+    base = render({})
+    for env, pool in [({"TGPU_EXTEND_Q": "0"}, 0), ({"TGPU_EXTEND_Q": "8"}, 0), ({"TGPU_BVH_LEAF": "4"}, 0),
+                      ({"TGPU_BVH_LEAF": "1", "TGPU_EXTEND_Q": "8"}, 50000), ({"TGPU_STACK_LDS": "3", "TGPU_TAIL_MAX": "0"}, 4096)]:
+        assert np.array_equal(render(env, pool), base), f"{env} pool {pool} changed the image"
+    render({})  # leave the shared context in its default configuration
+
+
 def test_image_matches_reference_golden_within_tolerance(ta, gpu_ctx):
     """GPU image vs the compiled reference's golden PFM: identical Sobol sequences, but the supplemental
     stream is path-local and t,u,v use IEEE division -> agreement is statistical, not bitwise."""

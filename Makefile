@@ -4,7 +4,7 @@ ROOT      := $(abspath .)
 CXX       ?= g++
 HIPCC     ?= /opt/rocm/bin/hipcc
 CXXFLAGS  := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -DTUNGSTEN_AMD_DEFAULT_ASSETS='"$(ROOT)/assets"'
-HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function
+HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-assume
 
 HOST_SRC  := tungsten_amd/host/scene.cpp tungsten_amd/host/capi.cpp
 CLI_SRC   := tungsten_amd/host/scene.cpp tungsten_amd/host/integrator.cpp tungsten_amd/host/tungsten_cli.cpp
@@ -43,4 +43,5 @@ $(ORACLE_LIB): oracle/oracle.cpp oracle/oracle.h include/tungsten_amd.h include/
 
 clean:
 	rm -f $(HOST_LIB) $(CORE_LIB) $(ORACLE_LIB) $(CLI_BIN)
+	rm -rf build/core
 .PHONY: all host core oracle cli clean

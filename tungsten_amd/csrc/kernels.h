@@ -2317,7 +2317,7 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
 // retires it.  Every slot of the lists ends on the free list.
 // =================================================================================================
 template <bool COUNT, bool INST, bool FWD>
-__global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
+__global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uint32_t spread)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
@@ -2328,9 +2328,12 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set)
     const uint32_t rounded = (total + 63u) & ~63u;
     TraceCounters tcE{0, 0}, tcS{0, 0};
     uint32_t extRays = 0, shRays = 0, events = 0;
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
+    // only every `spread`-th lane takes a path: a wave lasts as long as the slowest of its 64 / spread paths, and the paths
+    // spread over more waves per SIMD, which is what the last few thousand paths of a render need (latency, not throughput)
+    for (uint32_t g = blockIdx.x*blockDim.x + threadIdx.x; g < rounded*spread; g += stride) {
+        const uint32_t q = g/spread;
         uint32_t slot = 0, ring = 0xFFFFFFFFu;
-        const bool have = q < total && listFetch(st, lc, set, 0, q, slot);
+        const bool have = g % spread == 0 && q < total && listFetch(st, lc, set, 0, q, slot);
         if (have) {
             while (flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE) {
                 float4 ro = st.rayO[slot], rd = st.rayD[slot];
@@ -2499,9 +2502,9 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shadow<true, true, false>(DScene, DState, int); \
     PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
 #define TG_KERNELS_TAIL(PFX, I) \
-    PFX template __global__ void k_tail<false, I, false>(DScene, DState, int); \
-    PFX template __global__ void k_tail<false, I, true>(DScene, DState, int); \
-    PFX template __global__ void k_tail<true, I, false>(DScene, DState, int); \
-    PFX template __global__ void k_tail<true, I, true>(DScene, DState, int);
+    PFX template __global__ void k_tail<false, I, false>(DScene, DState, int, uint32_t); \
+    PFX template __global__ void k_tail<false, I, true>(DScene, DState, int, uint32_t); \
+    PFX template __global__ void k_tail<true, I, false>(DScene, DState, int, uint32_t); \
+    PFX template __global__ void k_tail<true, I, true>(DScene, DState, int, uint32_t);
 
 } // namespace tg

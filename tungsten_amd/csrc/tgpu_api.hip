@@ -83,6 +83,7 @@ struct tgpu_ctx {
     uint32_t nCur = 0, freeCount = 0;
     uint32_t listCount[TG_LISTS] = {0};
     uint64_t tailMax = 65536; // switch to the tail kernel below this many live paths
+    uint32_t tailSpread = 2;  // lanes per path in the tail kernel (power of two; TGPU_TAIL_SPREAD)
     uint64_t aliveCount = 0, hostExtendRays = 0;
     int curQ = 0;
     uint32_t ringFree = (1u << TG_RING) - 1u;
@@ -477,6 +478,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
 
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
     if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
+    if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
     if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
     float4 *dNodes, *dTris;
@@ -828,10 +830,13 @@ static int driveIteration(tgpu_ctx *ctx)
     }
     if (tail) {
         Timer t(ctx, &ctx->stats.other_ms);
-        int grid = gridFor(ctx, nCur);
+        // lanes per path: as many as keep the grid within the resident waves (profiles/r01_ab_notes.txt)
+        uint32_t spread = ctx->tailSpread;
+        while (spread > 1 && uint64_t(nCur)*spread > uint64_t(ctx->maxGrid)*256) spread /= 2;
+        int grid = gridFor(ctx, uint64_t(nCur)*spread);
         // variants: COUNT (visit counters), INST ("instances" in the scene), FWD (forward-scattering surfaces: shadow walk)
         const int variant = (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
-#define TG_LAUNCH_TAIL(C, I, F) hipLaunchKernelGGL((k_tail<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur)
+#define TG_LAUNCH_TAIL(C, I, F) hipLaunchKernelGGL((k_tail<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, spread)
         switch (variant) {
         case 0: TG_LAUNCH_TAIL(false, false, false); break;
         case 1: TG_LAUNCH_TAIL(false, false, true); break;

@@ -311,7 +311,8 @@ const char *tgpu_last_error(const tgpu_ctx *ctx);
 /* TraceableScene ctor + Integrator::prepareForRender
  * (TraceableScene.hpp:57-137, PathTraceIntegrator.cpp:184-201): copies the
  * flattened scene to HBM, builds the BVH, allocates the wavefront queues for
- * `max_paths_in_flight` paths (0 = pick from shard size).                    */
+ * `max_paths_in_flight` paths (0 = the default pool: 16 Mi slots = 5.3 GiB
+ * of HBM, fewer only for shards under 64 Ki pixels).                         */
 int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *scene,
                       const tgpu_shard_desc *shard, uint64_t max_paths_in_flight);
 

@@ -229,6 +229,18 @@ def test_scheduling_choices_do_not_change_the_image(ta, gpu_ctx, monkeypatch):
     render({})  # leave the shared context in its default configuration
 
 
+def test_full_size_image_bit_exact(ta, oracle_py, gpu_ctx):
+    """BASELINE config 2 at its full size, every pixel: 1280x720, 64 spp in 4 passes (the 256-spp render of the benchmark
+    was checked the same way once: 0 of 921600 pixels differ, GPU 0.29 s, oracle 50 s -- DESIGN.md section 3)."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render(64, spp_step=16)
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 64, spp_step=16)
+    assert_bit_exact(got, ref, "config 2, 1280x720x64spp")
+
+
 def test_image_matches_reference_golden_within_tolerance(ta, gpu_ctx):
     """GPU image vs the compiled reference's golden PFM: identical Sobol sequences, but the supplemental
     stream is path-local and t,u,v use IEEE division -> agreement is statistical, not bitwise."""

@@ -241,6 +241,27 @@ def test_full_size_image_bit_exact(ta, oracle_py, gpu_ctx):
     assert_bit_exact(got, ref, "config 2, 1280x720x64spp")
 
 
+@pytest.mark.xfail(strict=False, reason="KNOWN GAP (DESIGN.md section 3): at full size 1 pixel (config 5) / 2 pixels (config 4) of 921600 "
+                                        "differ from the oracle; deterministic and independent of every scheduling knob")
+@pytest.mark.parametrize("config", ["c5", "c4"])
+def test_full_size_other_configs_bit_exact(ta, oracle_py, gpu_ctx, tmp_path, config):
+    """Configs 5 (medium inside rough glass, 32 spp) and 4 (10 M instanced triangles, 16 spp) at 1280x720, every pixel."""
+    import subprocess
+    import sys
+    if config == "c5":
+        path, spp = scene_path("materialtest/c5.json"), 32
+    else:
+        subprocess.run([sys.executable, scene_path("instances/make_c4.py"), str(tmp_path)], check=True, stdout=subprocess.DEVNULL)
+        path, spp = str(tmp_path / "c4.json"), 16
+    hs = ta.HostScene(path)
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render(spp, spp_step=16)
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, spp, spp_step=16)
+    assert_bit_exact(got, ref, f"{config} at full size")
+
+
 def test_image_matches_reference_golden_within_tolerance(ta, gpu_ctx):
     """GPU image vs the compiled reference's golden PFM: identical Sobol sequences, but the supplemental
     stream is path-local and t,u,v use IEEE division -> agreement is statistical, not bitwise."""

@@ -48,6 +48,23 @@ def host_cores():
     return n
 
 
+def self_launch(n_ranks, argv=None, python=None):
+    """Start `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child process on a free local
+    port and pass its output through.  Returns the child's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +83,11 @@ def main():
                          "the per-launch roofline of k_extend no longer describes the kernel alone: the default stays 1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not imported torch or touched the GPU;
+        # the ranks are CHILD processes (one per GPU, torch.distributed.run), rank 0's JSON line and the return code are relayed.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch  # device memory, streams and torch.distributed: plumbing only
     import numpy as np
     import tungsten_amd as ta
@@ -76,8 +98,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     n_dev = torch.cuda.device_count()

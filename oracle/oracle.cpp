@@ -7,10 +7,13 @@
 // build has no FMA contraction).
 #include "oracle.h"
 #include "../include/tgpu_math.h"
+#include "../include/tgpu_bounds.h"
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -29,6 +32,13 @@ constexpr float INV_PI = 1.0f/PI;
 constexpr float INV_TWO_PI = 0.5f*INV_PI;
 constexpr float INV_FOUR_PI = 0.25f*INV_PI;
 const float INF = std::numeric_limits<float>::infinity();
+// Path tracing of ONE sample to stderr (ORACLE_TRACE=1): every vertex with the bits of ray, hit, throughput, radiance and
+// sampler state, to be diffed against the GPU's slot dump (TGPU_TRACE_SLOTS=1); tests/tools/trace_path.py drives both.
+static const bool g_trace = std::getenv("ORACLE_TRACE") != nullptr;
+// ORACLE_BRUTE=1: triangle queries test EVERY triangle (no BVH pruning) -- the definition the BVH walk must reproduce:
+// lexicographic minimum of (t, triangle id) over all triangles whose test passes.  Minutes per image; for single-path diagnosis.
+static const bool g_brute = std::getenv("ORACLE_BRUTE") != nullptr;
+#define TRC(...) do { if (g_trace) std::fprintf(stderr, __VA_ARGS__); } while (0)
 
 // ---- Vec3f (math/Vec.hpp:127-193) ---------------------------------------------------
 struct V3 {
@@ -64,6 +74,8 @@ struct V3 {
     float luminance() const { return x*0.2126f + y*0.7152f + z*0.0722f; }
 };
 inline V3 operator*(float s, const V3 &v) { return V3(v.x*s, v.y*s, v.z*s); }
+inline uint32_t hx(float f) { return tgpu_float_to_bits(f); }
+#define HX3(v) hx((v).x), hx((v).y), hx((v).z)
 inline V3 vabs(const V3 &v) { return V3(std::abs(v.x), std::abs(v.y), std::abs(v.z)); }
 inline float fmin2(float a, float b) { return a < b ? a : b; } // Tungsten::min (MathUtil.hpp)
 inline float fmax2(float a, float b) { return a > b ? a : b; }
@@ -233,6 +245,7 @@ struct oracle_instances;
 struct oracle_ctx {
     tgpu_scene_desc sc;
     int rngMode, mathMode, rcpMode;
+    bool brute = g_brute; // oracle_set_brute_force: triangle queries test every triangle (the definition the BVH walks must meet)
     TriBvh sceneBvh;                 // scene finites: triangles [0, n_tris)
     std::vector<TriIsect> tris;      // all triangles incl. the instance masters' (n_tris + n_master_tris)
     std::vector<Pcg32> tilePcg;
@@ -348,6 +361,7 @@ void oracle_ctx::buildBvh(uint32_t firstTri, uint32_t n, TriBvh &out) const
     std::vector<BvhNode> &nodes = out.nodes;
     std::vector<uint32_t> &triOrder = out.triOrder;
     triOrder.resize(n);
+    const float triPad = tgpu_bvh_pad(&sc);
     // per-triangle boxes, indexed by id - firstTri
     std::vector<float> cminL(size_t(n)*3), cmaxL(size_t(n)*3), cenL(size_t(n)*3);
     for (uint32_t i = 0; i < n; ++i) {
@@ -358,6 +372,9 @@ void oracle_ctx::buildBvh(uint32_t firstTri, uint32_t n, TriBvh &out) const
             cminL[size_t(i)*3 + k] = std::min(p0[k], std::min(p1[k], p2[k]));
             cmaxL[size_t(i)*3 + k] = std::max(p0[k], std::max(p1[k], p2[k]));
             cenL[size_t(i)*3 + k] = 0.5f*(cminL[size_t(i)*3 + k] + cmaxL[size_t(i)*3 + k]);
+            // include/tgpu_bounds.h: the binary32 triangle test can pass for a ray that misses the exact box by a few ulps
+            cminL[size_t(i)*3 + k] -= triPad;
+            cmaxL[size_t(i)*3 + k] += triPad;
         }
     }
     // views addressed by global id
@@ -460,8 +477,9 @@ void oracle_ctx::buildBvh(uint32_t firstTri, uint32_t n, TriBvh &out) const
 
 static inline bool slab(const BvhNode &n, const V3 &o, const V3 &inv, float tnear, float tfar)
 {
-    // conservative slab test: a ray parallel to a slab only has to start inside it
-    float t0 = tnear, t1 = tfar;
+    // conservative slab test: a ray parallel to a slab only has to start inside it; the ray interval carries the relative
+    // slack of include/tgpu_bounds.h (a triangle's computed t may lie a few ulps outside its box's [entry, exit])
+    float t0 = tnear*(1.0f - TGPU_BVH_T_SLACK), t1 = tfar*(1.0f + TGPU_BVH_T_SLACK);
     for (int k = 0; k < 3; ++k) {
         if (std::isinf(inv[k])) {
             if (o[k] < n.lo[k] || o[k] > n.hi[k]) return false;
@@ -524,12 +542,13 @@ void oracle_ctx::intersectTris(const TriBvh &bvh, const Ray &ray, float &bestT, 
     while (sp) {
         const BvhNode &n = nodes[size_t(stack[--sp])];
         c.nodes++;
-        if (!slab(n, ray.pos, inv, ray.nearT, bestT)) continue;
+        if (!brute && !slab(n, ray.pos, inv, ray.nearT, bestT)) continue;
         if (n.left < 0) {
             for (uint32_t i = n.first; i < n.first + n.count; ++i) {
                 uint32_t id = triOrder[i];
                 c.tris++;
                 TriHit h = triTest(tris[id], ray, tfar0, rcpMode);
+                if (h.valid) TRC("    valid tri=%u t=%08x u=%08x v=%08x\n", id, hx(h.t), hx(h.u), hx(h.v));
                 if (h.valid && (h.t < bestT || (h.t == bestT && id < bestPrim))) {
                     bestT = h.t; bestU = h.u; bestV = h.v; bestPrim = id;
                 }
@@ -554,7 +573,7 @@ bool oracle_ctx::occludedTris(const TriBvh &bvh, const Ray &ray, Counters &c) co
     while (sp) {
         const BvhNode &n = nodes[size_t(stack[--sp])];
         c.nodes++;
-        if (!slab(n, ray.pos, inv, ray.nearT, ray.farT)) continue;
+        if (!brute && !slab(n, ray.pos, inv, ray.nearT, ray.farT)) continue;
         if (n.left < 0) {
             for (uint32_t i = n.first; i < n.first + n.count; ++i) {
                 c.tris++;
@@ -1130,6 +1149,7 @@ bool oracle_ctx::masterIntersect(uint32_t setIndex, uint32_t master, Ray &ray, T
     uint32_t prim = 0xFFFFFFFFu;
     intersectTris(s.masterBvh[master], ray, t, u, v, prim, c);
     if (prim == 0xFFFFFFFFu) return false;
+    TRC("  master %u: tri=%u t=%08x u=%08x v=%08x (local nearT=%08x)\n", master, prim, hx(t), hx(u), hx(v), hx(ray.nearT));
     ray.farT = t;
     data.kind = PRIM_TRI;
     data.index = prim;
@@ -2390,10 +2410,12 @@ V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int medium, int bo
     Temp data;
     Info info;
     V3 e = attenuatedEmission(l, medium, sample.dist, data, info, bounce, true, ray, c);
+    TRC("  neeL d=%08x %08x %08x dist=%08x pdf=%08x f=%08x %08x %08x e=%08x %08x %08x farT=%08x\n", HX3(sample.d), hx(sample.dist), hx(sample.pdf), HX3(f), HX3(e), hx(ray.farT));
     if (e == 0.0f) return V3(0.0f);
     V3 lightF = f*e/sample.pdf;
     float bp = bsdfPdf(event.info->bsdf, event);
     lightF *= (sample.pdf*sample.pdf)/(sample.pdf*sample.pdf + bp*bp); // SampleWarp::powerHeuristic (SampleWarp.hpp:189-192)
+    TRC("  neeL bp=%08x L=%08x %08x %08x\n", hx(bp), HX3(lightF));
     return lightF;
 }
 
@@ -2413,10 +2435,12 @@ V3 oracle_ctx::bsdfSampleNee(const tgpu_light &l, Event &event, int medium, int 
     Temp data;
     Info info;
     V3 e = attenuatedEmission(l, medium, -1.0f, data, info, bounce, true, ray, c);
+    TRC("  neeB wo=%08x %08x %08x w=%08x %08x %08x pdf=%08x e=%08x %08x %08x farT=%08x\n", HX3(wo), HX3(event.weight), hx(event.pdf), HX3(e), hx(ray.farT));
     if (e == 0.0f) return V3(0.0f);
     V3 bsdfF = e*event.weight;
     float lp = lightDirectPdf(l, data, info, event.info->p);
     bsdfF *= (event.pdf*event.pdf)/(event.pdf*event.pdf + lp*lp);
+    TRC("  neeB lp=%08x B=%08x %08x %08x\n", hx(lp), HX3(bsdfF));
     return bsdfF;
 }
 
@@ -2710,6 +2734,7 @@ bool oracle_ctx::mediumSampleDistance(int medium, Sampler &sampler, const Ray &r
         }
         sample.weight /= sample.pdf;
         state.advance();
+        TRC("  med comp=%d t=%08x exited=%d w=%08x %08x %08x pdf=%08x\n", component, hx(sample.t), int(sample.exited), HX3(sample.weight), hx(sample.pdf));
     }
     sample.p = ray.pos + sample.t*ray.dir;
     return true;
@@ -2778,6 +2803,7 @@ V3 oracle_ctx::volumeEstimateDirect(Sampler &sampler, const MediumSampleO &ms, i
             Temp data;
             Info info;
             V3 e = attenuatedEmission(*light, medium, ls.dist, data, info, bounce, false, ray, c);
+            TRC("  volL d=%08x %08x %08x dist=%08x pdf=%08x f=%08x e=%08x %08x %08x farT=%08x\n", HX3(ls.d), hx(ls.dist), hx(ls.pdf), hx(f.x), HX3(e), hx(ray.farT));
             if (!(e == 0.0f)) {
                 lightF = f*e/ls.pdf;
                 float pp = phaseEval(sc.media[medium], parent.dir, ls.d); // phase->pdf
@@ -2793,6 +2819,7 @@ V3 oracle_ctx::volumeEstimateDirect(Sampler &sampler, const MediumSampleO &ms, i
         Temp data;
         Info info;
         V3 e = attenuatedEmission(*light, medium, -1.0f, data, info, bounce, false, ray, c);
+        TRC("  volB w=%08x %08x %08x pp=%08x e=%08x %08x %08x farT=%08x\n", HX3(w), hx(pp), HX3(e), hx(ray.farT));
         if (!(e == 0.0f)) {
             V3 phaseF = e*V3(1.0f); // phaseSample.weight
             float lp = lightDirectPdf(*light, data, info, ms.p);
@@ -2876,7 +2903,11 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
     c.extend++;
     bool didHit = intersect(ray, data, info, c);
     bool wasSpecular = true;
+    TRC("ORC start px=%u py=%u idx=%u scr=%08x O=%08x %08x %08x D=%08x %08x %08x\n", px, py, sampler.index, sampler.scramble, HX3(ray.pos), HX3(ray.dir));
     while ((didHit || medium >= 0) && bounce < maxBounces) {
+        TRC("ORC v%d hit=%d t=%08x u=%08x v=%08x kind=%d index=%u inst=%d med=%d tp=%08x %08x %08x em=%08x %08x %08x dim=%u pcg=%016llx\n", bounce, int(didHit), hx(ray.farT),
+            hx(data.u), hx(data.v), didHit ? info.kind : 0, didHit ? info.index : 0u, didHit ? data.inst : -1, medium, HX3(throughput), HX3(emission), sampler.dimension,
+            (unsigned long long)sampler.supplemental->state);
         bool hitSurface = true;
         if (medium >= 0) {
             if (!mediumSampleDistance(medium, sampler, ray, state, mediumSample)) return emission;
@@ -2905,6 +2936,8 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
         }
         if (std::isnan(ray.dir.sum() + ray.pos.sum())) return V3(0.0f);
         if (std::isnan(throughput.sum() + emission.sum())) return V3(0.0f);
+        TRC("ORC   -> O=%08x %08x %08x D=%08x %08x %08x tp=%08x %08x %08x em=%08x %08x %08x dim=%u pcg=%016llx\n", HX3(ray.pos), HX3(ray.dir), HX3(throughput), HX3(emission),
+            sampler.dimension, (unsigned long long)sampler.supplemental->state);
 
         bounce++;
         if (bounce < maxBounces) {
@@ -2926,12 +2959,24 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
         }
     }
     if (std::isnan(throughput.sum() + emission.sum())) return V3(0.0f);
+    TRC("ORC end bounce=%d em=%08x %08x %08x\n", bounce, HX3(emission));
     return emission;
 }
 
 // ========================================================================================
 // C API
 // ========================================================================================
+// ray batches are split over the host's threads (the brute-force mode is O(rays x triangles))
+template <class F>
+static void parallelRanges(uint32_t n, F body)
+{
+    uint32_t nt = std::max(1u, std::min(std::thread::hardware_concurrency(), (n + 255u)/256u));
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nt; ++t) th.emplace_back([=] { body(uint32_t(uint64_t(n)*t/nt), uint32_t(uint64_t(n)*(t + 1)/nt)); });
+    body(0u, uint32_t(uint64_t(n)/nt));
+    for (auto &t : th) t.join();
+}
+
 extern "C" {
 
 oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_mode, int rcp_mode)
@@ -2950,6 +2995,7 @@ oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_m
 }
 
 void oracle_destroy(oracle_ctx *ctx) { delete ctx; }
+void oracle_set_brute_force(oracle_ctx *ctx, int on) { if (ctx) ctx->brute = on != 0; }
 
 static void addSample(float *mean, uint32_t *count, const V3 &c) // cameras/OutputBuffer.hpp:104-132 (single buffer)
 {
@@ -3065,8 +3111,9 @@ int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t 
 
 int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *hits)
 {
+    parallelRanges(n, [=](uint32_t begin, uint32_t end) {
     oracle_ctx::Counters c;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = begin; i < end; ++i) {
         const float *r = rays + size_t(i)*8;
         Ray ray{V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7]};
         Temp data;
@@ -3088,13 +3135,15 @@ int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *
         std::memcpy(&h[3], &prim, 4);
     }
     flushCounters(ctx, c);
+    });
     return 0;
 }
 
 int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_t *occluded)
 {
+    parallelRanges(n, [=](uint32_t begin, uint32_t end) {
     oracle_ctx::Counters c;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = begin; i < end; ++i) {
         const float *r = rays + size_t(i)*8;
         Ray ray{V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7]};
         Temp data;
@@ -3102,6 +3151,7 @@ int oracle_trace_occluded(oracle_ctx *ctx, const float *rays, uint32_t n, uint8_
         occluded[i] = ctx->intersect(ray, data, info, c) ? 1 : 0;
     }
     flushCounters(ctx, c);
+    });
     return 0;
 }
 

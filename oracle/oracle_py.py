@@ -44,6 +44,7 @@ def lib():
         L.oracle_pcg_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
         L.oracle_camera_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.oracle_tile_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_set_brute_force.argtypes = [C.c_void_p, C.c_int]
         L.oracle_get_stats.argtypes = [C.c_void_p, C.POINTER(OracleStats)]
         L.oracle_reset_stats.argtypes = [C.c_void_p]
         _lib = L
@@ -118,6 +119,10 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle_render_shard_adaptive needs rng mode 1")
         return rgb, cnt, records
+
+    def set_brute_force(self, on=True):
+        """Triangle queries test every triangle (no BVH): the definition both BVH walks must reproduce."""
+        lib().oracle_set_brute_force(self._h, int(on))
 
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

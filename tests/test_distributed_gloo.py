@@ -115,3 +115,22 @@ def test_shard_sizes_are_balanced(ta):
         sizes = shard_sizes(1280, 720, world)
         assert sum(sizes) == 1280*720
         assert max(sizes) - min(sizes) <= 256  # at most one 16x16 tile
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_command_line():
+    """`python bench.py --gpus 2` (no WORLD_SIZE): the parent starts torch.distributed.run itself, before importing torch, and
+    relays the children's return code.  On this GPU-less box both ranks must get as far as bench.py's own "needs a GPU"
+    exit -- i.e. they were started with RANK / WORLD_SIZE set -- and the launcher must report the failure."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TGPU_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():  # a GPU box: the two gloo ranks share the card and the line must come out
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        import json
+        assert p.returncode == 0 and json.loads(line)["n_gpus"] == 2
+    else:
+        assert p.returncode != 0
+        assert (p.stdout + p.stderr).count("bench.py needs a GPU") >= 2

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, scene_path
+from conftest import GOLDEN, edge_and_vertex_rays, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -145,6 +145,38 @@ def test_ray_level_parity(ta, oracle_py, gpu_ctx, scene):
     assert np.array_equal(gpu_ctx.trace_occluded(rays), orc.trace_occluded(rays))
 
 
+def test_edge_and_vertex_rays_match_the_definition(ta, oracle_py, gpu_ctx):
+    """The nearest hit is the lexicographic minimum of (t, triangle id) over ALL triangles whose test passes
+    (include/tgpu_bounds.h); the oracle in brute-force mode evaluates exactly that.  Rays aimed at shared edges and vertices
+    are where a walk that prunes with unpadded boxes loses a triangle (the three round-1 full-size mismatches)."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(32, 32))
+    gpu_ctx.upload(hs, ta.Shard(32, 32))
+    orc = oracle_py.Oracle(hs, **oracle_py.GPU)
+    orc.set_brute_force(True)
+    rays = edge_and_vertex_rays(hs, 24000, 5)
+    g, o = gpu_ctx.trace_closest(rays), orc.trace_closest(rays)
+    bad = (g.view(np.uint32) != o.view(np.uint32)).any(axis=1)
+    assert not bad.any(), f"{int(bad.sum())} of {len(rays)} edge/vertex rays differ from the brute-force definition"
+    assert (o[:, 3].view(np.uint32) != 0xFFFFFFFF).mean() > 0.9
+    # any-hit with the far end just before / just behind the targeted edge
+    rays[:, 7] = o[:, 0]*np.where(np.arange(len(rays)) % 2 == 0, np.float32(1.0 - 1e-6), np.float32(1.0 + 1e-6))
+    rays[~np.isfinite(rays[:, 7]), 7] = 1.0
+    assert np.array_equal(gpu_ctx.trace_occluded(rays), orc.trace_occluded(rays))
+    # the mesh masters of an "instances" scene: local rays, their own BVHs
+    hs = ta.HostScene(scene_path("instances/inst_mesh.json"), resolution=(32, 32))
+    gpu_ctx.upload(hs, ta.Shard(32, 32))
+    orc = oracle_py.Oracle(hs, **oracle_py.GPU)
+    orc.set_brute_force(True)
+    rng = np.random.default_rng(9)
+    n = 20000
+    org = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    org[:, 1] = np.abs(org[:, 1]) + 0.2
+    d = rng.uniform(-2, 2, (n, 3)).astype(np.float32) - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, np.full((n, 1), 1e-4, np.float32), d.astype(np.float32), np.full((n, 1), np.inf, np.float32)], axis=1)
+    assert np.array_equal(gpu_ctx.trace_closest(rays).view(np.uint32), orc.trace_closest(rays).view(np.uint32))
+
+
 def test_portable_math_is_bit_identical_on_device(ta, oracle_py, gpu_ctx):
     L = oracle_py.lib()
     L.oracle_eval_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -241,8 +273,6 @@ def test_full_size_image_bit_exact(ta, oracle_py, gpu_ctx):
     assert_bit_exact(got, ref, "config 2, 1280x720x64spp")
 
 
-@pytest.mark.xfail(strict=False, reason="KNOWN GAP (DESIGN.md section 3): at full size 1 pixel (config 5) / 2 pixels (config 4) of 921600 "
-                                        "differ from the oracle; deterministic and independent of every scheduling knob")
 @pytest.mark.parametrize("config", ["c5", "c4"])
 def test_full_size_other_configs_bit_exact(ta, oracle_py, gpu_ctx, tmp_path, config):
     """Configs 5 (medium inside rough glass, 32 spp) and 4 (10 M instanced triangles, 16 spp) at 1280x720, every pixel."""

@@ -54,7 +54,9 @@ struct Box {
 
 class Builder {
 public:
-    Builder(const float *triPos, uint32_t nTris) : _pos(triPos), _n(nTris) {}
+    // triPad: every triangle box grows by this much in all directions (include/tgpu_bounds.h: the walk must never prune a
+    // triangle whose binary32 test passes)
+    Builder(const float *triPos, uint32_t nTris, float triPad) : _pos(triPos), _n(nTris), _triPad(triPad) {}
 
     Bvh build()
     {
@@ -70,6 +72,8 @@ public:
                 b.lo[k] = std::min(p[k], std::min(p[3 + k], p[6 + k]));
                 b.hi[k] = std::max(p[k], std::max(p[3 + k], p[6 + k]));
                 _cent[size_t(i)*3 + k] = 0.5f*(b.lo[k] + b.hi[k]);
+                b.lo[k] -= _triPad;
+                b.hi[k] += _triPad;
             }
             _boxes[i] = b;
             _order[i] = i;
@@ -217,6 +221,7 @@ private:
 
     const float *_pos;
     uint32_t _n;
+    float _triPad;
     Bvh *_out = nullptr;
     std::vector<Box> _boxes;
     std::vector<float> _cent;

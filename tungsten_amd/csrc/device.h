@@ -10,6 +10,7 @@
 
 #include "../../include/tungsten_amd.h"
 #include "../../include/tgpu_math.h"
+#include "../../include/tgpu_bounds.h"
 
 #define TG_DEV __device__ __forceinline__
 

@@ -499,6 +499,9 @@ TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounte
         float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
         if (!leaf) {
             if (COUNT) tc.nodes++;
+            // the interval the boxes are clipped to, with the relative slack of include/tgpu_bounds.h: the computed t of a
+            // triangle may lie a few ulps outside its box's [entry, exit]
+            const float tLo = tnear*(1.0f - TGPU_BVH_T_SLACK), tHi = bestT*(1.0f + TGPU_BVH_T_SLACK);
             const uint32_t eb = __float_as_uint(q0.w);
             // t = q*(scale*inv) + (origin - O)*inv, one fma per plane
             const float ax = __uint_as_float((eb & 0xFFu) << 23)*inv.x, ay = __uint_as_float(((eb >> 8) & 0xFFu) << 23)*inv.y,
@@ -514,12 +517,12 @@ TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounte
                 float tn = TGPU_FMA(float((Nx >> sh) & 0xFFu), ax, bx);
                 tn = fmaxf(tn, TGPU_FMA(float((Ny >> sh) & 0xFFu), ay, by));
                 tn = fmaxf(tn, TGPU_FMA(float((Nz >> sh) & 0xFFu), az, bz));
-                tn = fmaxf(tn, tnear);
+                tn = fmaxf(tn, tLo);
                 float tf = TGPU_FMA(float((Fx >> sh) & 0xFFu), ax, bx);
                 tf = fminf(tf, TGPU_FMA(float((Fy >> sh) & 0xFFu), ay, by));
                 tf = fminf(tf, TGPU_FMA(float((Fz >> sh) & 0xFFu), az, bz));
-                tf = fminf(tf, bestT);
-                // tn >= tnear > 0: its bit pattern orders like the float; the low 2 bits carry the slot
+                tf = fminf(tf, tHi);
+                // tn >= tLo >= 0: its bit pattern orders like the float; the low 2 bits carry the slot
                 key[c] = tn <= tf ? ((__float_as_uint(tn) & ~3u) | uint32_t(c)) : 0xFFFFFFFFu;
             }
             // sort the four keys ascending (5-comparator network)

@@ -93,6 +93,9 @@ struct tgpu_ctx {
     size_t ldsBytes = 0;
 
     uint32_t profFlags = 0;
+    bool traceSlots = false;            // TGPU_TRACE_SLOTS: dump the live slots after every iteration (debugging aid, small pools only)
+    std::vector<uint32_t> tracePrev;
+    uint64_t traceIter = 0;
     tgpu_stats stats{};
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::vector<tgpu_quad> hostQuads; // for host-side checks only
@@ -391,8 +394,9 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     std::vector<tgpu_bvh::Float4> allNodes, allTris;
     int maxDepth4 = 0;
     // appends one BVH over triangles [first, first + count) and returns its root child reference
+    const float triPad = tgpu_bvh_pad(s); // include/tgpu_bounds.h
     auto appendBvh = [&](uint32_t first, uint32_t count, const char *what) -> uint32_t {
-        tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count);
+        tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count, triPad);
         tgpu_bvh::Bvh bvh = builder.build();
         tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run(); // the quantised BVH4 the kernels traverse (bvh_build.h)
         const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/4);
@@ -479,6 +483,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
     if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
+    ctx->traceSlots = getenv("TGPU_TRACE_SLOTS") != nullptr;
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
     if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
     float4 *dNodes, *dTris;
@@ -910,6 +915,29 @@ static int driveIteration(tgpu_ctx *ctx)
         return TGPU_ERR_HIP;
     }
     const uint32_t *hc = ctx->hostCounters;
+    // TGPU_TRACE_SLOTS=1 (pools of <= 4096 slots, i.e. the one-pixel shards of tests/tools/trace_path.py): both records of every
+    // live slot after each iteration, as hex words, to be diffed against the oracle's ORACLE_TRACE output.  Host side only:
+    // the kernels are the production binaries.
+    if (ctx->traceSlots && ctx->capacity <= 4096) {
+        std::vector<uint32_t> rec(size_t(ctx->capacity)*32), sh(size_t(ctx->capacity)*32);
+        (void)hipMemcpy(rec.data(), st.rayO.base, rec.size()*4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sh.data(), st.shA.base, sh.size()*4, hipMemcpyDeviceToHost);
+        if (ctx->tracePrev.size() != ctx->capacity) ctx->tracePrev.assign(size_t(ctx->capacity), uint32_t(END_DEAD));
+        for (uint64_t s = 0; s < ctx->capacity; ++s) {
+            const uint32_t *r = &rec[s*32], *h = &sh[s*32];
+            const uint32_t end = (r[11] >> 24) & 0xFu;
+            if (end == uint32_t(END_DEAD) && ctx->tracePrev[s] == uint32_t(END_DEAD)) continue;
+            ctx->tracePrev[s] = end;
+            fprintf(stderr, "GPU it=%llu slot=%llu%s hit t=%08x u=%08x v=%08x prim=%08x inst=%08x | O=%08x %08x %08x tn=%08x D=%08x %08x %08x | tp=%08x %08x %08x bounce=%u spec=%u end=%u "
+                            "| em=%08x %08x %08x | dim=%u pcg=%08x%08x idx=%u med=%08x shFlag=%u\n",
+                    (unsigned long long)ctx->traceIter, (unsigned long long)s, tail ? " (tail)" : "", r[12], r[13], r[14], r[15], r[25], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[8], r[9], r[10],
+                    r[11] & 0xFFFFu, (r[11] >> 16) & 1u, end, r[16], r[17], r[18], r[20], r[22], r[21], r[23], r[24], r[26]);
+            if (r[26])
+                fprintf(stderr, "    nee dL=%08x %08x %08x tfarL=%08x | dB=%08x %08x %08x tfarB=%08x | L=%08x %08x %08x pick=%08x | B=%08x %08x %08x cap=%08x | tpV=%08x %08x %08x bits=%08x | F=%08x %08x %08x %08x\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
+        }
+        ctx->traceIter++;
+    }
     if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] iter in=%u out=[%u %u %u %u %u] claims=%u free=%u base=%llu limit=%llu active=%zu\n", nCur,
                                       hc[CNT(CNT_LIST0 + out*TG_LISTS)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 1)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 2)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 3)],
                                       hc[CNT(CNT_LIST0 + out*TG_LISTS + 4)], hc[CNT(CNT_REGEN)], hc[CNT(CNT_FREE)], ctx->sampleBase, limit, ctx->active.size());

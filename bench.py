@@ -14,11 +14,13 @@ here: total work is fixed -> "scaling": "strong"); each rank renders its shard w
 collective and one RCCL gather of the framebuffers to rank 0 closes the timed region.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = k_extend_q (closest-hit BVH traversal, four rays per lane), HBM bound.  achieved =
-               algorithmic bytes per launch / average launch duration, both measured live after
-               the timed region: bytes from the kernel's own visit counters (64 B per BVH node
-               fetch, 48 B per triangle fetch, 56 B of queue traffic per ray), duration from HIP
-               events recorded on the stream the kernel runs on.
+  roofline     the traversal kernel with the larger share of the step (k_extend_q: closest hit, four rays per lane; k_shadow_q:
+               any hit, eight rays per lane), HBM bound.  achieved = algorithmic bytes per launch / average launch
+               duration, both measured live after the timed region: bytes from the kernel's own visit counters (64 B per
+               BVH node fetch, 48 B per triangle fetch, plus the queue traffic per ray / vertex), duration from HIP events
+               recorded on the stream the kernel runs on.  `traffic` is NOT measured in this run: it is the HBM-side byte
+               count of a committed rocprofv3 --pmc pass of the same command (`traffic_source` names it).
+  roofline_kernels   the same object for both traversal kernels.
   cpu_baseline the CPU oracle (oracle/, a port -- test infrastructure) timed on this box's host
                cores on a bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -213,30 +215,61 @@ def main():
             return tot
         c = phase(1, done)                       # visit counters (k_extend_q<true>)
         t = phase(2, done + spp_step*rsteps)     # HIP-event timing of the production kernels, each on its own stream
-        launches = max(1, c["extend_launches"])
-        bytes_per_launch = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES +
-                            c["extend_rays"]*RAY_QUEUE_BYTES)/launches
-        avg_ms = t["extend_ms"]/max(1, t["extend_launches"])
-        achieved = bytes_per_launch/(avg_ms*1e-3)/1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(REPO, "profiles", "pmc_extend.json")
-        if os.path.exists(pmc_path) and not args.scene:  # the committed PMC pass was taken on configs[1]
+        # committed PMC pass of the same command on configs[1] (profiles/collect.sh + summarize.py): HBM-side bytes per launch.
+        # NOT measured in this run -- the source is named next to the number; null for other scenes / when the file is absent.
+        pmc, pmc_src = {}, None
+        pmc_path = os.path.join(REPO, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path) and not args.scene:
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                pmc_src = "committed profile " + str(pmc.get("_source", "profiles/pmc_latest.json")) + " (rocprofv3 --pmc, separate run)"
             except Exception:
-                traffic = None
-        result["roofline"] = {
-            "kernel": "k_extend_q", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "avg_launch_ms": round(avg_ms, 5),
+                pmc = {}
+
+        def roof(kernel, bytes_per_launch, ms, n_launch, extra):
+            avg_ms = ms/max(1, n_launch)
+            achieved = bytes_per_launch/(avg_ms*1e-3)/1e9 if avg_ms > 0 else 0.0
+            traffic = None
+            for name, v in pmc.items():
+                if isinstance(v, dict) and name.startswith(kernel):
+                    traffic = v.get("hbm_bytes_per_launch")
+            d = {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(achieved/HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "avg_launch_ms": round(avg_ms, 5)}
+            if traffic:
+                d["frac_of_peak_by_traffic"] = round(traffic/(avg_ms*1e-3)/1e9/HBM_PEAK_GBS, 4)
+            d.update(extra)
+            return d
+
+        launches = max(1, c["extend_launches"])
+        ext_bytes = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES + c["extend_rays"]*RAY_QUEUE_BYTES)/launches
+        ext = roof("k_extend_q", ext_bytes, t["extend_ms"], t["extend_launches"],
+                   {"per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
+                                "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)}})
+        # shadow kernel.  Queue form (k_shadow_q): per ray 36 B in (direction + far end, origin + near end, end cap), per vertex a
+        # 4-byte list entry in and a 4-byte visibility word out.  k_shadow (general scenes): per vertex the 112-byte NEE record
+        # and a 32-byte radiance read-modify-write.
+        sl = max(1, c["shadow_launches"])
+        queue_form = c.get("shadow_vertices", 0) > 0
+        if queue_form:
+            sh_queue = c["shadow_rays"]*36 + c["shadow_vertices"]*8
+        else:
+            sh_queue = (c["shadow_rays"]/2.0)*(112 + 32)
+        sh_bytes = (c["shadow_node_visits"]*NODE_BYTES + c["shadow_tri_tests"]*TRI_BYTES + sh_queue)/sl
+        sha = roof("k_shadow_q" if queue_form else "k_shadow", sh_bytes, t["shadow_ms"], t["shadow_launches"],
+                   {"per_ray": {"node_visits": round(c["shadow_node_visits"]/max(1, c["shadow_rays"]), 3),
+                                "tri_tests": round(c["shadow_tri_tests"]/max(1, c["shadow_rays"]), 3)}})
+        dominant = ext if t["extend_ms"] >= t["shadow_ms"] else sha
+        result["roofline"] = dict(dominant)
+        result["roofline"].update({
             "launches_per_step": round(launches/rsteps, 2), "pools": K,
-            "per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
-                        "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)},
             "per_sample": {"extend_rays": round(c["extend_rays"]/max(1, c["samples"]), 3),
                            "shadow_rays": round(c["shadow_rays"]/max(1, c["samples"]), 3),
                            "surface_events": round(c["surface_events"]/max(1, c["samples"]), 3)},
             "kernel_ms_per_step": {k: round(t[k]/rsteps, 3) for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms")},
-        }
+            "l2_peak_gbs": 34500.0, "frac_of_l2_peak": round(dominant["achieved"]/34500.0, 4),
+        })
+        result["roofline_kernels"] = [ext, sha]
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) ----------------------
     if not args.no_cpu_baseline and rank == 0 and world == 1:

@@ -298,6 +298,7 @@ typedef struct tgpu_stats {
     double   extend_ms, shadow_ms, shade_ms, other_ms; /* HIP-event kernel time, when timing on */
     uint64_t extend_launches, shadow_launches;
     uint64_t tail_launches;    /* fused tail-kernel launches                  */
+    uint64_t shadow_vertices;  /* path vertices whose NEE rays went through the shadow kernel's queue form */
 } tgpu_stats;
 
 typedef struct tgpu_ctx tgpu_ctx;

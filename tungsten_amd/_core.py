@@ -57,7 +57,7 @@ def core_lib():
     runtime (torch bundles libamdhip64.so.7; the loader then reuses it for our NEEDED entry)."""
     global _lib
     if _lib is None:
-        _lib = load_core(_CORE_LIB_PATH)
+        _lib = load_core(os.environ.get("TGPU_CORE_LIB", _CORE_LIB_PATH))  # TGPU_CORE_LIB: another build of the same core (A/B runs)
     return _lib
 
 

@@ -59,13 +59,20 @@ TG_DEV uint32_t packFlags(int bounce, bool wasSpecular, int end) { return uint32
 TG_DEV int flagsBounce(uint32_t f) { return int(f & 0xFFFFu); }
 TG_DEV bool flagsSpecular(uint32_t f) { return (f >> 16) & 1u; }
 TG_DEV int flagsEnd(uint32_t f) { return int((f >> 24) & 0xFu); }
+// state word (second half of the path record): bit 0 = NEE rays queued for the current vertex, [7:4] = end state (copy of tp.w's)
+TG_DEV uint32_t packState(bool nee, int end) { return (nee ? 1u : 0u) | (uint32_t(end) << 4); }
+TG_DEV bool stateNee(uint32_t s) { return (s & 1u) != 0; }
+TG_DEV int stateEnd(uint32_t s) { return int((s >> 4) & 0xFu); }
 
 // Path state lives in two 128-byte records per slot (array of structures): the lists hand the kernels slot numbers in
 // an order that decorrelates from memory order after a few bounces, so every field access of a lane is a random access.
 // With one array per field (16-byte elements) each of them costs a 64-byte HBM sector; with records the fields a
 // kernel needs share one or two sectors.  Strided<> keeps the `st.field[slot]` spelling.
-//   path record   : [0] rayO [1] rayD [2] tp [3] hit | [4] em [5] samp [6] med, hitInst, shFlag, sampleRef [7] -
-//   shadow record : [0] shA  [1] shB  [2] shC [3] shD | [4] shE [5] shF [6] shO [7] -
+//   path record   : [0] rayO [1] rayD [2] tp [3] hit | [4] em [5] samp [6] med, hitInst, state, sampleRef [7] tpSum
+//   shadow record : [0] shA  [1] shB  [2] shO [3] shX | [4] shC [5] shD [6] shE [7] shF
+// The halves are 64-byte sectors and are laid out by consumer: extend reads only the path record's first half, the shadow
+// traversal only the shadow record's first half (rays, origin, end cap), and retire + NEE resolve only the two second halves
+// (state, radiance, sample reference | contributions, visibility bits) -- a slot costs each kernel one or two sectors.
 template <class T, int STRIDE>
 struct Strided {
     T *base;
@@ -92,16 +99,20 @@ struct DState {
     // NEE records of the path's current vertex (origin = rayO.xyz, tnear = epsilon)
     RecF4 shA;      // light-sample dir.xyz, tfar (< 0: no ray)
     RecF4 shB;      // bsdf-sample dir.xyz, tfar (< 0: no ray)
+    RecF4 shO;      // origin of the NEE rays.xyz (info.p), tnear -- a copy, so that the shadow kernel leaves the path record alone
+    RecF4 shX;      // bits(end cap prim), bits(1 when the vertex has a second ray, in shB), -, -
     RecF4 shC;      // L.xyz (unoccluded light-sample term), light-pick weight
-    RecF4 shD;      // B.xyz (unoccluded bsdf-sample term), bits(end cap prim | postAdd flag << 31 hmm)
+    RecF4 shD;      // B.xyz (unoccluded bsdf-sample term), bits(visibility of the NEE rays: bit 0 the ray in shA, bit 1 the ray in shB; written by k_shadow_q)
     RecF4 shE;      // throughput at the vertex.xyz, bits(has post-add)
     RecF4 shF;      // emitter term to add after the NEE term.xyz
-    RecF4 shO;      // origin of the NEE rays.xyz (info.p), tnear -- a copy, so that the shadow kernel leaves the path record's first half alone
     RecU1 sampleRef;     // per slot: index into `results` of the sample the slot is tracing
     float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w unused)
     uint32_t *lists[2][TG_LISTS];
     uint32_t *freeQ;     // idle slots that were dropped from the lists (no sample admitted / end of render)
-    RecU1 shFlag;        // per slot: 1 when the current vertex queued NEE rays (shA..shF valid)
+    RecU1 state;         // per slot: bit 0 = NEE terms of the slot's last vertex still have to be folded into its radiance (shC..shF valid),
+                         // bits [7:4] = a copy of the end state of tp.w.  (A compact 4-byte array instead was slower: a random access costs a
+                         // line whatever its size, and the kernels that need the word read this sector anyway.)
+    Strided<float, 32> tpSum; // per slot: throughput.sum() of a path that ended END_CHECKED (traceSample's last NaN test, done at retire)
     uint32_t *counters;
     uint32_t nPixels;
     uint32_t resultSlice; // samples per ring slot = nPixels * resultSpp
@@ -214,6 +225,26 @@ TG_DEV uint32_t listTotal(const ListCounts &lc, int first)
     return n;
 }
 
+// The NEE terms of a vertex whose shadow rays went through k_shadow_q are folded into the path's radiance by whoever touches
+// the path next (the next vertex's shade / volume step, the environment lookup of an escaped path, the retire step of an
+// ended one, the tail kernel) -- all of them read these records anyway -- in the reference's order
+//   emission += ((0 + L*vis_L) + B*vis_B)*w*throughput   (TraceBase.cpp:383-400,483-494,537-538), then the emitter term (:540-543)
+TG_DEV V3 resolveNeeTerms(const DState &st, uint32_t slot, V3 em)
+{
+    // (plain loads: the non-temporal form of this triple trips an 'even aligned vector registers' backend error in the general shade kernels)
+    const float4 c = st.shC[slot], d = st.shD[slot], e = st.shE[slot];
+    const uint32_t vis = __float_as_uint(d.w);
+    // an occluded term enters as +0: x + 0 == x bit for bit, so this is ((0 + L*vis_L) + B*vis_B) without branches
+    const V3 lTerm = (vis & 1u) ? xyz(c) : V3(0.0f), bTerm = (vis & 2u) ? xyz(d) : V3(0.0f);
+    V3 result = (V3(0.0f) + lTerm) + bTerm;
+    em += (result*c.w)*xyz(e);
+    if (__float_as_uint(e.w) & 1u) em += xyz(st.shF[slot]);
+    return em;
+}
+// The general shade kernels call it out of line: inlined into k_shade<RoughConductor, general> it trips a register-allocation error of
+// this compiler ("Subtarget requires even aligned vector registers", ROCm 7.2 / gfx950); one call per vertex is not measurable.
+__device__ __noinline__ V3 resolveNeeTermsCall(const DState &st, uint32_t slot, V3 em) { return resolveNeeTerms(st, slot, em); }
+
 // =================================================================================================
 // K1 generate
 // =================================================================================================
@@ -295,6 +326,7 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
     st.em[slot] = mk4u(V3(0.0f), smp.scramble);
     st.samp[slot] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
     st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
+    st.state[slot] = packState(false, END_ALIVE);
     if (sc.nMedia) st.med[slot] = uint32_t(sc.cam.medium + 1) | (1u << 8); // cam().medium(), MediumState::reset()
 }
 
@@ -305,55 +337,98 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
 //  - ended and idle slots then claim the next sample in global order; when one is admitted (< limit) the
 //    slot starts it and simply stays in its list (the next extend traces its camera ray), otherwise the
 //    slot is marked idle and the next extend drops it onto the free list.
-// Claims are aggregated per 1024-thread block (one global atomic per 1024 entries), job counters per block
+// Claims are aggregated per block round (256 threads x TG_RETIRE_K entries: one global atomic per 1024 entries), job counters per block
 // in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
+TG_DEV int missPathEx(const DScene &sc, const DState &st, uint32_t path, V3 &emOut, float &tpSumOut);
 
+// Per shaded slot this kernel reads the 4-byte state word (compact array); only ended paths cost record sectors (radiance, pending
+// NEE terms, sample reference), escaped ones the whole path record (environment lookup).
 #ifdef TG_TU_MAIN
-static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
+#ifndef TG_RETIRE_K
+#define TG_RETIRE_K 1 /* list entries per thread and block round (1 / 2 / 4 with 1024 / 512 / 256-thread blocks measured the same within noise) */
+#endif
+#ifndef TG_RETIRE_BLOCK
+#define TG_RETIRE_BLOCK 256
+#endif
+static __global__ void __launch_bounds__(TG_RETIRE_BLOCK) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
                                                             unsigned long long limit)
 {
-    __shared__ uint32_t sWave[16];
+    __shared__ uint32_t sWave[TG_RETIRE_BLOCK/64];
     __shared__ uint32_t sHist[TG_RING];
     __shared__ uint32_t sBase;
     const ListCounts lc = loadListCounts(st, set);
     const uint32_t total = listTotal(lc, 0);
-    const uint32_t stride = gridDim.x*blockDim.x;
-    const uint32_t rounded = (total + blockDim.x - 1u)/blockDim.x*blockDim.x;
+    const uint32_t span = blockDim.x*TG_RETIRE_K;
+    const uint32_t rounded = (total + span - 1u)/span*span;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
     if (threadIdx.x < TG_RING) sHist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < rounded; q += stride) {
-        uint32_t slot = 0, ring = 0xFFFFFFFFu;
-        bool needs = false;
-        if (q < total && listFetch(st, lc, set, 0, q, slot)) {
-            // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so that
-            // their record is read and written once, not by a miss kernel first and by this one again
-            if (q < lc.n[0]) missPath(sc, st, slot);
-            float4 tpw = st.tp[slot];
-            int end = flagsEnd(__float_as_uint(tpw.w));
-            if (end != END_ALIVE) {
-                needs = true;
-                if (end != END_DEAD) {
-                    V3 c = xyz(st.em[slot]);
-                    if (end == END_ZERO) c = V3(0.0f);
-                    else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
-                    uint32_t ref = st.sampleRef[slot];
-                    st.results[ref] = mk4(c, 0.0f);
-                    ring = ref/st.resultSlice;
+    for (uint32_t q0 = blockIdx.x*span; q0 < rounded; q0 += gridDim.x*span) {
+        uint32_t slot[TG_RETIRE_K], stw[TG_RETIRE_K];
+        bool have[TG_RETIRE_K], needs[TG_RETIRE_K];
+#pragma unroll
+        for (int k = 0; k < TG_RETIRE_K; ++k) {
+            const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
+            slot[k] = 0;
+            have[k] = q < total && listFetch(st, lc, set, 0, q, slot[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < TG_RETIRE_K; ++k) {
+            const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
+            stw[k] = (have[k] && q >= lc.n[0]) ? st.state[slot[k]] : 0u;
+        }
+        uint32_t mine = 0; // entries of this thread that ask for a sample, over all k
+#pragma unroll
+        for (int k = 0; k < TG_RETIRE_K; ++k) {
+            const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
+            uint32_t ring = 0xFFFFFFFFu;
+            needs[k] = false;
+            if (have[k]) {
+                int end;
+                V3 c(0.0f);
+                float tpSum = 0.0f;
+                if (q < lc.n[0]) {
+                    // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so
+                    // that their record is read and written once, not by a miss kernel first and by this one again
+                    end = missPathEx(sc, st, slot[k], c, tpSum);
+                } else {
+                    end = stateEnd(stw[k]);
+                    if (end != END_ALIVE && end != END_DEAD) { // a path that goes on is left alone: its NEE terms ride with its next vertex
+                        c = xyz(st.em[slot[k]]);
+                        if (stateNee(stw[k])) c = resolveNeeTerms(st, slot[k], c);
+                        if (end == END_CHECKED) tpSum = st.tpSum[slot[k]];
+                    }
+                }
+                if (end != END_ALIVE) {
+                    needs[k] = true;
+                    if (end != END_DEAD) {
+                        if (end == END_ZERO) c = V3(0.0f);
+                        else if (end == END_CHECKED && isnanf_(tpSum + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
+                        uint32_t ref = st.sampleRef[slot[k]];
+                        st.results[ref] = mk4(c, 0.0f);
+                        ring = ref/st.resultSlice;
+                    }
                 }
             }
+            unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
+            while (todo) { // one LDS atomic per distinct job present in the wave
+                int leader = __builtin_ctzll(todo);
+                uint32_t r = __shfl(ring, leader);
+                unsigned long long m = __ballot(ring == r);
+                if (lane == leader) atomicAdd(&sHist[r], uint32_t(__builtin_popcountll(m)));
+                todo &= ~m;
+            }
+            if (needs[k]) mine++;
         }
-        unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
-        while (todo) { // one LDS atomic per distinct job present in the wave
-            int leader = __builtin_ctzll(todo);
-            uint32_t r = __shfl(ring, leader);
-            unsigned long long m = __ballot(ring == r);
-            if (lane == leader) atomicAdd(&sHist[r], uint32_t(__builtin_popcountll(m)));
-            todo &= ~m;
+        // claims: one global atomic per block round; thread order inside the wave by prefix sum over the lanes
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
         }
-        unsigned long long mask = __ballot(needs);
-        if (lane == 0) sWave[wave] = uint32_t(__builtin_popcountll(mask));
+        if (lane == 63) sWave[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t sum = 0;
@@ -361,17 +436,21 @@ static __global__ void __launch_bounds__(1024) k_retire_regenerate(DScene sc, DS
             sBase = sum ? atomicAdd(&st.counters[CNT(CNT_REGEN)], sum) : 0u;
         }
         __syncthreads();
-        if (needs) {
-            unsigned long long g = sampleBase + sBase + sWave[wave] + uint32_t(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+        unsigned long long g = sampleBase + sBase + sWave[wave] + (incl - mine);
+#pragma unroll
+        for (int k = 0; k < TG_RETIRE_K; ++k) {
+            if (!needs[k]) continue;
             if (g < limit) {
-                startSample(sc, st, jobs, g, slot);
-            } else {
-                float4 tpw = st.tp[slot];
-                st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
+                startSample(sc, st, jobs, g, slot[k]);
+            } else { // idle: the next extend drops the slot onto the free list (it reads tp.w)
+                reinterpret_cast<uint32_t *>(&st.tp[slot[k]])[3] = packFlags(0, false, END_DEAD);
+                st.state[slot[k]] = packState(false, END_DEAD);
             }
+            ++g;
         }
         __syncthreads();
     }
+    (void)below;
     if (threadIdx.x < TG_RING && sHist[threadIdx.x]) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + threadIdx.x)], sHist[threadIdx.x]);
 }
 #endif
@@ -481,9 +560,12 @@ TG_DEV void travInit(TravState &r, uint32_t root, const V3 &O, const V3 &D, floa
 // the same four loads at the top: every step costs a single memory round trip whichever mix of nodes and
 // triangles the lanes hold (a per-leaf triangle loop cost the wave one round trip per triangle of its largest leaf).
 // Closest (ANY = false): lexicographic minimum of (t, soup triangle id) over all valid triangles.
-template <bool ANY, bool COUNT>
+// SORTED = false (any-hit only): the children that are hit are visited in slot order -- no keys, no sorting network; the answer
+// of an any-hit query does not depend on the order.
+template <bool ANY, bool COUNT, bool SORTED = true>
 TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounters &tc)
 {
+    static_assert(ANY || SORTED, "closest-hit traversal needs the near-to-far order");
     const int maxSp = sc.stackEntries;
     const V3 &O = r.O, &D = r.D, &inv = r.inv, &noi = r.noi;
     const float tnear = r.tnear, tfar0 = r.tfar0;
@@ -511,6 +593,33 @@ TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounte
             const uint32_t HIx = __float_as_uint(q1.w), HIy = __float_as_uint(q2.x), HIz = __float_as_uint(q2.y);
             const uint32_t Nx = nx ? HIx : LOx, Fx = nx ? LOx : HIx, Ny = ny ? HIy : LOy, Fy = ny ? LOy : HIy, Nz = nz ? HIz : LOz, Fz = nz ? LOz : HIz;
             uint32_t key[4];
+            if (!SORTED) {
+                const uint32_t cr[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
+                uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+                for (int c = 3; c >= 0; --c) {
+                    const int sh = 8*c;
+                    float tn = TGPU_FMA(float((Nx >> sh) & 0xFFu), ax, bx);
+                    tn = fmaxf(tn, TGPU_FMA(float((Ny >> sh) & 0xFFu), ay, by));
+                    tn = fmaxf(tn, TGPU_FMA(float((Nz >> sh) & 0xFFu), az, bz));
+                    tn = fmaxf(tn, tLo);
+                    float tf = TGPU_FMA(float((Fx >> sh) & 0xFFu), ax, bx);
+                    tf = fminf(tf, TGPU_FMA(float((Fy >> sh) & 0xFFu), ay, by));
+                    tf = fminf(tf, TGPU_FMA(float((Fz >> sh) & 0xFFu), az, bz));
+                    tf = fminf(tf, tHi);
+                    if (tn <= tf) {
+                        if (first != 0xFFFFFFFFu && sp < maxSp) stackPush(sc, stack, sp, first);
+                        first = cr[c];
+                    }
+                }
+                if (first != 0xFFFFFFFFu) {
+                    node = first;
+                    return TRAV_MORE;
+                }
+                if (sp == 0) return TRAV_DONE;
+                node = stackPop(sc, stack, sp);
+                return TRAV_MORE;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int sh = 8*c;
@@ -1127,13 +1236,20 @@ __global__ void __launch_bounds__(256, (DEPTH > 4 ? TG_EXTQ_WAVES_DEEP : TG_EXTQ
 // =================================================================================================
 // K5 miss (runs inside k_retire_regenerate): TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) + end of traceSample
 // =================================================================================================
-TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
+// Returns the path's end state with its radiance and throughput.sum() (what the retire step needs), after writing them back.
+TG_DEV int missPathEx(const DScene &sc, const DState &st, uint32_t path, V3 &emOut, float &tpSumOut)
 {
     float4 tpw = st.tp[path];
     uint32_t flags = __float_as_uint(tpw.w);
-    if (flagsEnd(flags) != END_ALIVE) return; // slot without a live path (refilled later)
     float4 emw = st.em[path];
     V3 tp = xyz(tpw), em = xyz(emw);
+    if (flagsEnd(flags) == END_ALIVE && stateNee(st.state[path])) { // NEE terms of the path's last vertex (k_shadow_q)
+        em = resolveNeeTerms(st, path, em);
+        st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
+    }
+    emOut = em;
+    tpSumOut = tp.sum();
+    if (flagsEnd(flags) != END_ALIVE) return flagsEnd(flags); // slot without a live path (refilled later)
     int bounce = flagsBounce(flags);
     bool wasSpecular = flagsSpecular(flags);
     int end = END_CHECKED;
@@ -1154,9 +1270,19 @@ TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
             }
             em += tp*E;
             st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
+            emOut = em;
         }
     }
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
+    st.state[path] = packState(false, end);
+    st.tpSum[path] = tp.sum();
+    return end;
+}
+TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
+{
+    V3 em;
+    float tpSum;
+    (void)missPathEx(sc, st, path, em, tpSum);
 }
 
 
@@ -1653,6 +1779,18 @@ TG_DEV V3 phaseSample(const tgpu_medium &m, Sampler &smp, const V3 &wi, float &p
     return f.toGlobal(V3(cp*sinTheta, sp*sinTheta, cosTheta));
 }
 
+// Every shaded vertex ends here: the state word (NEE flag + end-state copy) and throughput.sum() for the retire step, and -- when
+// the vertex queued no NEE rays -- negative far ends, which is all the shadow traversal looks at.
+TG_DEV void closeVertex(const DState &st, uint32_t path, bool nee, int end, float tpSum)
+{
+    st.state[path] = packState(nee, end);
+    st.tpSum[path] = tpSum;
+    if (!nee) {
+        reinterpret_cast<float *>(&st.shA[path])[3] = -1.0f;
+        reinterpret_cast<float *>(&st.shB[path])[3] = -1.0f;
+    }
+}
+
 // One step of a path whose ray runs inside a medium: PathTracer.cpp:54-63 (HomogeneousMedium::sampleDistance,
 // HomogeneousMedium.cpp:65-108), then either the surface / miss code with the attenuated throughput or
 // TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect (:323-381, :402-414, :470-481) and the loop
@@ -1663,15 +1801,20 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
     float4 tpw = st.tp[path];
     uint32_t flags = __float_as_uint(tpw.w);
-    if (flagsEnd(flags) != END_ALIVE) { st.shFlag[path] = 0u; return; }
+    if (flagsEnd(flags) != END_ALIVE) { closeVertex(st, path, false, flagsEnd(flags), xyz(tpw).sum()); return; }
     float4 ro = st.rayO[path], rd = st.rayD[path], hw = st.hit[path], emw = st.em[path];
     uint4 sw = st.samp[path];
     V3 O = xyz(ro), D = xyz(rd), tp = xyz(tpw), em = xyz(emw);
+    if (stateNee(st.state[path])) { // NEE terms of the previous vertex (k_shadow_q left the visibility bits)
+        em = resolveNeeTerms(st, path, em);
+        st.em[path] = make_float4(em.x, em.y, em.z, emw.w);
+        st.state[path] = packState(false, END_ALIVE);
+    }
     int bounce = flagsBounce(flags);
     bool wasSpecular = flagsSpecular(flags);
     if (bounce > 0 && isnanf_(tp.sum() + em.sum())) { // PathTracer.cpp:121-122 for the previous vertex
         st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, END_ZERO));
-        st.shFlag[path] = 0u;
+        closeVertex(st, path, false, END_ZERO, tp.sum());
         return;
     }
     Sampler smp;
@@ -1721,7 +1864,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     }
     if (!ok) { // `return emission`
         st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, END_RAW));
-        st.shFlag[path] = 0u;
+        closeVertex(st, path, false, END_RAW, tp.sum());
         return;
     }
     tp *= weight;
@@ -1730,7 +1873,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
         st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
         st.med[path] = uint32_t(medium + 1) | (firstScatter ? 1u << 8 : 0u) | (stateBounce << 9);
         if (!didHit) { // `break`: handleInfiniteLights and the final NaN check
-            st.shFlag[path] = 0u;
+            closeVertex(st, path, false, END_ALIVE, tp.sum());
             missPath(sc, st, path);
         } else {
             shadePath<-1, true>(sc, st, path, true);
@@ -1846,11 +1989,16 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
     st.med[path] = uint32_t(medium + 1) | (firstScatter ? 1u << 8 : 0u) | (stateBounce << 9);
     if (pushShadow) {
+        if (!fwdScene && tfarL < 0.0f) { // a single ray always sits in slot A (the resolve adds 0 + B either way): k_shadow_q never arms an absent ray
+            dL = dB; tfarL = tfarB; L = B;
+            tfarB = -1.0f; B = V3(0.0f);
+        }
         st.shO[path] = mk4(p, 0.0f);
         st.shA[path] = mk4(dL, tfarL);
         st.shB[path] = mk4(dB, tfarB);
         st.shC[path] = mk4(fwdScene ? fL : L, pickWeight);
-        st.shD[path] = mk4u(fwdScene ? EB : B, endCap);
+        st.shD[path] = mk4u(fwdScene ? EB : B, 0u);
+        st.shX[path] = make_float4(__uint_as_float(endCap), __uint_as_float(tfarB >= 0.0f ? 1u : 0u), 0.0f, 0.0f);
         if (fwdScene) {
             st.shG[path] = mk4(EL, pdfL);
             st.shH[path] = make_float4(misL, misB, 0.0f, 0.0f);
@@ -1862,7 +2010,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     }
     st.em[path] = mk4u(em, smp.scramble);
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
-    st.shFlag[path] = pushShadow ? 1u : 0u;
+    closeVertex(st, path, pushShadow, end, tp.sum());
 }
 
 // One surface vertex of one path (the body of the shade kernels; the tail kernel calls it too):
@@ -1883,6 +2031,8 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
     int bounce = flagsBounce(flags);
     bool wasSpecular = flagsSpecular(flags);
     int end = END_ALIVE;
+    if (stateNee(st.state[path])) // NEE terms of the previous vertex (k_shadow_q left the visibility bits)
+        em = MEDIA ? resolveNeeTermsCall(st, path, em) : resolveNeeTerms(st, path, em);
 
     // afterMedium: volumePath ran the check before the distance sampling and scaled tp by the medium weight since
     if (!afterMedium && bounce > 0 && isnanf_(tp.sum() + em.sum())) {
@@ -2113,11 +2263,16 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         st.rayD[path] = mk4(wo, TG_INF);
         st.samp[path] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), sw.w);
         if (pushShadow) {
+            if (!fwdScene && tfarL < 0.0f) { // a single ray always sits in slot A (the resolve adds 0 + B either way)
+                dL = dB; tfarL = tfarB; L = B;
+                tfarB = -1.0f; B = V3(0.0f);
+            }
             st.shO[path] = mk4(neeOriginMoved ? info.p : hitpoint, eps);
             st.shA[path] = mk4(dL, tfarL);
             st.shB[path] = mk4(dB, tfarB);
             st.shC[path] = mk4(fwdScene ? fL : L, pickWeight);
-            st.shD[path] = mk4u(fwdScene ? EB : B, endCap);
+            st.shD[path] = mk4u(fwdScene ? EB : B, 0u);
+        st.shX[path] = make_float4(__uint_as_float(endCap), __uint_as_float(tfarB >= 0.0f ? 1u : 0u), 0.0f, 0.0f);
             if (fwdScene) {
                 st.shG[path] = mk4(EL, pdfL);
                 st.shH[path] = make_float4(misL, misB, 0.0f, 0.0f);
@@ -2134,7 +2289,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         st.em[path] = mk4u(em, smp.scramble);
     }
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
-    st.shFlag[path] = pushShadow ? 1u : 0u;
+    closeVertex(st, path, pushShadow, end, tp.sum());
 }
 
 template <int CLASS, bool MEDIA>
@@ -2233,7 +2388,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
 {
     float4 ro = ldStream(&st.shO[path]), a = ldStream(&st.shA[path]), b = ldStream(&st.shB[path]), c = ldStream(&st.shC[path]), d = ldStream(&st.shD[path]), e = ldStream(&st.shE[path]);
     V3 O = xyz(ro);
-    uint32_t endCap = __float_as_uint(d.w);
+    uint32_t endCap = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[path]));
     V3 result(0.0f);
     if (FWD) {
         const uint32_t bits = __float_as_uint(e.w);
@@ -2272,6 +2427,7 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
     em += (result*c.w)*xyz(e);
     if (__float_as_uint(e.w) & 1u) em += xyz(ldStream(&st.shF[path]));
     stStream(&st.em[path], make_float4(em.x, em.y, em.z, emw.w));
+    st.state[path] = st.state[path] & ~1u; // resolved here: nothing left for the next step that touches the path
 }
 
 template <bool COUNT, bool INST, bool FWD>
@@ -2292,11 +2448,182 @@ __global__ void __launch_bounds__(256, ((INST || FWD) ? 1 : TG_SHADOW_WAVES)) k_
         uint32_t idx = base + lane;
         uint32_t path = 0;
         // no `continue` here: the dequeue above must be executed by the whole wave together
-        if (idx < count && listFetch(st, lc, set, 1, idx, path) && ldStream(&st.shFlag[path])) shadowPath<COUNT, INST, FWD>(sc, st, stack, path, tc, rays);
+        if (idx < count && listFetch(st, lc, set, 1, idx, path) && stateNee(ldStream(&st.state[path]))) shadowPath<COUNT, INST, FWD>(sc, st, stack, path, tc, rays);
     }
     if (COUNT) flushCounters(st.stats, 2, tc);
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0 && rays) atomicAdd(&st.stats[4], (unsigned long long)rays);
+}
+
+// =================================================================================================
+// K4 shadow, queue form (scenes without instances / spheres / disks / forward-scattering surfaces): pure any-hit traversal with
+// persistent lanes.  The old kernel traced both NEE rays of a vertex in one lane and resolved them there: 14 % of the lanes busy
+// per VALU instruction (profiles/r01_ab_notes.txt) -- any-hit rays are short and bimodal, a wave lasted as long as its
+// unluckiest vertex.  Here a ray is 36 bytes in (origin, direction, far end, end cap: the first half of the shadow record) and
+// ONE BIT out.  A wave claims CHUNK = 64*DEPTH list entries with one atomic and hands them to its lanes one vertex at a time,
+// whenever a lane runs out of rays (wave-private cursor, no atomics): no lane waits for the slowest lane of a batch, only for
+// the next group re-arm (>= TG_SHADOWQ_THRESH waiting lanes, or nobody tracing).  Every lane keeps the next ray's record and the
+// next vertex's list entry in flight while it traces, so re-arming never waits for memory; absent rays (far end < 0) cost a
+// re-arm, not a traversal.  The visibility bits of a vertex go to shD.w; k_retire_regenerate folds the NEE terms into the
+// radiance (it visits every slot anyway and reads the second halves of both records).
+// =================================================================================================
+#ifndef TG_SHADOWQ_THRESH
+#define TG_SHADOWQ_THRESH 16
+#endif
+#ifndef TG_SHADOWQ_WAVES
+#define TG_SHADOWQ_WAVES 7
+#endif
+#ifndef TG_SHADOWQ_SORTED
+#define TG_SHADOWQ_SORTED false
+#endif
+template <bool COUNT, int DEPTH>
+__global__ void __launch_bounds__(256, TG_SHADOWQ_WAVES) k_shadow_q(DScene sc, DState st, int set)
+{
+    constexpr uint32_t CHUNK = 64u*DEPTH;
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 1); // every shaded slot
+    TraceCounters tc{0, 0};
+    uint32_t rays = 0, verts = 0;
+    // the wave's private chunk of list entries [chunkPos, chunkEnd) (wave-uniform)
+    uint32_t chunkPos = 0, chunkEnd = 0;
+    bool exhausted = false;
+    // hands one list entry to every lane that wants one (all lanes call)
+    auto claim = [&](bool want, uint32_t &slot) -> bool {
+        bool got = false;
+        unsigned long long m = __ballot(want);
+        while (m) {
+            if (chunkPos == chunkEnd) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&st.counters[CNT(CNT_HEAD_SHADOW)], CHUNK);
+                b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
+                if (b >= count) {
+                    exhausted = true;
+                    break;
+                }
+                chunkPos = b;
+                chunkEnd = min(b + CHUNK, count);
+            }
+            const uint32_t rank = uint32_t(__builtin_popcountll(m & below)), avail = chunkEnd - chunkPos;
+            const bool mine = ((m >> lane) & 1ull) && rank < avail;
+            if (mine) got = listFetch(st, lc, set, 1, chunkPos + rank, slot);
+            chunkPos += min(uint32_t(__builtin_popcountll(m)), avail);
+            m &= ~__ballot(mine);
+        }
+        return got;
+    };
+    // lane state: the vertex being traced (vs, ray cw), the ray whose record is in flight (pSlot, pWhich -> nro, nrd, ncap), the
+    // lane's next vertex (nvs: its list entry is in flight)
+    uint32_t vs = 0, pSlot = 0, nvs = 0, ncap = PRIM_MISS, nHasB = 0;
+    int cw = 0, pWhich = 0;
+    bool pre = false, haveNext = false;
+    float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
+    auto fetchRay = [&]() {
+        nrd = ldStream(pWhich ? &st.shB[pSlot] : &st.shA[pSlot]);
+        nro = ldStream(&st.shO[pSlot]);
+        ncap = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]));
+        nHasB = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]) + 1);
+    };
+    pre = claim(true, pSlot);
+    if (pre) fetchRay();
+    haveNext = claim(pre, nvs);
+    bool active = false, fin = false, blocked = false;
+    uint32_t vis = 0; // of the vertex vs: bit 0 / 1 = ray unoccluded, bit 2 = the vertex has a ray at all
+    bool last = true; // the ray being traced is its vertex's last one (its second ray, or its only one)
+    auto complete = [&](bool unoccluded) {
+        if (unoccluded) vis |= 1u << cw;
+        if (last) {
+            if (vis & 4u) {
+                stStream(reinterpret_cast<uint32_t *>(&st.shD[vs]) + 3, vis & 3u);
+                verts++;
+            }
+            vis = 0;
+        }
+    };
+    TravState t;
+    t.node = 0; t.sp = 0; t.bestT = 0.0f; t.bestU = 0.0f; t.bestV = 0.0f; t.bestPrim = PRIM_MISS;
+    while (true) {
+        if (active) {
+            const int s = travStep<true, COUNT, TG_SHADOWQ_SORTED>(sc, stack, t, tc);
+            if (s != TRAV_MORE) {
+                active = false;
+                fin = true;
+                blocked = s == TRAV_ANYHIT;
+            }
+        }
+        const bool waiting = !active && (fin || pre);
+        const unsigned long long w = __ballot(waiting), act = __ballot(active);
+        if (w == 0 && act == 0) break;
+        if (act != 0 && __builtin_popcountll(w) < TG_SHADOWQ_THRESH) continue;
+        bool wantVertex = false;
+        if (waiting) {
+            if (fin) {
+                complete(!blocked);
+                fin = false;
+            }
+            if (pre) { // arm the ray whose record was fetched ahead
+                vs = pSlot;
+                cw = pWhich;
+                last = cw == 1 || !nHasB;
+                if (nrd.w >= 0.0f) {
+                    vis |= 4u;
+                    rays++;
+                    const V3 O = xyz(nro), D = xyz(nrd);
+                    const float tnear = nro.w, tfar = nrd.w;
+                    bool hitAnalytic = false; // occluded()'s order: quads (not the end cap), cubes, triangles
+                    for (uint32_t i = 0; i < sc.nQuads; ++i) {
+                        QuadHit qh;
+                        if (mkPrim(KIND_QUAD, i) != ncap && quadIntersect(sc.quads[i], O, D, tnear, tfar, qh)) hitAnalytic = true;
+                    }
+                    for (uint32_t i = 0; i < sc.nCubes; ++i) {
+                        float tc2;
+                        bool back;
+                        if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, tc2, back)) hitAnalytic = true;
+                    }
+                    if (hitAnalytic) {
+                        complete(false);
+                    } else if (sc.nTris) {
+                        travInit(t, sc.rootChild, O, D, tnear, tfar, PRIM_MISS);
+                        active = true;
+                    } else {
+                        complete(true);
+                    }
+                } else {
+                    complete(false); // no ray: the bit is never looked at
+                }
+                // the next ray of this lane: the vertex's second ray if it has one, else the first one of the next vertex
+                if (!last) {
+                    pWhich = 1;
+                    fetchRay();
+                } else if (haveNext) {
+                    pSlot = nvs;
+                    pWhich = 0;
+                    haveNext = false;
+                    wantVertex = true;
+                    fetchRay();
+                } else {
+                    pre = false;
+                }
+            }
+        }
+        uint32_t slot = 0;
+        const bool got = claim(wantVertex, slot);
+        if (wantVertex) {
+            haveNext = got;
+            nvs = slot;
+        }
+    }
+    if (COUNT) flushCounters(st.stats, 2, tc);
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off);
+        verts += __shfl_down(verts, off);
+    }
+    if (lane == 0 && rays) atomicAdd(&st.stats[4], (unsigned long long)rays);
+    if (lane == 0 && verts) atomicAdd(&st.stats[7], (unsigned long long)verts);
 }
 
 // raw any-hit for tgpu_trace_occluded
@@ -2349,13 +2676,13 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
                 if (sc.nMedia && (st.med[slot] & 0xFFu)) {
                     volumePath(sc, st, slot);
                     events++;
-                    if (st.shFlag[slot]) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
+                    if (stateNee(st.state[slot])) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
                 } else if (prim == PRIM_MISS) {
                     missPath(sc, st, slot);
                 } else {
                     shadePath<-1, true>(sc, st, slot);
                     events++;
-                    if (st.shFlag[slot]) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
+                    if (stateNee(st.state[slot])) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
                 }
             }
             float4 tpw = st.tp[slot];
@@ -2368,6 +2695,7 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
                 st.results[ref] = mk4(c, 0.0f);
                 ring = ref/st.resultSlice;
                 st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
+                st.state[slot] = packState(false, END_DEAD);
             }
         }
         unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
@@ -2496,6 +2824,10 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shade<5, M>(DScene, DState, int); \
     PFX template __global__ void k_shade<TG_CLASS_OTHER, M>(DScene, DState, int);
 #define TG_KERNELS_SHADOW(PFX) \
+    PFX template __global__ void k_shadow_q<false, 4>(DScene, DState, int); \
+    PFX template __global__ void k_shadow_q<true, 4>(DScene, DState, int); \
+    PFX template __global__ void k_shadow_q<false, 8>(DScene, DState, int); \
+    PFX template __global__ void k_shadow_q<true, 8>(DScene, DState, int); \
     PFX template __global__ void k_shadow<false, false, false>(DScene, DState, int); \
     PFX template __global__ void k_shadow<false, false, true>(DScene, DState, int); \
     PFX template __global__ void k_shadow<false, true, false>(DScene, DState, int); \

@@ -90,6 +90,7 @@ struct tgpu_ctx {
     int numCUs = 256;
     int maxGrid = 2048;
     int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
+    int shadowQueue = 4;        // vertices (= 2 rays each) per lane of the shadow kernel's queue form: 4 or 8; TGPU_SHADOW_Q=0: k_shadow (A/B)
     size_t ldsBytes = 0;
 
     uint32_t profFlags = 0;
@@ -482,6 +483,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
 
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
     if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
+    if (const char *e = getenv("TGPU_SHADOW_Q")) ctx->shadowQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
     ctx->traceSlots = getenv("TGPU_TRACE_SLOTS") != nullptr;
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
@@ -701,8 +703,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         st.rayO.base = rec; st.rayD.base = rec + 1; st.tp.base = rec + 2; st.hit.base = rec + 3; st.em.base = rec + 4;
         st.samp.base = reinterpret_cast<uint4 *>(rec + 5);
         uint32_t *misc = reinterpret_cast<uint32_t *>(rec + 6);
-        st.med.base = misc; st.hitInst.base = misc + 1; st.shFlag.base = misc + 2; st.sampleRef.base = misc + 3;
-        st.shA.base = shrec; st.shB.base = shrec + 1; st.shC.base = shrec + 2; st.shD.base = shrec + 3; st.shE.base = shrec + 4; st.shF.base = shrec + 5; st.shO.base = shrec + 6;
+        st.med.base = misc; st.hitInst.base = misc + 1; st.state.base = misc + 2; st.sampleRef.base = misc + 3;
+        st.tpSum.base = reinterpret_cast<float *>(rec + 7);
+        st.shA.base = shrec; st.shB.base = shrec + 1; st.shO.base = shrec + 2; st.shX.base = shrec + 3;
+        st.shC.base = shrec + 4; st.shD.base = shrec + 5; st.shE.base = shrec + 6; st.shF.base = shrec + 7;
     }
     if (sc.hasForward) {
         float4 **fw[] = {&st.shG, &st.shH, &st.shI};
@@ -885,8 +889,20 @@ static int driveIteration(tgpu_ctx *ctx)
 #undef TG_LAUNCH_SHADE
             if (sc.nMedia) hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out);
         }
+        // the queue form of the shadow kernel (pure any-hit, visibility bits out; the retire kernel resolves the NEE terms) serves
+        // the scenes whose shadow rays are single segments through triangles / quads / cubes; the others keep k_shadow
+        const bool shadowQ = ctx->shadowQueue && !ctx->generalGeometry && !sc.hasForward;
         {
             Timer t(ctx, &ctx->stats.shadow_ms);
+            if (shadowQ) {
+                if (ctx->shadowQueue == 8) {
+                    if (count) hipLaunchKernelGGL((k_shadow_q<true, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                    else hipLaunchKernelGGL((k_shadow_q<false, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                } else {
+                    if (count) hipLaunchKernelGGL((k_shadow_q<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                    else hipLaunchKernelGGL((k_shadow_q<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                }
+            } else {
             const int variant = (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
 #define TG_LAUNCH_SHADOW(C, I, F) hipLaunchKernelGGL((k_shadow<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out)
             switch (variant) {
@@ -900,12 +916,14 @@ static int driveIteration(tgpu_ctx *ctx)
             default: TG_LAUNCH_SHADOW(true, true, true); break;
             }
 #undef TG_LAUNCH_SHADOW
+            }
         }
         ctx->stats.shadow_launches++;
         {
             Timer t(ctx, &ctx->stats.other_ms);
-            int g1024 = int(std::min<uint64_t>((uint64_t(nCur) + 1023)/1024, uint64_t(ctx->numCUs)*2));
-            hipLaunchKernelGGL(k_retire_regenerate, dim3(std::max(g1024, 1)), dim3(1024), 0, stream, sc, st, ring, out, ctx->sampleBase, limit);
+            const uint64_t perRound = uint64_t(TG_RETIRE_BLOCK)*TG_RETIRE_K;
+            int g1024 = int(std::min<uint64_t>((uint64_t(nCur) + perRound - 1)/perRound, uint64_t(ctx->numCUs)*(2048/TG_RETIRE_BLOCK)));
+            hipLaunchKernelGGL(k_retire_regenerate, dim3(std::max(g1024, 1)), dim3(TG_RETIRE_BLOCK), 0, stream, sc, st, ring, out, ctx->sampleBase, limit);
         }
     }
     hipError_t e = hipMemcpyAsync(ctx->hostCounters, st.counters, CNT_TOTAL*TG_CNT_STRIDE*sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -929,12 +947,12 @@ static int driveIteration(tgpu_ctx *ctx)
             if (end == uint32_t(END_DEAD) && ctx->tracePrev[s] == uint32_t(END_DEAD)) continue;
             ctx->tracePrev[s] = end;
             fprintf(stderr, "GPU it=%llu slot=%llu%s hit t=%08x u=%08x v=%08x prim=%08x inst=%08x | O=%08x %08x %08x tn=%08x D=%08x %08x %08x | tp=%08x %08x %08x bounce=%u spec=%u end=%u "
-                            "| em=%08x %08x %08x | dim=%u pcg=%08x%08x idx=%u med=%08x shFlag=%u\n",
+                            "| em=%08x %08x %08x | dim=%u pcg=%08x%08x idx=%u med=%08x state=%02x\n",
                     (unsigned long long)ctx->traceIter, (unsigned long long)s, tail ? " (tail)" : "", r[12], r[13], r[14], r[15], r[25], r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[8], r[9], r[10],
                     r[11] & 0xFFFFu, (r[11] >> 16) & 1u, end, r[16], r[17], r[18], r[20], r[22], r[21], r[23], r[24], r[26]);
-            if (r[26])
-                fprintf(stderr, "    nee dL=%08x %08x %08x tfarL=%08x | dB=%08x %08x %08x tfarB=%08x | L=%08x %08x %08x pick=%08x | B=%08x %08x %08x cap=%08x | tpV=%08x %08x %08x bits=%08x | F=%08x %08x %08x %08x\n",
-                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
+            if (r[26] & 1u)
+                fprintf(stderr, "    nee dL=%08x %08x %08x tfarL=%08x | dB=%08x %08x %08x tfarB=%08x | L=%08x %08x %08x pick=%08x | B=%08x %08x %08x vis=%08x | tpV=%08x %08x %08x bits=%08x | F=%08x %08x %08x %08x | cap=%08x\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27], h[28], h[29], h[30], h[31], h[12]);
         }
         ctx->traceIter++;
     }
@@ -1268,6 +1286,7 @@ int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out)
         ctx->stats.shadow_rays = d[4];
         ctx->stats.surface_events = d[5];
         ctx->stats.extend_rays = ctx->hostExtendRays + d[6];
+        ctx->stats.shadow_vertices = d[7];
     }
     *out = ctx->stats;
     return TGPU_OK;

@@ -12,5 +12,5 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD \
-    --output-format csv -d $OUT -- python3 $R/bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/run.log 2>&1 || { echo "pmc sq failed"; tail -5 $OUT/run.log; exit 1; }
+    --output-format csv -d $OUT -- python3 $R/bench.py --steps ${SQ_STEPS:-8} --warmup 1 --no-cpu-baseline --no-roofline $BENCH_ARGS > $OUT/run.log 2>&1 || { echo "pmc sq failed"; tail -5 $OUT/run.log; exit 1; }
 python3 $R/profiles/summarize_sq.py $OUT

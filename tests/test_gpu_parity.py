@@ -59,6 +59,23 @@ def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     assert_bit_exact(got, ref, f"{scene} {res} {spp}spp")
 
 
+def test_instance_kernel_forms_agree(ta, oracle_py, gpu_ctx, monkeypatch):
+    """Scenes with instances have two forms of each traversal kernel: nested loops (k_extend / k_shadow, one ray per lane) and the
+    flat state machine behind persistent lanes (k_extend_iq + k_classify / k_shadow_iq).  All four combinations give the oracle's bits."""
+    hs = ta.HostScene(scene_path("instances/inst_mesh.json"), resolution=(96, 54))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 8, spp_step=4)
+    for ext_q, sh_q in (("1", "4"), ("1", "0"), ("0", "4"), ("0", "0")):
+        monkeypatch.setenv("TGPU_INST_EXTEND_Q", ext_q)
+        monkeypatch.setenv("TGPU_SHADOW_Q", sh_q)
+        monkeypatch.setenv("TGPU_TAIL_MAX", "0")
+        got = render_gpu(ta, gpu_ctx, hs, shard, 8, 4)
+        assert_bit_exact(got, ref, f"inst_mesh, extend queue {ext_q}, shadow queue {sh_q}")
+    for k in ("TGPU_INST_EXTEND_Q", "TGPU_SHADOW_Q", "TGPU_TAIL_MAX"):
+        monkeypatch.delenv(k, raising=False)
+    gpu_ctx.upload(hs, shard)
+
+
 def test_instance_rays_bit_exact(ta, oracle_py, gpu_ctx):
     """Ray level: closest hits (t, u, v; instance hits report kind 3 << 29 | instance) and any-hit against the oracle."""
     hs = ta.HostScene(scene_path("instances/inst_mesh.json"), resolution=(64, 36))

@@ -84,7 +84,10 @@ enum : uint32_t {
 };
 
 // ---- device scene -----------------------------------------------------------------------------
-struct DBitmap { int32_t w, h, clamp, linear; float scale; const float4 *texels; float average[3]; }; // RGB padded to 16 B: one load per texel
+// texels: RGB padded to 16 B (one load per texel); rgbe: the same texels as 4-byte shared-exponent words when every one of them is
+// exactly representable that way (a Radiance .hdr file is: ImageIO.cpp:340-365 decodes it with float(m)*2^(e-136)) -- then the
+// float copy is not uploaded, the environment map shrinks from 8 MB to 2 MB (it fits the 4 MB L2) and a lookup decodes on the fly
+struct DBitmap { int32_t w, h, clamp, linear; float scale; const float4 *texels; float average[3]; const uint32_t *rgbe; };
 
 // "instances" primitives (primitives/Instance.cpp; host build in instance_bvh.h).
 // BVH2 node = 4 x float4: x-, y-, z-boxes of both children as (lMin, rMin, lMax, rMax) -- the lanes of
@@ -98,6 +101,9 @@ struct DInstSet {
     const DMaster *masters;
     float boundsMin[3], boundsMax[3];
     uint32_t rootIsLeaf;
+    // one 64-byte record per position of `order` (what a leaf's loop visits): (pos.xyz, bits(instance id)), rot (w, x, y, z),
+    // (bits(master kind), bits(master ref), -, -), - : entering an instance is one memory round trip, not three (instStep)
+    const float4 *entries;
 };
 constexpr int TG_TOP_STACK = 48; // BinaryBvh::trace needs depth + 1 entries; checked at upload
 
@@ -111,6 +117,7 @@ struct DScene {
     uint32_t nTris;
     int32_t stackEntries;       // worst-case traversal stack depth (3 pushes per BVH4 level)
     int32_t stackLds;           // levels kept in LDS; the rest spills to stackSpill[level - stackLds][global thread]
+    int32_t topStackLds;        // scenes with "instances": entries of the (node, tMin) stack of the top-level walk, in LDS behind the levels above
     uint32_t spillStride;       // threads of the largest grid
     uint32_t *stackSpill;
     // per-triangle shading records, soup order: 5 x float4
@@ -215,6 +222,23 @@ struct Sampler {
 
 // ---- textures ---------------------------------------------------------------------------------
 TG_DEV V3 loadRgb(const float4 *p) { float4 t = *p; return V3(t.x, t.y, t.z); }
+// stb_image's hdr_convert, exact: byte*2^(e - 136); e == 0 is black; e < 10 (denormal scale) never reaches the device (upload keeps floats)
+TG_DEV V3 decodeRgbe(uint32_t w)
+{
+    const uint32_t e = w >> 24;
+    if (e == 0u) return V3(0.0f);
+    const float f1 = __uint_as_float((e - 9u) << 23);
+    return V3(float(w & 0xFFu)*f1, float((w >> 8) & 0xFFu)*f1, float((w >> 16) & 0xFFu)*f1);
+}
+TG_DEV V3 loadTexel(const DBitmap &bm, size_t idx) { return bm.rgbe ? decodeRgbe(bm.rgbe[idx]) : loadRgb(bm.texels + idx); }
+// i mod n for the indices a lookup produces (almost always within one period of [0, n)); same value as ((i % n) + n) % n
+TG_DEV int wrapIndex(int i, int n)
+{
+    if (i < 0) i += n;
+    else if (i >= n) i -= n;
+    if (i < 0 || i >= n) i = ((i % n) + n) % n;
+    return i;
+}
 
 TG_DEV V3 bitmapEval(const DBitmap &bm, float ux, float uy) // textures/BitmapTexture.cpp:298-352
 {
@@ -233,20 +257,19 @@ TG_DEV V3 bitmapEval(const DBitmap &bm, float ux, float uy) // textures/BitmapTe
     u -= iu0;
     v -= iv0;
     if (!bm.clamp) {
-        iu0 = ((iu0 % w) + w) % w;
-        iu1 = ((iu1 % w) + w) % w;
-        iv0 = ((iv0 % h) + h) % h;
-        iv1 = ((iv1 % h) + h) % h;
+        iu0 = wrapIndex(iu0, w);
+        iu1 = wrapIndex(iu1, w);
+        iv0 = wrapIndex(iv0, h);
+        iv1 = wrapIndex(iv1, h);
     } else {
         iu0 = min(max(iu0, 0), w - 1);
         iu1 = min(max(iu1, 0), w - 1);
         iv0 = min(max(iv0, 0), h - 1);
         iv1 = min(max(iv1, 0), h - 1);
     }
-    const float4 *t = bm.texels;
-    if (!linear) return loadRgb(t + (size_t(iu0) + size_t(iv0)*w));
-    V3 x00 = loadRgb(t + (size_t(iu0) + size_t(iv0)*w)), x01 = loadRgb(t + (size_t(iu1) + size_t(iv0)*w));
-    V3 x10 = loadRgb(t + (size_t(iu0) + size_t(iv1)*w)), x11 = loadRgb(t + (size_t(iu1) + size_t(iv1)*w));
+    if (!linear) return loadTexel(bm, size_t(iu0) + size_t(iv0)*w);
+    V3 x00 = loadTexel(bm, size_t(iu0) + size_t(iv0)*w), x01 = loadTexel(bm, size_t(iu1) + size_t(iv0)*w);
+    V3 x10 = loadTexel(bm, size_t(iu0) + size_t(iv1)*w), x11 = loadTexel(bm, size_t(iu1) + size_t(iv1)*w);
     V3 l = (x00*(1.0f - u) + x01*u)*(1.0f - v) + (x10*(1.0f - u) + x11*u)*v;
     return bm.scale*l;
 }

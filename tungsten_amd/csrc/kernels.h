@@ -562,8 +562,16 @@ TG_DEV void travInit(TravState &r, uint32_t root, const V3 &O, const V3 &D, floa
 // Closest (ANY = false): lexicographic minimum of (t, soup triangle id) over all valid triangles.
 // SORTED = false (any-hit only): the children that are hit are visited in slot order -- no keys, no sorting network; the answer
 // of an any-hit query does not depend on the order.
-template <bool ANY, bool COUNT, bool SORTED = true>
-TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounters &tc)
+// The 64-byte record the next step of `r` needs (an inner node or one triangle of a leaf)
+TG_DEV const float4 *travItem(const DScene &sc, const TravState &r)
+{
+    return (r.node & 0x80000000u) ? sc.tris + size_t((r.node & 0x7FFFFFFFu) >> 3)*4 : sc.nodes + size_t(r.node)*4;
+}
+// travApply: one step on the record q0..q3 fetched from travItem(); travStep = fetch + apply.  ANYDYN: ANY is decided per lane
+// at run time (`any`) -- the instance state machine steps closest-hit and any-hit queries through one loop.
+template <bool ANY, bool COUNT, bool SORTED = true, bool ANYDYN = false>
+TG_DEV int travApply(const DScene &sc, uint32_t *stack, TravState &r, TraceCounters &tc, const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3,
+                     bool any = ANY)
 {
     static_assert(ANY || SORTED, "closest-hit traversal needs the near-to-far order");
     const int maxSp = sc.stackEntries;
@@ -577,8 +585,6 @@ TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounte
     {
         const bool leaf = (node & 0x80000000u) != 0;
         const uint32_t payload = node & 0x7FFFFFFFu; // leaf: first << 3 | count - 1
-        const float4 *n = leaf ? sc.tris + size_t(payload >> 3)*4 : sc.nodes + size_t(node)*4;
-        float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
         if (!leaf) {
             if (COUNT) tc.nodes++;
             // the interval the boxes are clipped to, with the relative slack of include/tgpu_bounds.h: the computed t of a
@@ -653,7 +659,7 @@ TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounte
             if (COUNT) tc.tris++;
             float t, u, v;
             if (triTest(q0, q1, q2, O, D, tnear, tfar0, t, u, v)) {
-                if (ANY) return TRAV_ANYHIT;
+                if (ANYDYN ? any : ANY) return TRAV_ANYHIT;
                 const uint32_t id = __float_as_uint(q3.x);
                 if (t < bestT || (t == bestT && id < bestPrim)) {
                     bestT = t; bestU = u; bestV = v; bestPrim = id;
@@ -668,6 +674,13 @@ TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounte
     if (sp == 0) return TRAV_DONE;
     node = stackPop(sc, stack, sp);
     return TRAV_MORE;
+}
+template <bool ANY, bool COUNT, bool SORTED = true>
+TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounters &tc)
+{
+    const float4 *n = travItem(sc, r);
+    const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+    return travApply<ANY, COUNT, SORTED>(sc, stack, r, tc, q0, q1, q2, q3);
 }
 
 template <bool ANY, bool COUNT>
@@ -953,6 +966,259 @@ TG_DEV bool occluded(const DScene &sc, uint32_t *stack, const V3 &O, const V3 &D
         if (traverse<true, COUNT>(sc, stack, sc.rootChild, O, D, tnear, t, u, v, p, tc)) return true;
     }
     return false;
+}
+
+// =================================================================================================
+// The same queries as closestHit<.., true> / occluded<.., true> as a FLAT state machine: one 64-byte record per step and lane --
+// a node of the instance BVH2, an instance entry, or a node / triangle of a mesh BVH4 -- so that the lanes of a wave advance
+// together whatever level of the two-level structure each of them is in (the nested loops of instanceIntersect make a wave
+// wait for its deepest lane at every level), and so that the per-lane ray queues of k_extend_q / k_shadow_q can drive it.
+// Order, arithmetic and the reference's quirks (local rays start at the leaf's entry distance with farT = infinity, the last
+// instance hit in traversal order wins: Instance.cpp:290-311, BinaryBvh.hpp:188-283) are instanceIntersect's, line by line.
+// The (node, tMin) stack of the top-level walk lives in LDS: topStack[level*256] per thread, sc.topStackLds levels.
+// =================================================================================================
+enum { IP_TOP = 0, IP_ENTRY = 1, IP_BOTTOM = 2, IP_SCENE = 3, IP_DONE = 4 };
+struct InstTrav {
+    V3 O, D, invDir;
+    float tnear, farT;          // the world ray; farT is what instance hits overwrite
+    float tMin, tMax, negFarLane;
+    uint32_t topNode, leafI, leafEnd, set, curInst;
+    int topSp, phase;
+    bool any, blocked;          // any: any-hit query (towards infinite lights); blocked: its answer
+    uint32_t prim, inst, endCap;
+    float u, v;
+    TravState b;                // the mesh BVH4 walk of the instance being visited (local ray), then of the scene's own triangles
+};
+
+// next set (or the part after the sets) -- instanceIntersect's prologue: bboxIntersection(_bounds, ...) :148-171
+TG_DEV void instBeginSet(const DScene &sc, InstTrav &r);
+// closestHit / occluded after the instance sets: analytic primitives in place, then the scene's triangles as one more BVH walk
+TG_DEV void instAfterSets(const DScene &sc, InstTrav &r)
+{
+    const V3 &O = r.O, &D = r.D;
+    if (!r.any) {
+        if (r.prim == PRIM_MISS) r.inst = INST_NONE;
+        for (uint32_t i = 0; i < sc.nQuads; ++i) {
+            QuadHit h;
+            if (quadIntersect(sc.quads[i], O, D, r.tnear, r.farT, h)) { r.farT = h.t; r.u = h.u; r.v = h.v; r.prim = mkPrim(KIND_QUAD, i); r.inst = INST_NONE; }
+        }
+        for (uint32_t i = 0; i < sc.nCubes; ++i) {
+            float t;
+            bool back;
+            if (cubeIntersect(sc.cubes[i], O, D, r.tnear, r.farT, t, back)) { r.farT = t; r.u = 0.0f; r.v = 0.0f; r.prim = mkPrim(KIND_CUBE, i); r.inst = INST_NONE; }
+        }
+        for (uint32_t i = 0; i < sc.nSpheres; ++i) {
+            float t;
+            bool back;
+            if (sphereIntersect(sc.spheres[i], O, D, r.tnear, r.farT, t, back)) { r.farT = t; r.u = 0.0f; r.v = 0.0f; r.prim = mkPrim(KIND_SPHERE, i); r.inst = INST_NONE; }
+        }
+        for (uint32_t i = 0; i < sc.nDisks; ++i) {
+            DiskHit h;
+            if (diskIntersect(sc.disks[i], O, D, r.tnear, r.farT, h)) { r.farT = h.t; r.u = h.rSq; r.v = 0.0f; r.prim = mkPrim(KIND_DISK, i); r.inst = INST_NONE; }
+        }
+    } else {
+        bool hit = false;
+        for (uint32_t i = 0; i < sc.nQuads; ++i) {
+            QuadHit h;
+            if (mkPrim(KIND_QUAD, i) != r.endCap && quadIntersect(sc.quads[i], O, D, r.tnear, r.farT, h)) hit = true;
+        }
+        for (uint32_t i = 0; i < sc.nCubes; ++i) {
+            float t;
+            bool back;
+            if (cubeIntersect(sc.cubes[i], O, D, r.tnear, r.farT, t, back)) hit = true;
+        }
+        for (uint32_t i = 0; i < sc.nSpheres; ++i) {
+            float t;
+            bool back;
+            if (mkPrim(KIND_SPHERE, i) != r.endCap && sphereIntersect(sc.spheres[i], O, D, r.tnear, r.farT, t, back)) hit = true;
+        }
+        for (uint32_t i = 0; i < sc.nDisks; ++i) {
+            DiskHit h;
+            if (mkPrim(KIND_DISK, i) != r.endCap && diskIntersect(sc.disks[i], O, D, r.tnear, r.farT, h)) hit = true;
+        }
+        if (hit) {
+            r.blocked = true;
+            r.phase = IP_DONE;
+            return;
+        }
+    }
+    if (sc.nTris) {
+        travInit(r.b, sc.rootChild, O, D, r.tnear, r.farT, PRIM_MISS);
+        r.phase = IP_SCENE;
+    } else {
+        r.phase = IP_DONE;
+    }
+}
+TG_DEV void instBeginSet(const DScene &sc, InstTrav &r)
+{
+    while (r.set < sc.nInstSets) {
+        const DInstSet &is = sc.instSets[r.set];
+        float ttMin = r.tnear, ttMax = r.farT;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float invD = 1.0f/r.D.comp(i);
+            float relMin = is.boundsMin[i] - r.O.comp(i), relMax = is.boundsMax[i] - r.O.comp(i);
+            if (invD >= 0.0f) {
+                ttMin = fmax2(ttMin, relMin*invD);
+                ttMax = fmin2(ttMax, relMax*invD);
+            } else {
+                ttMax = fmin2(ttMax, relMin*invD);
+                ttMin = fmax2(ttMin, relMax*invD);
+            }
+        }
+        if (ttMin <= ttMax) {
+            r.tMin = ttMin;
+            r.tMax = ttMax;
+            r.negFarLane = -r.farT;
+            r.topNode = 0;
+            r.topSp = 0;
+            r.phase = IP_TOP;
+            return;
+        }
+        r.set++;
+    }
+    instAfterSets(sc, r);
+}
+// a query for ray (O, D, tnear, tfar): closest hit, or any hit (`any`; endCap = the primitive the ray is aimed at)
+TG_DEV void instInit(const DScene &sc, InstTrav &r, const V3 &O, const V3 &D, float tnear, float tfar, bool any, uint32_t endCap)
+{
+    r.O = O; r.D = D;
+    r.invDir = V3(1.0f/D.x, 1.0f/D.y, 1.0f/D.z);
+    r.tnear = tnear; r.farT = tfar;
+    r.any = any; r.blocked = false; r.endCap = endCap;
+    r.prim = PRIM_MISS; r.inst = INST_NONE; r.u = 0.0f; r.v = 0.0f;
+    r.set = 0;
+    instBeginSet(sc, r);
+}
+// the record the next step needs
+TG_DEV const float4 *instItem(const DScene &sc, const InstTrav &r)
+{
+    if (r.phase == IP_TOP) return sc.instSets[r.set].nodes + size_t(r.topNode)*4;
+    if (r.phase == IP_ENTRY) return sc.instSets[r.set].entries + size_t(r.leafI)*4;
+    return travItem(sc, r.b);
+}
+// leave the current position of the top-level walk: pop until an entry is still in range, or finish the set
+TG_DEV void instPop(const DScene &sc, InstTrav &r, const uint2 *topStack)
+{
+    while (true) {
+        if (r.topSp == 0) {
+            r.set++;
+            instBeginSet(sc, r);
+            return;
+        }
+        --r.topSp;
+        const uint2 e = topStack[r.topSp*256];
+        r.topNode = e.x;
+        r.tMin = __uint_as_float(e.y);
+        if (r.tMax < r.tMin) continue;
+        r.phase = IP_TOP;
+        return;
+    }
+}
+// after the last instance of a leaf: BinaryBvh.hpp:262-264
+TG_DEV void instLeafDone(const DScene &sc, InstTrav &r, const uint2 *topStack)
+{
+    r.tMax = fmin2(r.tMax, r.farT);
+    r.negFarLane = -r.tMax;
+    instPop(sc, r, topStack);
+}
+// an instance was hit at local distance t (Instance.cpp:301-308): it wins whatever was found before
+TG_DEV void instRecordHit(InstTrav &r, float t, uint32_t prim, float u, float v)
+{
+    r.farT = t;
+    r.prim = prim; r.u = u; r.v = v;
+    r.inst = (r.set << 24) | r.curInst;
+}
+
+template <bool COUNT>
+TG_DEV void instStep(const DScene &sc, uint32_t *stack, uint2 *topStack, InstTrav &r, TraceCounters &tc, const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3)
+{
+    if (r.phase == IP_TOP) {
+        if (__float_as_uint(q3.y) == 0xFFFFFFFFu) { // a leaf: its instances next
+            r.leafI = __float_as_uint(q3.z);
+            r.leafEnd = r.leafI + __float_as_uint(q3.w);
+            if (r.leafI < r.leafEnd) r.phase = IP_ENTRY;
+            else instLeafDone(sc, r, topStack);
+            return;
+        }
+        if (COUNT) tc.nodes++;
+        const V3 &O = r.O, &invDir = r.invDir;
+        const bool px = r.D.x >= 0.0f, py = r.D.y >= 0.0f, pz = r.D.z >= 0.0f;
+        const float4 &bx = q0, &by = q1, &bz = q2;
+        // child 0 = lanes (x: min, z: max), child 1 = lanes (y: min, w: max)
+        float nx0 = px ? bx.x : bx.z, fx0 = px ? bx.z : bx.x, nx1 = px ? bx.y : bx.w, fx1 = px ? bx.w : bx.y;
+        float ny0 = py ? by.x : by.z, fy0 = py ? by.z : by.x, ny1 = py ? by.y : by.w, fy1 = py ? by.w : by.y;
+        float nz0 = pz ? bz.x : bz.z, fz0 = pz ? bz.z : bz.x, nz1 = pz ? bz.y : bz.w, fz1 = pz ? bz.w : bz.y;
+        float mn0 = sseMax(sseMax(sseMax((nx0 - O.x)*invDir.x, (ny0 - O.y)*invDir.y), (nz0 - O.z)*invDir.z), r.tnear);
+        float mn1 = sseMax(sseMax(sseMax((nx1 - O.x)*invDir.x, (ny1 - O.y)*invDir.y), (nz1 - O.z)*invDir.z), r.tnear);
+        float mx0 = -sseMax(sseMax(sseMax((fx0 - O.x)*(-invDir.x), (fy0 - O.y)*(-invDir.y)), (fz0 - O.z)*(-invDir.z)), r.negFarLane);
+        float mx1 = -sseMax(sseMax(sseMax((fx1 - O.x)*(-invDir.x), (fy1 - O.y)*(-invDir.y)), (fz1 - O.z)*(-invDir.z)), r.negFarLane);
+        const bool hitL = mn0 <= mx0, hitR = mn1 <= mx1;
+        const uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+        if (hitL && hitR) {
+            if (mn0 < mn1) { topStack[r.topSp*256] = make_uint2(rr, __float_as_uint(mn1)); ++r.topSp; r.topNode = l; r.tMin = mn0; }
+            else { topStack[r.topSp*256] = make_uint2(l, __float_as_uint(mn0)); ++r.topSp; r.topNode = rr; r.tMin = mn1; }
+        } else if (hitL) { r.topNode = l; r.tMin = mn0; }
+        else if (hitR) { r.topNode = rr; r.tMin = mn1; }
+        else instPop(sc, r, topStack);
+        return;
+    }
+    if (r.phase == IP_ENTRY) { // one instance of the leaf: Instance::intersect's lambda (:292-309)
+        const V3 pos(q0.x, q0.y, q0.z);
+        r.curInst = __float_as_uint(q0.w);
+        const float4 inv = make_float4(q1.x, -q1.y, -q1.z, -q1.w); // conjugate
+        const V3 lo = quatRotate(inv, r.O - pos), ld = quatRotate(inv, r.D);
+        const int kind = int(__float_as_uint(q2.x));
+        const uint32_t ref = __float_as_uint(q2.y);
+        if (kind == TGPU_MASTER_MESH) {
+            travInit(r.b, ref, lo, ld, r.tMin, TG_INF, PRIM_MISS); // Ray::scatter: farT = infinity (math/Ray.hpp:29)
+            r.phase = IP_BOTTOM;
+            return;
+        }
+        bool hitI = false;
+        if (kind == TGPU_MASTER_QUAD) {
+            QuadHit h;
+            if (quadIntersect(sc.quads[ref], lo, ld, r.tMin, TG_INF, h)) {
+                hitI = true;
+                if (!r.any) instRecordHit(r, h.t, mkPrim(KIND_QUAD, ref), h.u, h.v);
+            }
+        } else {
+            float t = 0.0f;
+            const int c = cubeMasterIntersect(sc.cubes[ref], lo, ld, r.tMin, TG_INF, t);
+            if (c != 0) {
+                hitI = true;
+                if (!r.any) {
+                    if (c == 2) instRecordHit(r, t, mkPrim(KIND_CUBE, ref), 0.0f, 0.0f);
+                    else { r.farT = TG_INF; r.inst = (r.set << 24) | r.curInst; } // Cube.cpp:113-124 returns true without a recorded hit: farT = the local ray's infinity, prim unchanged
+                }
+            }
+        }
+        if (hitI && r.any) { r.blocked = true; r.phase = IP_DONE; return; }
+        if (++r.leafI == r.leafEnd) instLeafDone(sc, r, topStack);
+        return;
+    }
+    // a mesh BVH4: the instance's master (local ray) or the scene's own triangles
+    const int s = travApply<false, COUNT, true, true>(sc, stack, r.b, tc, q0, q1, q2, q3, r.any);
+    if (s == TRAV_MORE) return;
+    if (r.phase == IP_BOTTOM) {
+        if (r.any) {
+            if (s == TRAV_ANYHIT) { r.blocked = true; r.phase = IP_DONE; return; }
+        } else if (r.b.bestPrim != PRIM_MISS) {
+            instRecordHit(r, r.b.bestT, r.b.bestPrim, r.b.bestU, r.b.bestV);
+        }
+        if (++r.leafI == r.leafEnd) instLeafDone(sc, r, topStack);
+        else r.phase = IP_ENTRY;
+        return;
+    }
+    // IP_SCENE
+    if (r.any) {
+        r.blocked = s == TRAV_ANYHIT;
+    } else if (r.b.bestPrim != PRIM_MISS) {
+        r.farT = r.b.bestT; r.u = r.b.bestU; r.v = r.b.bestV;
+        r.prim = r.b.bestPrim;
+        r.inst = INST_NONE;
+    }
+    r.phase = IP_DONE;
 }
 
 TG_DEV void flushCounters(unsigned long long *stats, int slot, const TraceCounters &tc)
@@ -2626,6 +2892,331 @@ __global__ void __launch_bounds__(256, TG_SHADOWQ_WAVES) k_shadow_q(DScene sc, D
     if (lane == 0 && verts) atomicAdd(&st.stats[7], (unsigned long long)verts);
 }
 
+// =================================================================================================
+// The queue kernels for scenes with "instances" (and spheres / disks): k_extend_q's and k_shadow_q's scaffolding around the flat
+// instance state machine (instStep).  Round 1 ran these scenes one ray per lane through nested loops with the top-level stack
+// in scratch memory (400-1168 B per lane) at one wave per SIMD.
+// =================================================================================================
+#ifndef TG_INSTQ_WAVES
+#define TG_INSTQ_WAVES 3
+#endif
+// Closest hit with persistent lanes: a wave claims CHUNK = 64*DEPTH entries of the input lists with one atomic and hands them to
+// its lanes one ray at a time (k_shadow_q's scheme); the hit goes to the slot's record, the sort by material is k_classify's job
+// (a ray of this scene family costs 5-7 thousand instructions, the extra pass over the list a few dozen).
+template <bool COUNT, int DEPTH>
+__global__ void __launch_bounds__(256, TG_INSTQ_WAVES) k_extend_iq(DScene sc, DState st, int set)
+{
+    constexpr uint32_t CHUNK = 64u*DEPTH;
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    uint2 *topStack = reinterpret_cast<uint2 *>(ldsStack + sc.stackLds*256) + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 0);
+    TraceCounters tc{0, 0};
+    uint32_t chunkPos = 0, chunkEnd = 0;
+    bool exhausted = false;
+    auto claim = [&](bool want, uint32_t &slot) -> bool {
+        bool got = false;
+        unsigned long long m = __ballot(want);
+        while (m) {
+            if (chunkPos == chunkEnd) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&st.counters[CNT(CNT_HEAD_EXT)], CHUNK);
+                b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
+                if (b >= count) {
+                    exhausted = true;
+                    break;
+                }
+                chunkPos = b;
+                chunkEnd = min(b + CHUNK, count);
+            }
+            const uint32_t rank = uint32_t(__builtin_popcountll(m & below)), avail = chunkEnd - chunkPos;
+            const bool mine = ((m >> lane) & 1ull) && rank < avail;
+            if (mine) got = listFetch(st, lc, set, 0, chunkPos + rank, slot);
+            chunkPos += min(uint32_t(__builtin_popcountll(m)), avail);
+            m &= ~__ballot(mine);
+        }
+        return got;
+    };
+    // the ray being traced (slot vs), the ray whose record is in flight (pSlot -> nro, nrd, nflags), the lane's next list entry (nvs)
+    uint32_t vs = 0, pSlot = 0, nvs = 0, nflags = 0;
+    bool pre = false, haveNext = false;
+    float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
+    auto fetchRay = [&]() {
+        nro = ldStream(&st.rayO[pSlot]);
+        nrd = ldStream(&st.rayD[pSlot]);
+        nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[pSlot]) + 3);
+    };
+    pre = claim(true, pSlot);
+    if (pre) fetchRay();
+    haveNext = claim(pre, nvs);
+    bool active = false, fin = false;
+    InstTrav r;
+    r.phase = IP_DONE; r.farT = 0.0f; r.u = 0.0f; r.v = 0.0f; r.prim = PRIM_MISS; r.inst = INST_NONE;
+    // The lane's next record is fetched as soon as it is known (right after a step / on arming) and consumed when the lane's KIND
+    // of step is the one the wave runs in an iteration: mesh-BVH steps (IP_BOTTOM / IP_SCENE) or top-level steps (IP_TOP /
+    // IP_ENTRY), whichever has more lanes ready -- otherwise the wave pays the instructions of all code paths in every step.
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0, q3 = q0;
+    auto fetchItem = [&]() {
+        const float4 *item = instItem(sc, r);
+        q0 = item[0]; q1 = item[1]; q2 = item[2]; q3 = item[3];
+    };
+    while (true) {
+        {
+            const bool isMesh = active && r.phase >= IP_BOTTOM, isTop = active && r.phase < IP_BOTTOM;
+            const bool runMesh = __builtin_popcountll(__ballot(isMesh)) >= __builtin_popcountll(__ballot(isTop));
+            if (runMesh ? isMesh : isTop) {
+                instStep<COUNT>(sc, stack, topStack, r, tc, q0, q1, q2, q3);
+                if (r.phase == IP_DONE) {
+                    active = false;
+                    fin = true;
+                } else {
+                    fetchItem();
+                }
+            }
+        }
+        const bool waiting = !active && (fin || pre);
+        const unsigned long long w = __ballot(waiting), act = __ballot(active);
+        if (w == 0 && act == 0) break;
+        if (act != 0 && __builtin_popcountll(w) < TG_EXTQ_THRESH) continue;
+        bool wantEntry = false;
+        if (waiting) {
+            if (fin) { // retire the ray of slot vs
+                stStream(&st.hit[vs], make_float4(r.farT, r.u, r.v, __uint_as_float(r.prim)));
+                stStream(&st.hitInst[vs], r.prim == PRIM_MISS ? INST_NONE : r.inst);
+                fin = false;
+            }
+            if (pre) {
+                vs = pSlot;
+                if (flagsEnd(nflags) != END_DEAD) { // idle slots are k_classify's business
+                    instInit(sc, r, xyz(nro), xyz(nrd), nro.w, nrd.w, false, PRIM_MISS);
+                    if (r.phase == IP_DONE) {
+                        fin = true;
+                    } else {
+                        active = true;
+                        fetchItem();
+                    }
+                }
+                if (haveNext) {
+                    pSlot = nvs;
+                    haveNext = false;
+                    wantEntry = true;
+                    fetchRay();
+                } else {
+                    pre = false;
+                }
+            }
+        }
+        uint32_t slot = 0;
+        const bool got = claim(wantEntry, slot);
+        if (wantEntry) {
+            haveNext = got;
+            nvs = slot;
+        }
+    }
+    if (COUNT) flushCounters(st.stats, 0, tc);
+}
+
+// Sort by material after k_extend_iq: every entry of the input lists goes to the list of its hit's BSDF class (miss: list 0, path in
+// a medium: the volume list, idle slot: the free list) of the other set -- the tail of k_extend_q as a pass of its own.
+#ifdef TG_TU_MAIN
+static __global__ void __launch_bounds__(256) k_classify(DScene sc, DState st, int set)
+{
+    const int lane = threadIdx.x & 63;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 0);
+    const uint32_t waves = gridDim.x*(blockDim.x >> 6), wave = blockIdx.x*(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int out = set ^ 1;
+    for (uint32_t base = wave*256u; base < count; base += waves*256u) {
+        uint32_t p[4], cls4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p[q] = 0;
+            uint32_t cls = 0xFEu;
+            if (base + lane + 64u*q < count && listFetch(st, lc, set, 0, base + lane + 64u*q, p[q])) {
+                if (flagsEnd(__float_as_uint(ldStream(&st.tp[p[q]]).w)) == END_DEAD) {
+                    cls = 0xFDu;
+                } else {
+                    cls = hitClass(sc, __float_as_uint(ldStream(&st.hit[p[q]]).w));
+                    if (sc.nMedia && (st.med[p[q]] & 0xFFu)) cls = TG_CLASS_VOLUME;
+                }
+            }
+            cls4 |= cls << (8*q);
+        }
+#pragma unroll
+        for (int l = 0; l <= TG_LISTS; ++l) {
+            const uint32_t want = l == 0 ? 0xFFu : (l == TG_LISTS ? 0xFDu : uint32_t(l - 1));
+            unsigned long long m0 = __ballot((cls4 & 0xFFu) == want), m1 = __ballot(((cls4 >> 8) & 0xFFu) == want);
+            unsigned long long m2 = __ballot(((cls4 >> 16) & 0xFFu) == want), m3 = __ballot((cls4 >> 24) == want);
+            uint32_t n0 = uint32_t(__builtin_popcountll(m0)), n1 = uint32_t(__builtin_popcountll(m1));
+            uint32_t n2 = uint32_t(__builtin_popcountll(m2)), n3 = uint32_t(__builtin_popcountll(m3));
+            uint32_t nn = n0 + n1 + n2 + n3;
+            if (nn == 0) continue;
+            uint32_t *dst = l == TG_LISTS ? st.freeQ : st.lists[out][l];
+            uint32_t *ctr = l == TG_LISTS ? &st.counters[CNT(CNT_FREE)] : &st.counters[CNT(CNT_LIST0 + out*TG_LISTS + l)];
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(ctr, nn);
+            wbase = __shfl(wbase, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p[0]);
+            if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p[1]);
+            if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p[2]);
+            if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p[3]);
+        }
+    }
+}
+#endif
+
+template <bool COUNT, int DEPTH>
+__global__ void __launch_bounds__(256, TG_INSTQ_WAVES) k_shadow_iq(DScene sc, DState st, int set)
+{
+    constexpr uint32_t CHUNK = 64u*DEPTH;
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    uint2 *topStack = reinterpret_cast<uint2 *>(ldsStack + sc.stackLds*256) + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 1);
+    TraceCounters tc{0, 0};
+    uint32_t rays = 0, verts = 0;
+    uint32_t chunkPos = 0, chunkEnd = 0;
+    bool exhausted = false;
+    auto claim = [&](bool want, uint32_t &slot) -> bool {
+        bool got = false;
+        unsigned long long m = __ballot(want);
+        while (m) {
+            if (chunkPos == chunkEnd) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&st.counters[CNT(CNT_HEAD_SHADOW)], CHUNK);
+                b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
+                if (b >= count) {
+                    exhausted = true;
+                    break;
+                }
+                chunkPos = b;
+                chunkEnd = min(b + CHUNK, count);
+            }
+            const uint32_t rank = uint32_t(__builtin_popcountll(m & below)), avail = chunkEnd - chunkPos;
+            const bool mine = ((m >> lane) & 1ull) && rank < avail;
+            if (mine) got = listFetch(st, lc, set, 1, chunkPos + rank, slot);
+            chunkPos += min(uint32_t(__builtin_popcountll(m)), avail);
+            m &= ~__ballot(mine);
+        }
+        return got;
+    };
+    uint32_t vs = 0, pSlot = 0, nvs = 0, ncap = PRIM_MISS, nHasB = 0, curCap = PRIM_MISS;
+    int cw = 0, pWhich = 0;
+    bool pre = false, haveNext = false, closestMode = false;
+    float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
+    auto fetchRay = [&]() {
+        nrd = ldStream(pWhich ? &st.shB[pSlot] : &st.shA[pSlot]);
+        nro = ldStream(&st.shO[pSlot]);
+        ncap = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]));
+        nHasB = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]) + 1);
+    };
+    pre = claim(true, pSlot);
+    if (pre) fetchRay();
+    haveNext = claim(pre, nvs);
+    bool active = false, fin = false;
+    uint32_t vis = 0;
+    bool last = true;
+    auto complete = [&](bool unoccluded) {
+        if (unoccluded) vis |= 1u << cw;
+        if (last) {
+            if (vis & 4u) {
+                stStream(reinterpret_cast<uint32_t *>(&st.shD[vs]) + 3, vis & 3u);
+                verts++;
+            }
+            vis = 0;
+        }
+    };
+    InstTrav r;
+    r.phase = IP_DONE; r.blocked = false; r.prim = PRIM_MISS; r.inst = INST_NONE;
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0, q3 = q0; // the lane's next record (see k_extend_iq)
+    auto fetchItem = [&]() {
+        const float4 *item = instItem(sc, r);
+        q0 = item[0]; q1 = item[1]; q2 = item[2]; q3 = item[3];
+    };
+    while (true) {
+        {
+            const bool isMesh = active && r.phase >= IP_BOTTOM, isTop = active && r.phase < IP_BOTTOM;
+            const bool runMesh = __builtin_popcountll(__ballot(isMesh)) >= __builtin_popcountll(__ballot(isTop));
+            if (runMesh ? isMesh : isTop) {
+                instStep<COUNT>(sc, stack, topStack, r, tc, q0, q1, q2, q3);
+                if (r.phase == IP_DONE) {
+                    active = false;
+                    fin = true;
+                } else {
+                    fetchItem();
+                }
+            }
+        }
+        const bool waiting = !active && (fin || pre);
+        const unsigned long long w = __ballot(waiting), act = __ballot(active);
+        if (w == 0 && act == 0) break;
+        if (act != 0 && __builtin_popcountll(w) < TG_SHADOWQ_THRESH) continue;
+        bool wantVertex = false;
+        if (waiting) {
+            if (fin) {
+                // a finite light behind "instances": generalizedShadowRay's full closest-hit query (occluded<.., true>)
+                const bool blocked = closestMode ? (r.prim != PRIM_MISS && !(r.inst == INST_NONE && r.prim == curCap)) : r.blocked;
+                complete(!blocked);
+                fin = false;
+            }
+            if (pre) {
+                vs = pSlot;
+                cw = pWhich;
+                last = cw == 1 || !nHasB;
+                if (nrd.w >= 0.0f) {
+                    vis |= 4u;
+                    rays++;
+                    curCap = ncap;
+                    closestMode = sc.nInstSets && ncap != PRIM_MISS && primKind(ncap) != KIND_ENV;
+                    instInit(sc, r, xyz(nro), xyz(nrd), nro.w, nrd.w, !closestMode, ncap);
+                    if (r.phase == IP_DONE) {
+                        fin = true;
+                    } else {
+                        active = true;
+                        fetchItem();
+                    }
+                } else {
+                    complete(false);
+                }
+                if (!last) {
+                    pWhich = 1;
+                    fetchRay();
+                } else if (haveNext) {
+                    pSlot = nvs;
+                    pWhich = 0;
+                    haveNext = false;
+                    wantVertex = true;
+                    fetchRay();
+                } else {
+                    pre = false;
+                }
+            }
+        }
+        uint32_t slot = 0;
+        const bool got = claim(wantVertex, slot);
+        if (wantVertex) {
+            haveNext = got;
+            nvs = slot;
+        }
+    }
+    if (COUNT) flushCounters(st.stats, 2, tc);
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off);
+        verts += __shfl_down(verts, off);
+    }
+    if (lane == 0 && rays) atomicAdd(&st.stats[4], (unsigned long long)rays);
+    if (lane == 0 && verts) atomicAdd(&st.stats[7], (unsigned long long)verts);
+}
+
 // raw any-hit for tgpu_trace_occluded
 template <bool INST>
 __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint32_t count, uint8_t *out)
@@ -2823,6 +3414,11 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shade<4, M>(DScene, DState, int); \
     PFX template __global__ void k_shade<5, M>(DScene, DState, int); \
     PFX template __global__ void k_shade<TG_CLASS_OTHER, M>(DScene, DState, int);
+#define TG_KERNELS_INSTQ(PFX) \
+    PFX template __global__ void k_extend_iq<false, 4>(DScene, DState, int); \
+    PFX template __global__ void k_extend_iq<true, 4>(DScene, DState, int); \
+    PFX template __global__ void k_shadow_iq<false, 4>(DScene, DState, int); \
+    PFX template __global__ void k_shadow_iq<true, 4>(DScene, DState, int);
 #define TG_KERNELS_SHADOW(PFX) \
     PFX template __global__ void k_shadow_q<false, 4>(DScene, DState, int); \
     PFX template __global__ void k_shadow_q<true, 4>(DScene, DState, int); \

@@ -28,6 +28,7 @@ namespace tg {
 TG_KERNELS_SHADE(extern, false)
 TG_KERNELS_SHADE(extern, true)
 TG_KERNELS_SHADOW(extern)
+TG_KERNELS_INSTQ(extern)
 TG_KERNELS_TAIL(extern, false)
 TG_KERNELS_TAIL(extern, true)
 }
@@ -90,6 +91,7 @@ struct tgpu_ctx {
     int numCUs = 256;
     int maxGrid = 2048;
     int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
+    bool instExtendQueue = false; // TGPU_INST_EXTEND_Q=1: k_extend_iq + k_classify for scenes with instances / spheres / disks (A/B)
     int shadowQueue = 4;        // vertices (= 2 rays each) per lane of the shadow kernel's queue form: 4 or 8; TGPU_SHADOW_Q=0: k_shadow (A/B)
     size_t ldsBytes = 0;
 
@@ -437,6 +439,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     // ---- "instances" (Instance::prepareForRender: the BVH2 over instance boxes is built in instance_bvh.h) ----
     auto bitsToFloat = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
     std::vector<DInstSet> instSets(s->n_instance_sets);
+    int topDepth = 0; // entries of the top-level (node, tMin) stack: BinaryBvh::trace needs depth + 1
     for (uint32_t si = 0; si < s->n_instance_sets; ++si) {
         const tgpu_instances &is = s->instance_sets[si];
         std::vector<DMaster> masters(is.n_masters);
@@ -470,7 +473,19 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         if ((rc = upload(ctx, ctx->allocs, pos.data(), pos.size(), &dP))) return rc;
         if ((rc = upload(ctx, ctx->allocs, rot.data(), rot.size(), &dR))) return rc;
         if ((rc = upload(ctx, ctx->allocs, masters.data(), masters.size(), &dM))) return rc;
+        std::vector<float4> entries(tree.order.size()*4);
+        for (size_t i = 0; i < tree.order.size(); ++i) {
+            const uint32_t id = tree.order[i];
+            entries[i*4 + 0] = make_float4(pos[id].x, pos[id].y, pos[id].z, bitsToFloat(id));
+            entries[i*4 + 1] = rot[id];
+            entries[i*4 + 2] = make_float4(bitsToFloat(uint32_t(masters[is.master_id[id]].kind)), bitsToFloat(masters[is.master_id[id]].ref), 0.0f, 0.0f);
+            entries[i*4 + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        float4 *dE;
+        if ((rc = upload(ctx, ctx->allocs, entries.data(), entries.size(), &dE))) return rc;
+        topDepth = std::max(topDepth, tree.depth + 1);
         DInstSet &d = instSets[si];
+        d.entries = dE;
         d.nodes = dN; d.order = dO; d.pos = dP; d.rot = dR; d.masters = dM;
         for (int k = 0; k < 3; ++k) { d.boundsMin[k] = tree.bounds.lo[k]; d.boundsMax[k] = tree.bounds.hi[k]; }
         d.rootIsLeaf = tree.nodes[0].right < 0;
@@ -483,6 +498,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
 
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
     if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
+    ctx->instExtendQueue = getenv("TGPU_INST_EXTEND_Q") && atoi(getenv("TGPU_INST_EXTEND_Q")) != 0;
     if (const char *e = getenv("TGPU_SHADOW_Q")) ctx->shadowQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
     ctx->traceSlots = getenv("TGPU_TRACE_SLOTS") != nullptr;
@@ -497,6 +513,9 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     // (profiles/r01_ab_notes.txt); deeper levels spill to global memory
     sc.stackLds = 20;
     if (const char *e = getenv("TGPU_STACK_LDS")) sc.stackLds = std::max(1, atoi(e));
+    // scenes with "instances": the top-level stack lives in LDS too (8 bytes per entry and thread), the mesh levels shrink to 12
+    sc.topStackLds = topDepth;
+    if (topDepth && !getenv("TGPU_STACK_LDS")) sc.stackLds = 12;
     sc.stackLds = std::min(sc.stackLds, sc.stackEntries);
     sc.spillStride = uint32_t(ctx->maxGrid)*256u;
     sc.stackSpill = nullptr;
@@ -505,7 +524,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         if ((rc = upload<uint32_t>(ctx, ctx->allocs, nullptr, size_t(sc.stackEntries - sc.stackLds)*sc.spillStride, &dSpill))) return rc;
         sc.stackSpill = dSpill;
     }
-    ctx->ldsBytes = size_t(sc.stackLds)*256*sizeof(uint32_t);
+    ctx->ldsBytes = size_t(sc.stackLds)*256*sizeof(uint32_t) + size_t(sc.topStackLds)*256*2*sizeof(uint32_t);
 
     // ---- shading records ----
     std::vector<tgpu_bvh::Float4> shade(size_t(nAllTris)*5);
@@ -585,11 +604,44 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     std::vector<DBitmap> bitmaps(s->n_bitmaps);
     for (uint32_t i = 0; i < s->n_bitmaps; ++i) {
         const tgpu_bitmap &b = s->bitmaps[i];
-        std::vector<float4> padded(size_t(b.w)*b.h);
-        for (size_t t = 0; t < padded.size(); ++t) padded[t] = make_float4(b.texels[t*3], b.texels[t*3 + 1], b.texels[t*3 + 2], 0.0f);
-        float4 *dTexels;
-        if ((rc = upload(ctx, ctx->allocs, padded.data(), padded.size(), &dTexels))) return rc;
-        bitmaps[i] = DBitmap{b.w, b.h, b.clamp, b.linear, b.scale, dTexels, {b.average[0], b.average[1], b.average[2]}};
+        // shared-exponent words when every texel survives the round trip bit for bit (device.h, decodeRgbe); TGPU_TEX_FLOAT=1 keeps floats (A/B)
+        const size_t nTexels = size_t(b.w)*b.h;
+        std::vector<uint32_t> rgbe(nTexels);
+        bool exact = getenv("TGPU_TEX_FLOAT") == nullptr;
+        for (size_t t = 0; t < nTexels && exact; ++t) {
+            const float *c = b.texels + t*3;
+            const float m = std::max(c[0], std::max(c[1], c[2]));
+            uint32_t w = 0;
+            if (!(c[0] >= 0.0f && c[1] >= 0.0f && c[2] >= 0.0f) || !std::isfinite(m)) { exact = false; break; }
+            if (m > 0.0f) {
+                int k;
+                (void)std::frexp(m, &k); // m = f*2^k, f in [0.5, 1): the largest byte lands in [128, 255]
+                const int e = k + 128;
+                if (e < 10 || e > 255) { exact = false; break; }
+                uint32_t scaleBits = uint32_t(e - 9) << 23;
+                float f1;
+                std::memcpy(&f1, &scaleBits, 4);
+                uint32_t bytes[3];
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float q = c[ch]/f1; // exact: a power-of-two scale
+                    bytes[ch] = uint32_t(q);
+                    if (q != float(bytes[ch]) || bytes[ch] > 255u || float(bytes[ch])*f1 != c[ch]) exact = false;
+                }
+                w = bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | (uint32_t(e) << 24);
+            }
+            rgbe[t] = w;
+        }
+        float4 *dTexels = nullptr;
+        uint32_t *dRgbe = nullptr;
+        if (exact) {
+            if ((rc = upload(ctx, ctx->allocs, rgbe.data(), rgbe.size(), &dRgbe))) return rc;
+        } else {
+            std::vector<float4> padded(nTexels);
+            for (size_t t = 0; t < padded.size(); ++t) padded[t] = make_float4(b.texels[t*3], b.texels[t*3 + 1], b.texels[t*3 + 2], 0.0f);
+            if ((rc = upload(ctx, ctx->allocs, padded.data(), padded.size(), &dTexels))) return rc;
+        }
+        if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] bitmap %u: %dx%d as %s\n", i, b.w, b.h, exact ? "RGBE words" : "float4 texels");
+        bitmaps[i] = DBitmap{b.w, b.h, b.clamp, b.linear, b.scale, dTexels, {b.average[0], b.average[1], b.average[2]}, dRgbe};
     }
     DBitmap *dBitmaps;
     if ((rc = upload(ctx, ctx->allocs, bitmaps.data(), bitmaps.size(), &dBitmaps))) return rc;
@@ -864,7 +916,15 @@ static int driveIteration(tgpu_ctx *ctx)
         int grid = gridFor(ctx, nCur);
         {
             Timer t(ctx, &ctx->stats.extend_ms);
-            if (ctx->generalGeometry) {
+            // scenes with instances / spheres / disks: the nested-loop kernel stays the default for closest hits -- the persistent-lane
+            // form around the flat state machine (k_extend_iq + k_classify, TGPU_INST_EXTEND_Q=1) doubles the lanes busy per
+            // instruction but spends them on its own bookkeeping: 81 against 64 ms per step on config 4 (profiles/r02_ab_notes.txt).
+            // For shadow rays the same state machine wins (k_shadow_iq: 29 against 49 ms).
+            if (ctx->generalGeometry && ctx->instExtendQueue) {
+                if (count) hipLaunchKernelGGL((k_extend_iq<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                else hipLaunchKernelGGL((k_extend_iq<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, stream, sc, st, cur);
+            } else if (ctx->generalGeometry) {
                 if (count) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
                 else hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
             } else {
@@ -889,12 +949,15 @@ static int driveIteration(tgpu_ctx *ctx)
 #undef TG_LAUNCH_SHADE
             if (sc.nMedia) hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out);
         }
-        // the queue form of the shadow kernel (pure any-hit, visibility bits out; the retire kernel resolves the NEE terms) serves
-        // the scenes whose shadow rays are single segments through triangles / quads / cubes; the others keep k_shadow
-        const bool shadowQ = ctx->shadowQueue && !ctx->generalGeometry && !sc.hasForward;
+        // the queue forms of the shadow kernel (visibility bits out; the next kernel that touches the path folds the NEE terms in)
+        // serve every scene whose shadow rays are single segments; forward-scattering scenes keep k_shadow's multi-segment walk
+        const bool shadowQ = ctx->shadowQueue && !sc.hasForward;
         {
             Timer t(ctx, &ctx->stats.shadow_ms);
-            if (shadowQ) {
+            if (shadowQ && ctx->generalGeometry) {
+                if (count) hipLaunchKernelGGL((k_shadow_iq<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                else hipLaunchKernelGGL((k_shadow_iq<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+            } else if (shadowQ) {
                 if (ctx->shadowQueue == 8) {
                     if (count) hipLaunchKernelGGL((k_shadow_q<true, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
                     else hipLaunchKernelGGL((k_shadow_q<false, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);

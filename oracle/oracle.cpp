@@ -1086,6 +1086,30 @@ inline bool bboxIntersection(const IBox &box, const V3 &o, const V3 &d, float &t
 
 struct oracle_instances { std::vector<InstSet> sets; };
 
+// BinaryBvh(prims, 2) (bvh/BinaryBvh.hpp:174-195) on top of BvhBuilder(2) (bvh/BvhBuilder.cpp:99-185)
+static void buildBinaryBvh(InstSet &s, IPrims &prims)
+{
+    s.nodes.clear();
+    if (prims.empty()) {
+        s.depth = 0;
+        s.nodes.emplace_back();
+        setJointBbox(s.nodes[0], IBox(), IBox());
+        s.nodes[0].l = 0; s.nodes[0].r = 0; // rChild = itself: an inner node that never passes the box test
+        return;
+    }
+    IBox geomBounds, centroidBounds;
+    for (const IPrim &p : prims) { geomBounds.grow(p.box); centroidBounds.grow(p.centroid); }
+    NaiveNode root;
+    size_t count = prims.size();
+    naiveBuild(root, 0, uint32_t(count - 1), prims, geomBounds, centroidBounds, s.depth);
+    s.bounds = root.box;
+    s.primIndices.resize(count);
+    s.nodes.resize(2*count);
+    uint32_t tail = 1, primIndex = 0;
+    tinyBuild(s, &root, 0, tail, primIndex, 2);
+    s.nodes.resize(tail);
+}
+
 void oracle_ctx::buildInstances()
 {
     inst.reset(new oracle_instances());
@@ -1114,26 +1138,7 @@ void oracle_ctx::buildInstances()
             p.box = bGlobal; p.centroid = bGlobal.center(); p.id = i; p.area = bGlobal.area();
             prims.push_back(p);
         }
-        // BinaryBvh(prims, 2) :174-195
-        s.nodes.clear();
-        if (prims.empty()) {
-            s.depth = 0;
-            s.nodes.emplace_back();
-            setJointBbox(s.nodes[0], IBox(), IBox());
-            s.nodes[0].l = 0; s.nodes[0].r = 0; // rChild = itself: an inner node that never passes the box test
-            continue;
-        }
-        IBox geomBounds, centroidBounds;
-        for (const IPrim &p : prims) { geomBounds.grow(p.box); centroidBounds.grow(p.centroid); }
-        NaiveNode root;
-        size_t count = prims.size();
-        naiveBuild(root, 0, uint32_t(count - 1), prims, geomBounds, centroidBounds, s.depth);
-        s.bounds = root.box;
-        s.primIndices.resize(count);
-        s.nodes.resize(2*count);
-        uint32_t tail = 1, primIndex = 0;
-        tinyBuild(s, &root, 0, tail, primIndex, 2);
-        s.nodes.resize(tail);
+        buildBinaryBvh(s, prims);
     }
 }
 
@@ -1162,24 +1167,12 @@ bool oracle_ctx::masterIntersect(uint32_t setIndex, uint32_t master, Ray &ray, T
     return true;
 }
 
-bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Counters &c) const // Instance.cpp:290-311
+// BinaryBvh::trace (bvh/BinaryBvh.hpp:188-283), the SSE lanes written out per child; intersector(id, tMin) may shorten ray.farT
+template <class F>
+static void walkBinaryBvh(const InstSet &s, Ray &ray, uint64_t &nodeVisits, F intersector)
 {
-    const InstSet &s = inst->sets[setIndex];
-    const tgpu_instances &is = sc.instance_sets[setIndex];
-    bool hit = false;
-    uint32_t prim = 0;
-    auto intersector = [&](uint32_t id, float tMin) {
-        float invRot[4] = {is.rot[size_t(id)*4], -is.rot[size_t(id)*4 + 1], -is.rot[size_t(id)*4 + 2], -is.rot[size_t(id)*4 + 3]};
-        Ray localRay{qrot(invRot, ray.pos - V3(is.pos + size_t(id)*3)), qrot(invRot, ray.dir), tMin, INF}; // Ray::scatter: farT = infinity
-        if (masterIntersect(setIndex, is.master_id[id], localRay, data, c)) {
-            hit = true;
-            prim = id;
-            ray.farT = localRay.farT;
-        }
-    };
-    // ---- BinaryBvh::trace (:188-283), the SSE lanes written out per child
     float tMin = ray.nearT, tMax = ray.farT;
-    if (!bboxIntersection(s.bounds, ray.pos, ray.dir, tMin, tMax)) return false;
+    if (!bboxIntersection(s.bounds, ray.pos, ray.dir, tMin, tMax)) return;
     struct StackNode { int32_t node; float tMin; };
     std::vector<StackNode> stack(size_t(s.depth) + 2);
     size_t sp = 0;
@@ -1192,7 +1185,7 @@ bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Coun
         bool skipLeaf = false;
         while (s.nodes[size_t(node)].isNode()) {
             const TinyNode &n = s.nodes[size_t(node)];
-            c.nodes++;
+            nodeVisits++;
             float mn[2], mx[2];
             for (int ch = 0; ch < 2; ++ch) {
                 float tn[3], tfNeg[3];
@@ -1230,6 +1223,23 @@ bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Coun
         }
         if (done) break;
     }
+}
+
+bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Counters &c) const // Instance.cpp:290-311
+{
+    const InstSet &s = inst->sets[setIndex];
+    const tgpu_instances &is = sc.instance_sets[setIndex];
+    bool hit = false;
+    uint32_t prim = 0;
+    walkBinaryBvh(s, ray, c.nodes, [&](uint32_t id, float tMin) {
+        float invRot[4] = {is.rot[size_t(id)*4], -is.rot[size_t(id)*4 + 1], -is.rot[size_t(id)*4 + 2], -is.rot[size_t(id)*4 + 3]};
+        Ray localRay{qrot(invRot, ray.pos - V3(is.pos + size_t(id)*3)), qrot(invRot, ray.dir), tMin, INF}; // Ray::scatter: farT = infinity
+        if (masterIntersect(setIndex, is.master_id[id], localRay, data, c)) {
+            hit = true;
+            prim = id;
+            ray.farT = localRay.farT;
+        }
+    });
     if (hit) {
         data.inst = int32_t(prim);
         data.instSet = int32_t(setIndex);
@@ -3184,6 +3194,34 @@ void oracle_camera_ray(const oracle_ctx *ctx, uint32_t px, uint32_t py, float xi
     Ray r;
     ctx->cameraRay(px, py, xi0, xi1, r);
     o[0] = r.pos.x; o[1] = r.pos.y; o[2] = r.pos.z; o[3] = r.dir.x; o[4] = r.dir.y; o[5] = r.dir.z;
+}
+
+/* Known-answer entry for the instance BVH2 (tests/test_oracle_kat.py against tests/golden/ref_kat2.json, produced by the reference's
+ * own BvhBuilder / BinaryBvh): builds the tree over `n` boxes (6 floats each: min, max; primitive id = index, centroid = box centre)
+ * and walks one ray (origin, direction, nearT 1e-4, farT infinity); every visit (id, bits(tMin)) goes to out[2*k], out[2*k + 1], and
+ * a visit of an id divisible by 5 shortens the ray to tMin + 0.75 as a hit would.  Returns the number of visits. */
+uint32_t oracle_kat_binary_bvh(const float *boxes6, uint32_t n, const float *origin3, const float *dir3, uint32_t *out, uint32_t maxVisits)
+{
+    IPrims prims;
+    for (uint32_t i = 0; i < n; ++i) {
+        IPrim p;
+        p.box = IBox();
+        p.box.grow(V3(boxes6 + size_t(i)*6));
+        p.box.grow(V3(boxes6 + size_t(i)*6 + 3));
+        p.centroid = p.box.center(); p.id = i; p.area = p.box.area();
+        prims.push_back(p);
+    }
+    InstSet s;
+    buildBinaryBvh(s, prims);
+    Ray ray{V3(origin3), V3(dir3), 1e-4f, INF};
+    uint64_t nodes = 0;
+    uint32_t k = 0;
+    walkBinaryBvh(s, ray, nodes, [&](uint32_t id, float tMin) {
+        if (k < maxVisits) { out[2*k] = id; out[2*k + 1] = tgpu_float_to_bits(tMin); }
+        ++k;
+        if (id % 5 == 0) ray.farT = tMin + 0.75f;
+    });
+    return k;
 }
 
 void oracle_get_stats(oracle_ctx *ctx, oracle_stats *out)

@@ -74,6 +74,7 @@ uint32_t oracle_sobol(const oracle_ctx *ctx, uint32_t index, uint32_t dim, uint3
 void oracle_pcg_stream(uint64_t state, uint64_t seq, uint32_t n, uint32_t *out);
 void oracle_camera_ray(const oracle_ctx *ctx, uint32_t px, uint32_t py, float xi0, float xi1, float *origin_dir6);
 void oracle_tile_seeds(uint32_t res_x, uint32_t res_y, uint32_t seed, uint32_t *out);
+uint32_t oracle_kat_binary_bvh(const float *boxes6, uint32_t n, const float *origin3, const float *dir3, uint32_t *out, uint32_t max_visits);
 
 /* Triangle queries test EVERY triangle instead of walking the BVH: the definition (include/tgpu_bounds.h) both BVH walks
  * are checked against.  O(rays x triangles): ray batches and single paths only. */

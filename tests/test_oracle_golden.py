@@ -123,3 +123,21 @@ def test_path_local_stream_is_unbiased(ta, oracle_py):
     rel = np.abs(pool(img) - pool(ref)).mean()/pool(ref).mean()
     assert rel < 0.05
     assert abs(img.mean()/ref.mean() - 1.0) < 0.02
+
+
+def test_golden_fixtures_match_their_manifest():
+    """Every reference-rendered fixture is listed in tests/golden/MANIFEST.sha256 with its digest: the PFMs came from a build of
+    the unmodified reference that this repo's recipe cannot redo, so their bytes are pinned here."""
+    import hashlib
+    manifest = {}
+    for line in open(os.path.join(GOLDEN, "MANIFEST.sha256")):
+        digest, name = line.split()
+        manifest[name] = digest
+    on_disk = set()
+    for root, _, files in os.walk(GOLDEN):
+        for f in files:
+            if f.endswith((".pfm", ".dat")) or f in ("ref_kat.json", "ref_kat2.json"):
+                on_disk.add(os.path.relpath(os.path.join(root, f), GOLDEN))
+    assert on_disk == set(manifest), f"fixtures without manifest entry or vice versa: {sorted(on_disk ^ set(manifest))}"
+    for name, digest in manifest.items():
+        assert hashlib.sha256(open(os.path.join(GOLDEN, name), "rb").read()).hexdigest() == digest, name

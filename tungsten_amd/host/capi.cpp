@@ -108,6 +108,14 @@ int tgh_adaptive_generate(tgh_adaptive *a, uint32_t currentSpp, uint32_t nextSpp
     return 1;
 }
 
+// Mat4f::rotYXZ (math/Mat4f.cpp:118-130) as the transform parser uses it; out9 = row-major upper 3x3 (known-answer test)
+void tgh_rot_yxz(const float *rotDeg3, float *out9)
+{
+    Mat4 m = Mat4::rotYXZ(Vec3(rotDeg3[0], rotDeg3[1], rotDeg3[2]));
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out9[r*3 + c] = m(r, c);
+}
+
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h) { return savePfm(path, rgb, w, h) ? 0 : -1; }
 int tgh_save_png_tonemapped(const char *path, const char *tonemap, const float *rgb, int w, int h)
 {

@@ -364,6 +364,91 @@ def test_cpp_host_integrator_cli(ta, oracle_py, tmp_path):
     assert os.path.getsize(tmp_path / "cli.png") > 1000
 
 
+def test_cli_resume_file_continues_a_render_bit_for_bit(ta, oracle_py, tmp_path):
+    """Integrator::saveRenderResumeData / resumeRender on the reference's file layout (Integrator.cpp:108-162): 16 spp, then a second
+    run that resumes to 32 spp, equals a straight 32-spp render in every bit; -r (restart) ignores the file; --timeout stops after a
+    pass; -i resolves resources; the reference's own resume file (tests/golden/next/RenderState_*.dat) loads with a hash warning."""
+    import json
+    import shutil
+    import struct
+    import subprocess
+    from conftest import REPO, ASSETS
+    d = json.load(open(scene_path("materialtest/c2.json")))
+    d["camera"]["resolution"] = [64, 36]
+    d["renderer"].update({"spp": 16, "spp_step": 16, "output_file": "r.png", "hdr_output_file": "r.pfm", "enable_resume_render": True,
+                          "resume_render_file": "RenderState.dat"})
+    exe = os.path.join(REPO, "tungsten_amd", "tungsten_amd_cli")
+    env = dict(os.environ, TUNGSTEN_AMD_ASSETS=ASSETS)
+    indir = os.path.join(ASSETS, "materialtest")  # relative "file" entries resolve against -i
+
+    def run(spp, *flags, outdir):
+        d["renderer"]["spp"] = spp
+        scene_file = tmp_path / "resume_scene.json"
+        scene_file.write_text(json.dumps(d))
+        os.makedirs(outdir, exist_ok=True)
+        r = subprocess.run([exe, "-i", indir, "-d", str(outdir), *flags, str(scene_file)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout, scene_file
+
+    a = tmp_path / "a"
+    out, _ = run(16, outdir=a)
+    assert "Resume unsuccessful" in out and "Completed 16/16 spp" in out
+    state = (a / "RenderState.dat").read_bytes()
+    header = state[:state.index(b"\0")]
+    assert json.loads(header) == {"current_spp": 16, "adaptive_sampling": False, "stratified_sampler": True}
+    assert header == b'{\n    "current_spp": 16,\n    "adaptive_sampling": false,\n    "stratified_sampler": true\n}'   # rapidjson PrettyWriter's layout
+    n_px, n_vt, n_tiles = 64*36, 16*9, 4*3
+    assert len(state) == len(header) + 1 + 8 + n_px*16 + n_vt*24 + n_tiles*12                                           # the reference's sizes
+    out, _ = run(32, outdir=a)                                  # second run: resumes at 16, renders one more pass
+    assert "Resume successful" in out and "Completed 32/32 spp" in out and "Completed 16/32 spp" not in out
+    b = tmp_path / "b"
+    out, _ = run(32, "-r", outdir=b)                            # straight render
+    assert "Trying to resume" not in out
+    resumed, straight = ta.load_pfm(a / "r.pfm"), ta.load_pfm(b / "r.pfm")
+    assert np.array_equal(resumed, straight)
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(64, 36))   # the same scene, resources next to the file
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    ref, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 32, spp_step=16)
+    assert np.array_equal(straight, shard.scatter(ref))
+    # --timeout: the pass loop stops after the first pass that ends past the limit (Shared.hpp:295-296)
+    c = tmp_path / "c"
+    out, _ = run(64, "-r", "--timeout", "1ms", outdir=c)
+    assert "Completed 16/64 spp" in out and "Completed 32/64 spp" not in out
+    # the reference's own file (c2 at 64x36, 32 spp): same layout; its scene hash is the reference's re-serialisation -> warning only
+    e = tmp_path / "e"
+    os.makedirs(e)
+    shutil.copy(os.path.join(GOLDEN, "next", "RenderState_c2_64x36_32spp_step16.dat"), e / "RenderState.dat")
+    out, _ = run(32, outdir=e)
+    assert "Resume successful" in out and "Warning: the resume file was written for another scene text" in out
+    assert "Completed" not in out                                # 32 of 32 spp are in the file: nothing left to render
+    got = ta.load_pfm(e / "r.pfm")
+    want = ta.load_pfm(os.path.join(GOLDEN, "next", "RenderState_c2_64x36_32spp_step16.pfm"))
+    assert np.array_equal(got, want)                             # the colour buffer of the file, written back out unchanged
+
+
+def test_abort_mid_render_then_render_again(ta, oracle_py, gpu_ctx):
+    """Integrator::abortRender (PathTraceIntegrator.cpp:249-256) from a second thread while passes are queued: tgpu_wait reports
+    TGPU_ERR_ABORTED, and the same context then renders correctly again."""
+    import threading
+    import time
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(640, 360))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    for i in range(64):                                          # 1024 spp queued: several hundred ms of work
+        gpu_ctx.render_pass(16*i, 16)
+    killer = threading.Timer(0.03, lambda: ta.core_lib().tgpu_abort(gpu_ctx._h))
+    killer.start()
+    t0 = time.perf_counter()
+    with pytest.raises(ta.CoreError, match="aborted"):
+        gpu_ctx.wait()
+    killer.join()
+    assert time.perf_counter() - t0 < 5.0
+    gpu_ctx.upload(hs, shard)                                    # fresh framebuffer on the same context
+    gpu_ctx.render(8, spp_step=4)
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 8, spp_step=4)
+    assert_bit_exact(gpu_ctx.download(), ref, "render after an abort")
+
+
 def _records_image(rec, hs):
     """RECORD_DTYPE table -> (varH, varW, 3) float32 like Oracle.render_reference's third result."""
     var_w, var_h = (hs.res_x + 3)//4, (hs.res_y + 3)//4
@@ -387,6 +472,38 @@ def test_adaptive_sampling_bit_exact(ta, oracle_py, gpu_ctx):
     assert np.array_equal(shard.scatter(cnt.reshape(-1, 1).repeat(3, 1).astype(np.float32))[..., 0], ref_cnt.astype(np.float32))
     assert np.array_equal(_records_image(rec, hs).view(np.uint32), ref_rec.view(np.uint32))
     assert np.array_equal(shard.scatter(rgb), ref_img)
+
+
+def test_adaptive_passes_larger_than_a_result_slice_are_split(ta, oracle_py, gpu_ctx):
+    """A pass whose samples exceed one slice of the result ring (spp_step 32 > 16 spp per slice; a shard handed three times its
+    share) runs as several jobs cut along 16x16 tiles: same bits as the oracle's single loop (round 1 refused such passes)."""
+    from tungsten_amd.passes import render_passes
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(128, 72))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    render_passes(gpu_ctx, hs.res_x, hs.res_y, 96, 32, adaptive=True)          # uniform 32-spp pass, then two adaptive ones
+    rgb, cnt = gpu_ctx.download()
+    rec = gpu_ctx.download_records()
+    ref_img, ref_cnt, ref_rec = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(96, spp_step=32, adaptive=True)
+    assert np.array_equal(_records_image(rec, hs).view(np.uint32), ref_rec.view(np.uint32))
+    assert np.array_equal(shard.scatter(rgb), ref_img)
+    # a synthetic, skewed table: a band of variance tiles gets 60 samples per pixel, the rest 1 -> 3x the slice of an even pass
+    var_w, var_h = (hs.res_x + 3)//4, (hs.res_y + 3)//4
+    idx = np.zeros(var_w*var_h, np.uint32)
+    skew = np.ones((var_h, var_w), np.uint32)
+    skew[4:14, :] = 60
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render_pass_adaptive(idx, skew.ravel())
+    gpu_ctx.wait()
+    rgb, cnt = gpu_ctx.download()
+    o_rgb = np.zeros((shard.n_pixels, 3), np.float32)
+    o_cnt = np.zeros(shard.n_pixels, np.uint32)
+    o_rec = np.zeros(var_w*var_h, ta.RECORD_DTYPE)
+    oracle_py.Oracle(hs, **oracle_py.GPU).render_shard_adaptive(shard, idx, skew.ravel(), o_rgb, o_cnt, o_rec)
+    assert int(cnt.sum()) == int(o_cnt.sum()) > shard.n_pixels*24
+    assert_bit_exact((rgb, cnt), (o_rgb, o_cnt), "skewed adaptive pass")
+    got_rec = gpu_ctx.download_records()
+    assert np.array_equal(got_rec.view(np.uint32), o_rec.view(np.uint32))
 
 
 def test_adaptive_sampling_ragged_image_and_two_shards(ta, oracle_py, gpu_ctx):

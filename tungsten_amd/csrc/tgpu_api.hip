@@ -74,6 +74,8 @@ struct tgpu_ctx {
     uint32_t varW = 0, varH = 0;
     std::vector<uint32_t> vtGlobal;       // local variance tile -> whole-image variance tile
     std::vector<uint32_t> vtOfPixelHost;  // shard pixel -> local variance tile
+    uint32_t lastTileOfUpload = 0;
+    std::vector<uint32_t> tileStart;      // first shard pixel of every 16x16 tile of the shard, + nPixels (adaptive passes split here)
     std::mutex mtx;
     std::condition_variable cvWork, cvIdle;
     std::deque<Job> pending, active;
@@ -701,7 +703,15 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     ctx->varH = (s->camera.res_y + 3)/4;
     ctx->vtGlobal.clear();
     ctx->vtOfPixelHost.clear();
+    ctx->tileStart.clear();
     if (ctx->trackRecords) {
+        for (uint32_t i = 0; i < shard->n_pixels; ++i) {
+            const uint32_t x = shard->pixel_index[i] % s->camera.res_x, y = shard->pixel_index[i]/s->camera.res_x;
+            const uint32_t tile = x/16 + (y/16)*((s->camera.res_x + 15)/16);
+            if (i == 0 || tile != ctx->lastTileOfUpload) ctx->tileStart.push_back(i);
+            ctx->lastTileOfUpload = tile;
+        }
+        ctx->tileStart.push_back(shard->n_pixels);
         std::vector<uint32_t> gids(shard->n_pixels);
         for (uint32_t i = 0; i < shard->n_pixels; ++i) {
             uint32_t x = shard->pixel_index[i] % s->camera.res_x, y = shard->pixel_index[i]/s->camera.res_x;
@@ -1087,7 +1097,7 @@ static void workerMain(tgpu_ctx *ctx)
                 more = !ctx->pending.empty() || !ctx->active.empty() || ctx->aliveCount > 0;
             }
             if (!more) break;
-            if (ctx->abortFlag.load()) { rc = TGPU_ERR_ABORTED; break; }
+            if (ctx->abortFlag.exchange(false)) { rc = TGPU_ERR_ABORTED; break; } // consumed here, and only here
             rc = driveIteration(ctx);
         }
         (void)hipStreamSynchronize(ctx->stream);
@@ -1105,7 +1115,10 @@ static void workerMain(tgpu_ctx *ctx)
                 ctx->lastRc = rc;
             }
             ctx->idle = ctx->pending.empty();
-            if (ctx->idle) ctx->cvIdle.notify_all();
+            if (ctx->idle) {
+                ctx->abortFlag = false; // an abort that arrived after the last iteration has nothing left to stop (tgpu_abort sets it under this mutex)
+                ctx->cvIdle.notify_all();
+            }
         }
     }
 }
@@ -1116,9 +1129,10 @@ int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *
     if (!ctx->uploaded) { fail(ctx, "tgpu_render_pass before tgpu_upload_scene"); return TGPU_ERR_STATE; }
     if (sppCount == 0) return TGPU_OK;
     if (ctx->trackRecords && sppCount > ctx->resultSpp) {
-        // a SampleRecord sees ALL samples of a pixel before the next pixel's (renderTile order): the pass must fit one slice
-        fail(ctx, "with adaptive_sampling a pass holds at most %u spp (spp_step), got %u", ctx->resultSpp, sppCount);
-        return TGPU_ERR_UNSUPPORTED;
+        // a SampleRecord sees ALL samples of a pixel before the next pixel's (renderTile order), so the pass cannot be cut into spp
+        // slices like below: it goes the way of the adaptive passes (pixel-major jobs, cut along 16x16 tiles) with one count for all
+        std::vector<uint32_t> index(size_t(ctx->varW)*ctx->varH, sppBegin), cnt(size_t(ctx->varW)*ctx->varH, sppCount);
+        return tgpu_render_pass_adaptive(ctx, index.data(), cnt.data(), streamPtr);
     }
     if (streamPtr) {
         // work submitted so far on the caller's stream must precede the pass: order the context stream after it
@@ -1131,7 +1145,6 @@ int tgpu_render_pass(tgpu_ctx *ctx, uint32_t sppBegin, uint32_t sppCount, void *
     }
     {
         std::lock_guard<std::mutex> lk(ctx->mtx);
-        ctx->abortFlag = false;
         for (uint32_t s = 0; s < sppCount; s += ctx->resultSpp) { // one job per result-ring slice
             uint32_t n = std::min(ctx->resultSpp, sppCount - s);
             {
@@ -1152,28 +1165,46 @@ int tgpu_render_pass_adaptive(tgpu_ctx *ctx, const uint32_t *vtSampleIndex, cons
     if (!ctx->uploaded) { fail(ctx, "tgpu_render_pass_adaptive before tgpu_upload_scene"); return TGPU_ERR_STATE; }
     if (!ctx->trackRecords) { fail(ctx, "tgpu_render_pass_adaptive needs settings.adaptive_sampling at upload"); return TGPU_ERR_STATE; }
     (void)streamPtr;
-    tgpu_ctx::Job job;
-    job.adaptive = true;
-    job.sppBegin = 0;
-    job.sppCount = 0;
-    job.start = 0;
-    job.ringSlot = 0;
-    job.offsets.resize(size_t(ctx->nPixels) + 1);
-    unsigned long long total = 0;
-    for (uint32_t k = 0; k < ctx->nPixels; ++k) {
-        job.offsets[k] = uint32_t(total);
-        total += vtSampleCount[ctx->vtGlobal[ctx->vtOfPixelHost[k]]];
-        if (total > ctx->st.resultSlice) { fail(ctx, "adaptive pass of %llu+ samples exceeds the result-ring slice (%u)", total, ctx->st.resultSlice); return TGPU_ERR_UNSUPPORTED; }
+    // A pass whose samples do not fit one slice of the result ring (a shard that owns the noisy tiles of the image can be handed
+    // several times its share, and spp_step may exceed 16) becomes several jobs along 16x16-tile boundaries: the pixels outside a
+    // job have an empty range in it (offset[k + 1] == offset[k]), so the per-variance-tile sample order of k_accumulate_records
+    // -- variance tiles never straddle a 16x16 tile -- is what a single job would give.
+    std::vector<tgpu_ctx::Job> jobs;
+    std::vector<uint32_t> vtIndex(ctx->vtGlobal.size());
+    for (size_t v = 0; v < ctx->vtGlobal.size(); ++v) vtIndex[v] = vtSampleIndex[ctx->vtGlobal[v]];
+    size_t t0 = 0; // first 16x16 tile of the job being filled
+    while (t0 + 1 < ctx->tileStart.size()) {
+        unsigned long long total = 0;
+        size_t t1 = t0;
+        while (t1 + 1 < ctx->tileStart.size()) {
+            unsigned long long tileTotal = 0;
+            for (uint32_t k = ctx->tileStart[t1]; k < ctx->tileStart[t1 + 1]; ++k) tileTotal += vtSampleCount[ctx->vtGlobal[ctx->vtOfPixelHost[k]]];
+            if (total + tileTotal > ctx->st.resultSlice) break;
+            total += tileTotal;
+            ++t1;
+        }
+        if (t1 == t0) { fail(ctx, "adaptive pass: one 16x16 tile alone exceeds the result-ring slice (%u samples)", ctx->st.resultSlice); return TGPU_ERR_UNSUPPORTED; }
+        if (total) {
+            tgpu_ctx::Job job;
+            job.adaptive = true;
+            job.sppBegin = 0; job.sppCount = 0; job.start = 0; job.ringSlot = 0;
+            job.offsets.resize(size_t(ctx->nPixels) + 1);
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < ctx->nPixels; ++k) {
+                job.offsets[k] = run;
+                if (k >= ctx->tileStart[t0] && k < ctx->tileStart[t1]) run += vtSampleCount[ctx->vtGlobal[ctx->vtOfPixelHost[k]]];
+            }
+            job.offsets[ctx->nPixels] = run;
+            job.total = total;
+            job.vtIndex = vtIndex;
+            jobs.push_back(std::move(job));
+        }
+        t0 = t1;
     }
-    job.offsets[ctx->nPixels] = uint32_t(total);
-    job.total = total;
-    job.vtIndex.resize(ctx->vtGlobal.size());
-    for (size_t v = 0; v < ctx->vtGlobal.size(); ++v) job.vtIndex[v] = vtSampleIndex[ctx->vtGlobal[v]];
-    if (total == 0) return TGPU_OK;
+    if (jobs.empty()) return TGPU_OK;
     {
         std::lock_guard<std::mutex> lk(ctx->mtx);
-        ctx->abortFlag = false;
-        ctx->pending.push_back(std::move(job));
+        for (tgpu_ctx::Job &j : jobs) ctx->pending.push_back(std::move(j));
         ctx->idle = false;
     }
     ctx->cvWork.notify_one();
@@ -1228,12 +1259,8 @@ int tgpu_wait(tgpu_ctx *ctx)
 int tgpu_abort(tgpu_ctx *ctx)
 {
     if (!ctx) return TGPU_ERR_INVALID;
-    bool busy;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mtx);
-        busy = !ctx->idle;
-    }
-    if (busy) ctx->abortFlag = true;
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (!ctx->idle) ctx->abortFlag = true; // the worker consumes it at its next iteration; passes queued later on are not affected by it
     return TGPU_OK;
 }
 

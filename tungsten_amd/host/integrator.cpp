@@ -1,7 +1,10 @@
 #include "integrator.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <stdexcept>
 
 namespace tungsten_amd {
@@ -34,6 +37,101 @@ void Integrator::writeBuffers(const std::string &suffix, bool /*overwrite*/)
     }
 }
 
+// the scene text without its top-level "renderer" member (the reference leaves the renderer settings out of the hash so that spp or
+// output names can change between runs, Integrator.cpp:92-106)
+static std::string withoutRenderer(const std::string &text)
+{
+    int depth = 0;
+    for (size_t i = 0; i < text.size(); ++i) {
+        char c = text[i];
+        if (c == '"') {
+            size_t end = i + 1;
+            while (end < text.size() && text[end] != '"') end += text[end] == '\\' ? 2 : 1;
+            if (depth == 1 && text.compare(i, end - i + 1, "\"renderer\"") == 0) {
+                size_t j = end + 1;
+                while (j < text.size() && text[j] != '{' && text[j] != ',' && text[j] != '}') ++j;
+                if (j < text.size() && text[j] == '{') {
+                    int d = 0;
+                    for (; j < text.size(); ++j) {
+                        if (text[j] == '"') { ++j; while (j < text.size() && text[j] != '"') j += text[j] == '\\' ? 2 : 1; }
+                        else if (text[j] == '{') ++d;
+                        else if (text[j] == '}' && --d == 0) { ++j; break; }
+                    }
+                    return text.substr(0, i) + text.substr(j);
+                }
+            }
+            i = end;
+        } else if (c == '{' || c == '[') ++depth;
+        else if (c == '}' || c == ']') --depth;
+    }
+    return text;
+}
+static uint64_t sceneHash(const Scene &scene) // BitManip::hash (math/BitManip.hpp:82-88)
+{
+    uint64_t result = 0;
+    for (char c : withoutRenderer(scene.sceneJsonText)) result = result*65599ull + uint64_t(c);
+    return result;
+}
+
+void Integrator::saveRenderResumeData()
+{
+    const std::string &path = _scene->renderer.resumeRenderFile;
+    std::ofstream out(path, std::ios::binary);
+    if (!out) {
+        std::fprintf(stderr, "Failed to open render resume state at '%s'\n", path.c_str());
+        return;
+    }
+    // rapidjson::PrettyWriter's default layout (io/JsonUtils.cpp: jsonToString): four spaces, one member per line
+    std::ostringstream header;
+    header << "{\n    \"current_spp\": " << _currentSpp << ",\n    \"adaptive_sampling\": " << (_scene->renderer.useAdaptiveSampling ? "true" : "false")
+           << ",\n    \"stratified_sampler\": " << (_scene->renderer.useSobol ? "true" : "false") << "\n}";
+    const std::string h = header.str();
+    out.write(h.c_str(), std::streamsize(h.size() + 1)); // FileUtils::streamWrite<std::string>: the characters and a NUL
+    const uint64_t hash = sceneHash(*_scene);
+    out.write(reinterpret_cast<const char *>(&hash), sizeof(hash));
+    std::vector<float> rgb;
+    std::vector<uint32_t> counts;
+    downloadOutputBuffer(rgb, counts);
+    out.write(reinterpret_cast<const char *>(rgb.data()), std::streamsize(rgb.size()*sizeof(float)));
+    out.write(reinterpret_cast<const char *>(counts.data()), std::streamsize(counts.size()*sizeof(uint32_t)));
+    saveState(out);
+}
+
+bool Integrator::resumeRender(bool *hashMismatch)
+{
+    if (hashMismatch) *hashMismatch = false;
+    std::ifstream in(_scene->renderer.resumeRenderFile, std::ios::binary);
+    if (!in) return false;
+    std::string header;
+    std::getline(in, header, '\0');
+    Json doc;
+    try {
+        doc = Json::parse(header);
+    } catch (const std::exception &) {
+        return false;
+    }
+    bool adaptiveSampling, stratifiedSampler;
+    if (!doc.getField("adaptive_sampling", adaptiveSampling) || adaptiveSampling != _scene->renderer.useAdaptiveSampling) return false;
+    if (!doc.getField("stratified_sampler", stratifiedSampler) || stratifiedSampler != _scene->renderer.useSobol) return false;
+    int jsonSpp;
+    if (!doc.getField("current_spp", jsonSpp) || jsonSpp < 0) return false;
+    uint64_t jsonHash = 0;
+    in.read(reinterpret_cast<char *>(&jsonHash), sizeof(jsonHash));
+    if (!in) return false;
+    if (jsonHash != sceneHash(*_scene) && hashMismatch) *hashMismatch = true; // see the header comment: a warning, not a refusal
+    const size_t nPixels = size_t(_scene->resX)*_scene->resY;
+    std::vector<float> rgb(nPixels*3);
+    std::vector<uint32_t> counts(nPixels);
+    in.read(reinterpret_cast<char *>(rgb.data()), std::streamsize(rgb.size()*sizeof(float)));
+    in.read(reinterpret_cast<char *>(counts.data()), std::streamsize(counts.size()*sizeof(uint32_t)));
+    if (!in) return false; // another resolution
+    if (!loadState(in)) return false;
+    uploadOutputBuffer(rgb, counts);
+    _currentSpp = uint32_t(jsonSpp);
+    advanceSpp();
+    return true;
+}
+
 void Integrator::saveOutputs() { writeBuffers("", _scene->renderer.overwriteOutputFiles); }
 void Integrator::saveCheckpoint() { writeBuffers("_checkpoint", true); }
 
@@ -48,6 +146,7 @@ void PathTraceIntegrator::prepareForRender(Scene &scene, uint32_t seed)
 {
     teardownAfterRender();
     _scene = &scene;
+    _seed = seed;
     _currentSpp = 0;
     _spp = scene.renderer.spp;
     _sppStep = std::max<uint32_t>(scene.renderer.sppStep, 1);
@@ -152,6 +251,90 @@ void PathTraceIntegrator::frameBuffer(std::vector<float> &rgb)
         for (size_t i = 0; i < d.shard.pixelIndex.size(); ++i)
             std::memcpy(&rgb[size_t(d.shard.pixelIndex[i])*3], &local[i*3], 3*sizeof(float));
     }
+}
+
+void PathTraceIntegrator::downloadOutputBuffer(std::vector<float> &rgb, std::vector<uint32_t> &counts)
+{
+    rgb.assign(size_t(_scene->resX)*_scene->resY*3, 0.0f);
+    counts.assign(size_t(_scene->resX)*_scene->resY, 0u);
+    std::vector<float> local;
+    std::vector<uint32_t> localCnt;
+    for (Device &d : _devices) {
+        local.resize(d.shard.pixelIndex.size()*3);
+        localCnt.resize(d.shard.pixelIndex.size());
+        check(d.ctx, tgpu_download(d.ctx, local.data(), localCnt.data()), "tgpu_download");
+        for (size_t i = 0; i < d.shard.pixelIndex.size(); ++i) {
+            std::memcpy(&rgb[size_t(d.shard.pixelIndex[i])*3], &local[i*3], 3*sizeof(float));
+            counts[d.shard.pixelIndex[i]] = localCnt[i];
+        }
+    }
+}
+
+void PathTraceIntegrator::uploadOutputBuffer(const std::vector<float> &rgb, const std::vector<uint32_t> &counts)
+{
+    std::vector<float> local;
+    std::vector<uint32_t> localCnt;
+    for (Device &d : _devices) {
+        local.resize(d.shard.pixelIndex.size()*3);
+        localCnt.resize(d.shard.pixelIndex.size());
+        for (size_t i = 0; i < d.shard.pixelIndex.size(); ++i) {
+            std::memcpy(&local[i*3], &rgb[size_t(d.shard.pixelIndex[i])*3], 3*sizeof(float));
+            localCnt[i] = counts[d.shard.pixelIndex[i]];
+        }
+        check(d.ctx, tgpu_upload_framebuffer(d.ctx, local.data(), localCnt.data()), "tgpu_upload_framebuffer");
+    }
+}
+
+void PathTraceIntegrator::saveState(std::ostream &out)
+{
+    if (_scene->renderer.useAdaptiveSampling) collectRecords(); // mean / variance live on the devices between passes
+    for (const SampleRecord &r : _work.samples()) {
+        // without adaptive_sampling the devices keep no SampleRecords (the reference updates them regardless but never reads
+        // them then): the counters are filled in, mean and variance stay 0
+        SampleRecord w = r;
+        if (!_scene->renderer.useAdaptiveSampling) w.sampleCount = 0;
+        out.write(reinterpret_cast<const char *>(&w.sampleCount), 4);
+        out.write(reinterpret_cast<const char *>(&w.nextSampleCount), 4);
+        out.write(reinterpret_cast<const char *>(&w.sampleIndex), 4);
+        out.write(reinterpret_cast<const char *>(&w.adaptiveWeight), 4);
+        out.write(reinterpret_cast<const char *>(&w.mean), 4);
+        out.write(reinterpret_cast<const char *>(&w.runningVariance), 4);
+    }
+    std::vector<uint32_t> seeds = tileSeeds(_scene->resX, _scene->resY, _seed);
+    for (uint32_t seed : seeds) {
+        const uint64_t state = seed; // UniformSampler(seed): _state = seed (UniformSampler.hpp:22-26)
+        if (_scene->renderer.useSobol) out.write(reinterpret_cast<const char *>(&seed), 4);
+        out.write(reinterpret_cast<const char *>(&state), 8);
+    }
+}
+
+bool PathTraceIntegrator::loadState(std::istream &in)
+{
+    std::vector<SampleRecord> records(_work.samples().size());
+    for (SampleRecord &r : records) {
+        in.read(reinterpret_cast<char *>(&r.sampleCount), 4);
+        in.read(reinterpret_cast<char *>(&r.nextSampleCount), 4);
+        in.read(reinterpret_cast<char *>(&r.sampleIndex), 4);
+        in.read(reinterpret_cast<char *>(&r.adaptiveWeight), 4);
+        in.read(reinterpret_cast<char *>(&r.mean), 4);
+        in.read(reinterpret_cast<char *>(&r.runningVariance), 4);
+    }
+    std::vector<uint32_t> seeds = tileSeeds(_scene->resX, _scene->resY, _seed);
+    for (uint32_t expect : seeds) {
+        uint32_t seed = expect;
+        uint64_t state;
+        if (_scene->renderer.useSobol) in.read(reinterpret_cast<char *>(&seed), 4);
+        in.read(reinterpret_cast<char *>(&state), 8);
+        if (!in) return false;
+        if (seed != expect) return false; // rendered with another seed: its samples do not continue this render's sequences
+    }
+    _work.samples() = records;
+    if (_scene->renderer.useAdaptiveSampling) {
+        std::vector<tgpu_sample_record> table(records.size());
+        for (size_t i = 0; i < records.size(); ++i) table[i] = tgpu_sample_record{records[i].sampleCount, records[i].mean, records[i].runningVariance};
+        for (Device &d : _devices) check(d.ctx, tgpu_upload_records(d.ctx, table.data()), "tgpu_upload_records");
+    }
+    return true;
 }
 
 std::shared_ptr<Integrator> instantiateIntegrator(const std::string &type)

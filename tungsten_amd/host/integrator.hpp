@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <functional>
+#include <iosfwd>
 #include <memory>
 #include <string>
 #include <thread>
@@ -31,6 +32,13 @@ public:
     virtual void saveOutputs();
     virtual void saveCheckpoint();
     virtual bool supportsResumeRender() const { return false; }
+    // Integrator::saveRenderResumeData / resumeRender (Integrator.cpp:108-162) on the reference's file layout: a JSON header
+    // {current_spp, adaptive_sampling, stratified_sampler} + NUL, a 64-bit scene hash, the colour buffer (RGB float32 per pixel,
+    // then uint32 sample counts), then the integrator's saveState()/loadState() block.  The hash is BitManip::hash (65599
+    // polynomial) of THIS loader's scene text without its "renderer" member -- the reference hashes its own re-serialisation of
+    // the scene, which only it can produce -- so a file written by the reference loads with a warning (`hashMismatch`), not an error.
+    void saveRenderResumeData();
+    bool resumeRender(bool *hashMismatch = nullptr);
 
     bool done() const { return _currentSpp >= _spp; }       // Integrator.hpp:52-55
     uint32_t currentSpp() const { return _currentSpp; }
@@ -38,8 +46,13 @@ public:
 
     // Camera::colorBuffer() contents in image order (what the reference reads through Camera::getLinear)
     virtual void frameBuffer(std::vector<float> &rgb) = 0;
+    // OutputBuffer::_bufferA / _sampleCount in image order, out and back in (serialize / deserialize, OutputBuffer.hpp:191-211)
+    virtual void downloadOutputBuffer(std::vector<float> &rgb, std::vector<uint32_t> &counts) = 0;
+    virtual void uploadOutputBuffer(const std::vector<float> &rgb, const std::vector<uint32_t> &counts) = 0;
 
 protected:
+    virtual void saveState(std::ostream &out) = 0;  // Integrator.hpp:33-34
+    virtual bool loadState(std::istream &in) = 0;
     void advanceSpp() { _nextSpp = std::min(_currentSpp + _sppStep, _spp); } // Integrator.cpp:51-54
     void writeBuffers(const std::string &suffix, bool overwrite);             // Integrator.cpp:56-80
 
@@ -61,6 +74,9 @@ public:
     void waitForCompletion() override;                             // :241-247 (rethrows worker errors)
     void abortRender() override;                                   // :249-256
     void frameBuffer(std::vector<float> &rgb) override;
+    void downloadOutputBuffer(std::vector<float> &rgb, std::vector<uint32_t> &counts) override;
+    void uploadOutputBuffer(const std::vector<float> &rgb, const std::vector<uint32_t> &counts) override;
+    bool supportsResumeRender() const override { return true; }
 
     // SampleRecords (adaptive.hpp), one per 4x4 variance tile of the whole image
     const std::vector<SampleRecord> &sampleRecords() const { return _work.samples(); }
@@ -69,8 +85,17 @@ public:
     // other ranks' tiles (an all-reduce/all-gather; tungsten_amd/dist.py does it over torch.distributed).
     std::function<void(std::vector<tgpu_sample_record> &)> recordExchange;
 
+protected:
+    // PathTraceIntegrator::saveState / loadState (PathTraceIntegrator.cpp:158-172): the SampleRecords (24 bytes each, SampleRecord.hpp:24-32),
+    // then per 16x16 tile the sampler state -- {seed, PCG state} of a SobolPathSampler (SobolPathSampler.hpp:35-45), the PCG state
+    // alone of a UniformPathSampler.  The supplemental stream of this core is path-local, so the PCG states carry no information
+    // here: the tile's initial state is written, what a file holds is ignored.
+    void saveState(std::ostream &out) override;
+    bool loadState(std::istream &in) override;
+
 private:
     void collectRecords();
+    uint32_t _seed = 0;
 
     AdaptiveScheduler _work;
 

@@ -949,10 +949,10 @@ void Scene::parseCamera(const Json &v)
     v.getField("fov", fovDeg);
 }
 
-Scene Scene::load(const std::string &jsonPath)
+Scene Scene::load(const std::string &jsonPath, const std::string &inputDirectory)
 {
     Scene s;
-    s.sceneDir = dirName(jsonPath);
+    s.sceneDir = inputDirectory.empty() ? dirName(jsonPath) : inputDirectory;
     s.sceneJsonText = readFile(jsonPath);
     Json root = Json::parse(s.sceneJsonText);
 
@@ -1450,6 +1450,15 @@ void Scene::flatten()
 // ---------------------------------------------------------------------------
 // shard
 // ---------------------------------------------------------------------------
+std::vector<uint32_t> tileSeeds(uint32_t resX, uint32_t resY, uint32_t seed)
+{
+    std::vector<uint32_t> seeds;
+    Pcg32 sampler(hash32(seed));
+    for (uint32_t y = 0; y < resY; y += 16)
+        for (uint32_t x = 0; x < resX; x += 16) seeds.push_back(hash32(sampler.nextI()));
+    return seeds;
+}
+
 Shard makeShard(uint32_t resX, uint32_t resY, uint32_t seed, uint32_t rank, uint32_t world)
 {
     const uint32_t TileSize = 16;

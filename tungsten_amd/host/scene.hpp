@@ -43,7 +43,8 @@ struct MeshData {
 class Scene {
 public:
     // Scene::load (Scene.cpp:378-391). Throws JsonLoadException / std::runtime_error.
-    static Scene load(const std::string &jsonPath);
+    // inputDirectory: where relative resource paths are resolved (the CLI's -i; default: the scene file's directory, Shared.hpp:205)
+    static Scene load(const std::string &jsonPath, const std::string &inputDirectory = std::string());
 
     // CLI-style overrides applied before flatten() (Shared.hpp:221-248)
     void setResolution(uint32_t w, uint32_t h);
@@ -144,6 +145,8 @@ struct Shard {
     }
 };
 Shard makeShard(uint32_t resX, uint32_t resY, uint32_t seed, uint32_t rank, uint32_t world);
+// the seeds diceTiles draws for the 16x16 tiles, row-major (PathTraceIntegrator.cpp:27-42)
+std::vector<uint32_t> tileSeeds(uint32_t resX, uint32_t resY, uint32_t seed);
 
 // UniformSampler / hash32 restated for seeding (UniformSampler.hpp:40-52, MathUtil.hpp:120-128)
 uint32_t hash32(uint32_t x);

@@ -352,4 +352,48 @@ private:
     Bvh4 *_out = nullptr;
 };
 
+// Renumber the nodes of a BVH4 so that the top `levels` levels (root = level 0) come first, in breadth-first order: those are the
+// nodes the traversal kernels may stage in LDS ("nodelets").  Returns how many nodes the top levels hold.
+inline uint32_t reorderTopLevels(Bvh4 &b, int levels)
+{
+    if (b.rootChild & 0x80000000u) return 0; // the root is a leaf: no inner nodes
+    auto bitsOf = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto floatOf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    const uint32_t n = uint32_t(b.nodes.size()/4);
+    std::vector<uint32_t> order; // new index -> old index
+    std::vector<uint32_t> frontier = {b.rootChild};
+    for (int l = 0; l < levels && !frontier.empty(); ++l) {
+        std::vector<uint32_t> next;
+        for (uint32_t node : frontier) {
+            order.push_back(node);
+            const Float4 &q3 = b.nodes[size_t(node)*4 + 3];
+            const float c[4] = {q3.x, q3.y, q3.z, q3.w};
+            for (float f : c) {
+                uint32_t ref = bitsOf(f);
+                if (ref != 0xFFFFFFFFu && !(ref & 0x80000000u)) next.push_back(ref);
+            }
+        }
+        frontier.swap(next);
+    }
+    const uint32_t top = uint32_t(order.size());
+    std::vector<uint32_t> newIndex(n, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < top; ++i) newIndex[order[i]] = i;
+    uint32_t nextFree = top;
+    for (uint32_t old = 0; old < n; ++old)
+        if (newIndex[old] == 0xFFFFFFFFu) { newIndex[old] = nextFree++; order.push_back(old); }
+    std::vector<Float4> nodes(b.nodes.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) nodes[size_t(i)*4 + k] = b.nodes[size_t(order[i])*4 + k];
+        Float4 &q3 = nodes[size_t(i)*4 + 3];
+        float *c[4] = {&q3.x, &q3.y, &q3.z, &q3.w};
+        for (float *f : c) {
+            uint32_t ref = bitsOf(*f);
+            if (ref != 0xFFFFFFFFu && !(ref & 0x80000000u)) *f = floatOf(newIndex[ref]);
+        }
+    }
+    b.nodes.swap(nodes);
+    b.rootChild = newIndex[b.rootChild];
+    return top;
+}
+
 } // namespace tgpu_bvh

@@ -117,6 +117,9 @@ struct DScene {
     uint32_t nTris;
     int32_t stackEntries;       // worst-case traversal stack depth (3 pushes per BVH4 level)
     int32_t stackLds;           // levels kept in LDS; the rest spills to stackSpill[level - stackLds][global thread]
+    uint32_t ldsNodes;          // nodes [0, ldsNodes) of `nodes` (the top levels of the scene's BVH4, breadth first) are staged in LDS by the kernel
+                                // this copy of the scene is launched with (0: none); ldsNodeWord: their offset in the dynamic LDS block, in words
+    uint32_t ldsNodeWord;
     int32_t topStackLds;        // scenes with "instances": entries of the (node, tMin) stack of the top-level walk, in LDS behind the levels above
     uint32_t spillStride;       // threads of the largest grid
     uint32_t *stackSpill;

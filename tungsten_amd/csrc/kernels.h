@@ -675,11 +675,30 @@ TG_DEV int travApply(const DScene &sc, uint32_t *stack, TravState &r, TraceCount
     node = stackPop(sc, stack, sp);
     return TRAV_MORE;
 }
+// LDS "nodelets" (BASELINE north_star): the kernel a scene copy with ldsNodes != 0 is launched with has copied the first ldsNodes
+// nodes (the top levels of the BVH4, breadth first: bvh_build.h, reorderTopLevels) behind its traversal stacks; a lane whose next
+// record is one of them reads it from LDS (~50 cycles) instead of L2 (~200).  Measured: profiles/r02_ab_notes.txt.
+TG_DEV void stageNodelets(const DScene &sc)
+{
+    extern __shared__ uint32_t ldsStack[];
+    if (sc.ldsNodes) {
+        float4 *dst = reinterpret_cast<float4 *>(ldsStack + sc.ldsNodeWord);
+        for (uint32_t i = threadIdx.x; i < sc.ldsNodes*4u; i += blockDim.x) dst[i] = sc.nodes[i];
+        __syncthreads();
+    }
+}
 template <bool ANY, bool COUNT, bool SORTED = true>
 TG_DEV int travStep(const DScene &sc, uint32_t *stack, TravState &r, TraceCounters &tc)
 {
-    const float4 *n = travItem(sc, r);
-    const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+    extern __shared__ uint32_t ldsStack[];
+    float4 q0, q1, q2, q3;
+    if (r.node < sc.ldsNodes) { // never true for a leaf reference (bit 31) nor when nothing is staged
+        const float4 *n = reinterpret_cast<const float4 *>(ldsStack + sc.ldsNodeWord) + size_t(r.node)*4;
+        q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3];
+    } else {
+        const float4 *n = travItem(sc, r);
+        q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3];
+    }
     return travApply<ANY, COUNT, SORTED>(sc, stack, r, tc, q0, q1, q2, q3);
 }
 
@@ -1363,6 +1382,7 @@ __global__ void __launch_bounds__(256, (DEPTH > 4 ? TG_EXTQ_WAVES_DEEP : TG_EXTQ
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    stageNodelets(sc);
     const ListCounts lc = loadListCounts(st, set);
     const uint32_t count = listTotal(lc, 0);
     TraceCounters tc{0, 0};
@@ -2750,6 +2770,7 @@ __global__ void __launch_bounds__(256, TG_SHADOWQ_WAVES) k_shadow_q(DScene sc, D
     uint32_t *stack = ldsStack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+    stageNodelets(sc);
     const ListCounts lc = loadListCounts(st, set);
     const uint32_t count = listTotal(lc, 1); // every shaded slot
     TraceCounters tc{0, 0};

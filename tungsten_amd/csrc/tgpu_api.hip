@@ -93,6 +93,7 @@ struct tgpu_ctx {
     int numCUs = 256;
     int maxGrid = 2048;
     int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
+    uint32_t nodeletCount = 0;   // nodes of the top BVH4 levels staged in LDS by the queue kernels (TGPU_LDS_NODELETS)
     bool instExtendQueue = false; // TGPU_INST_EXTEND_Q=1: k_extend_iq + k_classify for scenes with instances / spheres / disks (A/B)
     int shadowQueue = 4;        // vertices (= 2 rays each) per lane of the shadow kernel's queue form: 4 or 8; TGPU_SHADOW_Q=0: k_shadow (A/B)
     size_t ldsBytes = 0;
@@ -400,10 +401,15 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     int maxDepth4 = 0;
     // appends one BVH over triangles [first, first + count) and returns its root child reference
     const float triPad = tgpu_bvh_pad(s); // include/tgpu_bounds.h
+    // TGPU_LDS_NODELETS=L: stage the top L levels of the scene's BVH4 (1 + 4 + 16 + ... nodes) in LDS in the queue kernels (A/B; default off:
+    // no gain measured, profiles/r02_ab_notes.txt)
+    const int nodeletLevels = getenv("TGPU_LDS_NODELETS") ? std::min(std::max(atoi(getenv("TGPU_LDS_NODELETS")), 0), 5) : 0;
+    uint32_t nodeletCount = 0;
     auto appendBvh = [&](uint32_t first, uint32_t count, const char *what) -> uint32_t {
         tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count, triPad);
         tgpu_bvh::Bvh bvh = builder.build();
         tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run(); // the quantised BVH4 the kernels traverse (bvh_build.h)
+        if (first == 0 && nodeletLevels > 0) nodeletCount = tgpu_bvh::reorderTopLevels(bvh4, nodeletLevels); // the scene's own BVH only
         const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/4);
         auto rebase = [&](uint32_t ref) -> uint32_t {
             if (ref == 0xFFFFFFFFu) return ref;                               // empty slot
@@ -527,6 +533,9 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         sc.stackSpill = dSpill;
     }
     ctx->ldsBytes = size_t(sc.stackLds)*256*sizeof(uint32_t) + size_t(sc.topStackLds)*256*2*sizeof(uint32_t);
+    sc.ldsNodes = 0; // the scene copy of the queue kernels' launches carries the real count (driveIteration)
+    sc.ldsNodeWord = uint32_t(ctx->ldsBytes/sizeof(uint32_t));
+    ctx->nodeletCount = nodeletCount;
 
     // ---- shading records ----
     std::vector<tgpu_bvh::Float4> shade(size_t(nAllTris)*5);
@@ -938,12 +947,15 @@ static int driveIteration(tgpu_ctx *ctx)
                 if (count) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
                 else hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
             } else {
+                DScene scq = sc; // the queue kernels' copy: with the LDS nodelets, if any
+                scq.ldsNodes = ctx->nodeletCount;
+                const size_t ldsQ = ctx->ldsBytes + size_t(ctx->nodeletCount)*64;
                 if (ctx->extendQueue == 8) { // queue form: eight (or four) rays per lane (kernels.h, k_extend_q)
-                    if (count) hipLaunchKernelGGL((k_extend_q<true, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-                    else hipLaunchKernelGGL((k_extend_q<false, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                    if (count) hipLaunchKernelGGL((k_extend_q<true, 8>), dim3(grid), dim3(256), ldsQ, stream, scq, st, cur);
+                    else hipLaunchKernelGGL((k_extend_q<false, 8>), dim3(grid), dim3(256), ldsQ, stream, scq, st, cur);
                 } else if (ctx->extendQueue) {
-                    if (count) hipLaunchKernelGGL((k_extend_q<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
-                    else hipLaunchKernelGGL((k_extend_q<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur);
+                    if (count) hipLaunchKernelGGL((k_extend_q<true, 4>), dim3(grid), dim3(256), ldsQ, stream, scq, st, cur);
+                    else hipLaunchKernelGGL((k_extend_q<false, 4>), dim3(grid), dim3(256), ldsQ, stream, scq, st, cur);
                 } else if (count) hipLaunchKernelGGL((k_extend<true, false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
                 else hipLaunchKernelGGL((k_extend<false, false, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, 0u);
             }
@@ -968,12 +980,15 @@ static int driveIteration(tgpu_ctx *ctx)
                 if (count) hipLaunchKernelGGL((k_shadow_iq<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
                 else hipLaunchKernelGGL((k_shadow_iq<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
             } else if (shadowQ) {
+                DScene scq = sc;
+                scq.ldsNodes = ctx->nodeletCount;
+                const size_t ldsQ = ctx->ldsBytes + size_t(ctx->nodeletCount)*64;
                 if (ctx->shadowQueue == 8) {
-                    if (count) hipLaunchKernelGGL((k_shadow_q<true, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
-                    else hipLaunchKernelGGL((k_shadow_q<false, 8>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                    if (count) hipLaunchKernelGGL((k_shadow_q<true, 8>), dim3(grid), dim3(256), ldsQ, stream, scq, st, out);
+                    else hipLaunchKernelGGL((k_shadow_q<false, 8>), dim3(grid), dim3(256), ldsQ, stream, scq, st, out);
                 } else {
-                    if (count) hipLaunchKernelGGL((k_shadow_q<true, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
-                    else hipLaunchKernelGGL((k_shadow_q<false, 4>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, out);
+                    if (count) hipLaunchKernelGGL((k_shadow_q<true, 4>), dim3(grid), dim3(256), ldsQ, stream, scq, st, out);
+                    else hipLaunchKernelGGL((k_shadow_q<false, 4>), dim3(grid), dim3(256), ldsQ, stream, scq, st, out);
                 }
             } else {
             const int variant = (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);

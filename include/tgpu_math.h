@@ -131,6 +131,16 @@ TGPU_HD float tgpu_logf(float x)
     return r;
 }
 
+/* tan(x) = sin/cos of the same reduction (<= 4 ulp away from the poles); pow(x, y) = exp(y*log(x)) for x > 0 (x == 0: 0 for y > 0,
+ * 1 for y == 0): relative error ~ |y log x| ulp -- both are used by the Oren-Nayar and Phong BSDFs only, identically on CPU and GPU. */
+TGPU_HD float tgpu_tanf(float x) { float s, c; tgpu_sincosf(x, &s, &c); return s/c; }
+TGPU_HD float tgpu_powf(float x, float y)
+{
+    if (y == 0.0f) return 1.0f;
+    if (x == 0.0f) return y > 0.0f ? 0.0f : tgpu_bits_to_float(0x7F800000u);
+    return tgpu_expf(y*tgpu_logf(x));
+}
+
 /* atan(x) for any finite x */
 TGPU_HD float tgpu_atanf(float x)
 {

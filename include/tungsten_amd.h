@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGPU_ABI_VERSION 2
+#define TGPU_ABI_VERSION 3
 
 typedef enum tgpu_status {
     TGPU_OK = 0,
@@ -74,7 +74,13 @@ enum {
     TGPU_BSDF_CONDUCTOR = 8,        /* ConductorBsdf.cpp:53-90 (eta, k)  */
     TGPU_BSDF_PLASTIC = 9,          /* PlasticBsdf.cpp:45-195 (ior, thickness, sigma_a) */
     TGPU_BSDF_ROUGH_PLASTIC = 10,   /* RoughPlasticBsdf.cpp:55-260 (+ distribution, roughness) */
-    TGPU_BSDF_NUM_TYPES = 11
+    TGPU_BSDF_OREN_NAYAR = 11,      /* OrenNayarBsdf.cpp:41-98 (roughness)   */
+    TGPU_BSDF_PHONG = 12,           /* PhongBsdf.cpp:39-131 (exponent, diffuse_ratio) */
+    TGPU_BSDF_MIXED = 13,           /* MixedBsdf.cpp:72-136: substrate = bsdf0, aux_bsdf = bsdf1, aux_tex = ratio */
+    TGPU_BSDF_ROUGH_COAT = 14,      /* RoughCoatBsdf.cpp:47-307: substrate, ior, thickness, sigma_a, distribution, roughness */
+    TGPU_BSDF_TRANSPARENCY = 15,    /* TransparencyBsdf.cpp:42-69: substrate = base, aux_tex = alpha (opacity) */
+    TGPU_BSDF_THINSHEET = 16,       /* ThinSheetBsdf.cpp:50-120: ior, sigma_a, aux_tex = thickness; enable_interference is out of scope */
+    TGPU_BSDF_NUM_TYPES = 17
 };
 enum { TGPU_DIST_BECKMANN = 0, TGPU_DIST_PHONG = 1, TGPU_DIST_GGX = 2 };
 
@@ -93,6 +99,10 @@ typedef struct tgpu_bsdf {
     int32_t enable_refraction;   /* rough_dielectric "enable_refraction" (default 1)  */
     float   diffuse_fresnel;     /* plastics: Fresnel::computeDiffuseFresnel(ior, 1000000) (Fresnel.hpp:141-153) */
     float   substrate_weight;    /* rough_plastic: albedo->average().avg() (RoughPlasticBsdf.cpp:252-258) */
+    float   exponent;            /* phong "exponent" (default 64)                                        */
+    float   diffuse_ratio;       /* phong "diffuse_ratio" (default 0.2)                                  */
+    int32_t aux_bsdf;            /* mixed: bsdf1                                                         */
+    int32_t aux_tex;             /* mixed: ratio; transparency: alpha; thinsheet: thickness               */
 } tgpu_bsdf;
 
 /* ---- participating media (src/core/media) ------------------------------- */
@@ -208,6 +218,30 @@ typedef struct tgpu_settings {
     int32_t enable_volume_light_sampling; /* PathTracerSettings.hpp:14-27 (default 1) */
 } tgpu_settings;
 
+/* renderer "output_buffers" (cameras/OutputBufferSettings.hpp:13-19, Camera.cpp:148-166): the colour buffer and the four
+ * auxiliary buffers the path tracer feeds when they are requested (PathTracer.cpp:78-96,133-140).  Every buffer is an
+ * OutputBuffer<float | Vec3f> (cameras/OutputBuffer.hpp): a running mean per pixel, optionally split over two half
+ * buffers (two_buffer_variance) and with Welford variance sums (sample_variance), plus a sample count per pixel. */
+typedef enum tgpu_output_type {
+    TGPU_OUTPUT_COLOR = 0,      /* 3 channels; always present                                      */
+    TGPU_OUTPUT_DEPTH = 1,      /* 1 channel : distance along the path to the first non-specular hit */
+    TGPU_OUTPUT_NORMAL = 2,     /* 3 channels: shading normal there (-ray.dir() for escaped paths)  */
+    TGPU_OUTPUT_ALBEDO = 3,     /* 3 channels: BSDF albedo (+ emission) there                       */
+    TGPU_OUTPUT_VISIBILITY = 4, /* 1 channel : mean transmittance of that vertex' light sample       */
+    TGPU_OUTPUT_COUNT = 5
+} tgpu_output_type;
+typedef enum tgpu_output_part {
+    TGPU_PART_A = 0,        /* _bufferA: the mean (of the even samples with two_buffer_variance)   */
+    TGPU_PART_B = 1,        /* _bufferB: mean of the odd samples (two_buffer_variance only)          */
+    TGPU_PART_VARIANCE = 2, /* _variance: running sum of squared deviations (sample_variance only) */
+    TGPU_PART_COUNT = 3     /* _sampleCount: uint32 per pixel                                      */
+} tgpu_output_part;
+typedef struct tgpu_output_buffer {
+    int32_t enabled;              /* ignored for TGPU_OUTPUT_COLOR */
+    int32_t two_buffer_variance;
+    int32_t sample_variance;
+} tgpu_output_buffer;
+
 /* A light is an emissive, samplable primitive, in scene order
  * (TraceableScene.hpp:86-102).                                              */
 enum { TGPU_LIGHT_ENV = 0, TGPU_LIGHT_QUAD = 1, TGPU_LIGHT_SPHERE = 2, TGPU_LIGHT_DISK = 3 };
@@ -246,6 +280,7 @@ typedef struct tgpu_scene_desc {
 
     tgpu_camera   camera;
     tgpu_settings settings;
+    tgpu_output_buffer output_buffers[TGPU_OUTPUT_COUNT]; /* indexed by tgpu_output_type */
 
     /* triangle soup: every mesh baked to world space (TriangleMesh.cpp:542-552) */
     uint32_t       n_tris;
@@ -354,6 +389,12 @@ int tgpu_download(tgpu_ctx *ctx, float *rgb_mean, uint32_t *sample_count);
 int tgpu_resolve_to_device(tgpu_ctx *ctx, void *device_rgb, void *stream);
 /* Integrator::resumeRender support: restore running means + counts.          */
 int tgpu_upload_framebuffer(tgpu_ctx *ctx, const float *rgb_mean, const uint32_t *sample_count);
+
+/* Any part of any requested output buffer (Camera::depthBuffer() ... / OutputBuffer::serialize, OutputBuffer.hpp:206-226), shard
+ * order, host memory: n_pixels*channels floats for parts A, B and VARIANCE, n_pixels uint32 for part COUNT.  Asking for a buffer
+ * or part that was not requested at upload is TGPU_ERR_INVALID.  TGPU_OUTPUT_COLOR / A and COUNT are what tgpu_download returns. */
+int tgpu_download_output_buffer(tgpu_ctx *ctx, int type, int part, void *dst);
+int tgpu_upload_output_buffer(tgpu_ctx *ctx, int type, int part, const void *src);
 
 /* Ray-level entry points used by the parity tests (TraceableScene::intersect /
  * generalizedShadowRay on dumped ray batches).  rays: n*8 floats

@@ -63,6 +63,7 @@ struct V3 {
     V3 &operator*=(float s) { x *= s; y *= s; z *= s; return *this; }
     V3 &operator/=(float s) { x /= s; y /= s; z /= s; return *this; }
     bool operator==(float s) const { return x == s && y == s && z == s; }
+    bool operator!=(float s) const { return x != s || y != s || z != s; }
     float dot(const V3 &o) const { float s = x*o.x; s += y*o.y; s += z*o.z; return s; }
     float lengthSq() const { float r = 0.0f; r += x*x; r += y*y; r += z*z; return r; }
     float length() const { return std::sqrt(lengthSq()); }
@@ -230,6 +231,14 @@ struct Event { // samplerecords/SurfaceScatterEvent.hpp:14-66
 struct LightSample { V3 d; float dist, pdf; };
 } // namespace
 // media/Medium.hpp:30-47, samplerecords/MediumSample.hpp
+// What one sample contributes to the auxiliary output buffers (PathTracer.cpp:78-96,133-140).  NaN = no sample for that buffer
+// (OutputBuffer::addSample drops NaN and infinite values anyway, cameras/OutputBuffer.hpp:106-107).
+struct AovSample {
+    float depth = std::numeric_limits<float>::quiet_NaN();
+    V3 normal = V3(std::numeric_limits<float>::quiet_NaN());
+    V3 albedo = V3(std::numeric_limits<float>::quiet_NaN());
+    float visibility = std::numeric_limits<float>::quiet_NaN();
+};
 struct MediumStateO { bool firstScatter; int bounce; void reset() { firstScatter = true; bounce = 0; } void advance() { firstScatter = false; bounce++; } };
 struct MediumSampleO { V3 p; float t; V3 weight, emission; float pdf; bool exited; };
 namespace {
@@ -260,8 +269,12 @@ struct oracle_ctx {
     float mlog(float x) const { return mathMode ? tgpu_logf(x) : std::log(x); }
     float matan2(float y, float x) const { return mathMode ? tgpu_atan2f(y, x) : std::atan2(y, x); }
     float macos(float x) const { return mathMode ? tgpu_acosf(x) : std::acos(x); }
+    float mtan(float x) const { return mathMode ? tgpu_tanf(x) : std::tan(x); }
+    float mpow(float x, float y) const { return mathMode ? tgpu_powf(x, y) : std::pow(x, y); }
 
     struct Counters { uint64_t extend = 0, shadow = 0, surface = 0, nodes = 0, tris = 0, samples = 0; };
+    oracle_outbuf out[TGPU_OUTPUT_COUNT] = {}; // output buffers bound by the test (oracle_bind_output_buffers)
+    bool trackOutputs = false;
 
     // ---- BVH ---------------------------------------------------------------------------
     std::unique_ptr<oracle_instances> inst;
@@ -305,10 +318,11 @@ struct oracle_ctx {
     // ---- integrator --------------------------------------------------------------------
     Event makeLocalScatterEvent(const Temp &data, const Info &info, const Ray &ray, Sampler *sampler) const;
     V3 shadowRay(Ray &ray, int medium, int endKind, uint32_t endIndex, int bounce, bool startsOnSurface, bool endsOnSurface, Counters &c) const;
-    V3 attenuatedEmission(const tgpu_light &l, int medium, float expectedDist, Temp &data, Info &info, int bounce, bool startsOnSurface, Ray &ray, Counters &c) const;
-    V3 lightSample(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
+    V3 attenuatedEmission(const tgpu_light &l, int medium, float expectedDist, Temp &data, Info &info, int bounce, bool startsOnSurface, Ray &ray, Counters &c,
+                          V3 *transmittance = nullptr) const;
+    V3 lightSample(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c, V3 *transmittance = nullptr) const;
     V3 bsdfSampleNee(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
-    V3 estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c) const;
+    V3 estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c, V3 *transmittance = nullptr) const;
     const tgpu_light *chooseLight(const V3 &p, Sampler &sampler, float &weight) const;
     // RoughDielectricBsdf::sampleBase/evalBase/pdfBase (static helpers shared with RoughPlasticBsdf)
     bool rdSampleBase(Event &e, bool sampleR, bool sampleT, float roughness, float ior, int distribution) const;
@@ -332,8 +346,8 @@ struct oracle_ctx {
     float expA, expB;
     void buildExpTable();
     bool handleSurface(Event &event, Temp &data, Info &info, int &medium, int bounce, bool enableLightSampling, Ray &ray,
-                       V3 &throughput, V3 &emission, bool &wasSpecular, struct MediumStateO &state, Counters &c) const;
-    V3 traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c) const;
+                       V3 &throughput, V3 &emission, bool &wasSpecular, struct MediumStateO &state, Counters &c, V3 *transmittance = nullptr) const;
+    V3 traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c, struct AovSample *aov = nullptr) const;
     void cameraRay(uint32_t px, uint32_t py, float xi0, float xi1, Ray &ray) const;
 };
 
@@ -1534,7 +1548,13 @@ uint32_t oracle_ctx::bsdfLobes(int b) const
     switch (d.type) {
     case TGPU_BSDF_LAMBERT: return DiffuseReflectionLobe;
     case TGPU_BSDF_ROUGH_CONDUCTOR: return GlossyReflectionLobe;
+    case TGPU_BSDF_OREN_NAYAR: return DiffuseReflectionLobe;                            // OrenNayarBsdf.cpp:20
+    case TGPU_BSDF_PHONG: return GlossyReflectionLobe | DiffuseReflectionLobe;          // PhongBsdf.cpp:126
     case TGPU_BSDF_SMOOTH_COAT: return SpecularReflectionLobe | bsdfLobes(d.substrate);
+    case TGPU_BSDF_MIXED: return bsdfLobes(d.substrate) | bsdfLobes(d.aux_bsdf);         // MixedBsdf.cpp:133-136
+    case TGPU_BSDF_ROUGH_COAT: return GlossyReflectionLobe | bsdfLobes(d.substrate);      // RoughCoatBsdf.cpp:304
+    case TGPU_BSDF_TRANSPARENCY: return ForwardLobe | bsdfLobes(d.substrate);             // TransparencyBsdf.cpp:66-69
+    case TGPU_BSDF_THINSHEET: return SpecularReflectionLobe | ForwardLobe;                // ThinSheetBsdf.cpp:24
     case TGPU_BSDF_FORWARD: return ForwardLobe; // ForwardBsdf.cpp:9-12
     case TGPU_BSDF_MIRROR: case TGPU_BSDF_CONDUCTOR: return SpecularReflectionLobe;
     case TGPU_BSDF_PLASTIC: return SpecularReflectionLobe | DiffuseReflectionLobe;     // PlasticBsdf.cpp:19-24
@@ -1634,6 +1654,18 @@ inline float dielectricReflectance(float eta, float cosThetaI, float &cosThetaT)
     float Rs = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT);
     float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
     return (Rs*Rs + Rp*Rp)*0.5f;
+}
+inline float thinFilmReflectance(float eta, float cosThetaI, float &cosThetaT) // bsdfs/Fresnel.hpp:15-28
+{
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    cosThetaT = std::sqrt(fmax2(1.0f - sinThetaTSq, 0.0f));
+    float a = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT), b = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
+    float Rs = a*a, Rp = b*b;
+    return 1.0f - ((1.0f - Rs)/(1.0f + Rs) + (1.0f - Rp)/(1.0f + Rp))*0.5f;
 }
 inline float sgnE(float v) { return v < 0.0f ? -1.0f : 1.0f; } // RoughDielectricBsdf.cpp:13-17
 // Bsdf::eval/sample(event, adjoint = false) multiply by sqr(eta(event)) (Bsdf.hpp:71-97, RoughDielectricBsdf.cpp:266-272)
@@ -1770,6 +1802,45 @@ V3 oracle_ctx::bsdfEval(int b, const Event &e) const
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
         return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*INV_PI*e.wo.z;
     }
+    case TGPU_BSDF_OREN_NAYAR: { // bsdfs/OrenNayarBsdf.cpp:63-98
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return V3(0.0f);
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        const V3 &wi = e.wi, &wo = e.wo;
+        float thetaR = macos(wo.z);
+        float thetaI = macos(wi.z);
+        float alpha = fmax2(thetaR, thetaI);
+        float beta = fmin2(thetaR, thetaI);
+        float sinAlpha = msin(alpha);
+        float denom = (wi.x*wi.x + wi.y*wi.y)*(wo.x*wo.x + wo.y*wo.y);
+        float cosDeltaPhi = denom == 0.0f ? 1.0f : (wi.x*wo.x + wi.y*wo.y)/std::sqrt(denom);
+        const float RoughnessToSigma = 1.0f/std::sqrt(2.0f);
+        float sigma = RoughnessToSigma*texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float sigmaSq = sigma*sigma;
+        float C1 = 1.0f - 0.5f*sigmaSq/(sigmaSq + 0.33f);
+        float C2 = 0.45f*sigmaSq/(sigmaSq + 0.09f);
+        auto cube = [](float x) { return x*x*x; };
+        auto sqr = [](float x) { return x*x; };
+        if (cosDeltaPhi >= 0.0f) C2 *= sinAlpha;
+        else C2 *= sinAlpha - cube((2.0f*INV_PI)*beta);
+        float C3 = 0.125f*(sigmaSq/(sigmaSq + 0.09f))*sqr((4.0f*INV_PI*INV_PI)*alpha*beta);
+        float fr1 = (C1 + cosDeltaPhi*C2*mtan(beta) + (1.0f - std::abs(cosDeltaPhi))*C3*mtan(0.5f*(alpha + beta)));
+        float fr2 = 0.17f*sigmaSq/(sigmaSq + 0.13f)*(1.0f - cosDeltaPhi*sqr((2.0f*INV_PI)*beta));
+        V3 diffuseAlbedo = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        return (diffuseAlbedo*fr1 + diffuseAlbedo*diffuseAlbedo*fr2)*wo.z*INV_PI;
+    }
+    case TGPU_BSDF_PHONG: { // bsdfs/PhongBsdf.cpp:79-100 ; factors of prepareForRender :123-131
+        bool evalGlossy = (e.requestedLobe & GlossyReflectionLobe) != 0, evalDiffuse = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!evalGlossy && !evalDiffuse) return V3(0.0f);
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        const float brdfFactor = (d.exponent + 2.0f)*INV_TWO_PI;
+        float result = 0.0f;
+        if (evalDiffuse) result += d.diffuse_ratio*INV_PI;
+        if (evalGlossy) {
+            float cosTheta = V3(-e.wi.x, -e.wi.y, e.wi.z).dot(e.wo);
+            if (cosTheta > 0.0f) result += mpow(cosTheta, d.exponent)*brdfFactor*(1.0f - d.diffuse_ratio);
+        }
+        return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*e.wo.z*result;
+    }
     case TGPU_BSDF_ROUGH_CONDUCTOR: { // bsdfs/RoughConductorBsdf.cpp:93-110
         if (!(e.requestedLobe & GlossyReflectionLobe)) return V3(0.0f);
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
@@ -1883,6 +1954,56 @@ V3 oracle_ctx::bsdfEval(int b, const Event &e) const
         f *= dielectricEtaSq(d.ior, e.wi, e.wo);
         return f;
     }
+    case TGPU_BSDF_MIXED: { // bsdfs/MixedBsdf.cpp:104-108
+        float ratio = texEval(d.aux_tex, e.info->uvx, e.info->uvy).x;
+        return texEval(d.albedo_tex, e.info->uvx, e.info->uvy)*(bsdfEval(d.substrate, e)*ratio + bsdfEval(d.aux_bsdf, e)*(1.0f - ratio));
+    }
+    case TGPU_BSDF_TRANSPARENCY: { // bsdfs/TransparencyBsdf.cpp:47-53 ; BsdfLobes::isForward(): exactly the forward lobe
+        if (e.requestedLobe == uint32_t(ForwardLobe)) {
+            V3 nwi = -e.wi;
+            return (nwi.x == e.wo.x && nwi.y == e.wo.y && nwi.z == e.wo.z) ? V3(1.0f - texEval(d.aux_tex, e.info->uvx, e.info->uvy).x) : V3(0.0f);
+        }
+        return bsdfEval(d.substrate, e);
+    }
+    case TGPU_BSDF_THINSHEET: { // bsdfs/ThinSheetBsdf.cpp:83-103 (enable_interference off), Fresnel::thinFilmReflectance (Fresnel.hpp:15-28)
+        V3 nwi = -e.wi;
+        if (e.requestedLobe != uint32_t(ForwardLobe) || !(nwi.x == e.wo.x && nwi.y == e.wo.y && nwi.z == e.wo.z)) return V3(0.0f);
+        float thickness = texEval(d.aux_tex, e.info->uvx, e.info->uvy).x;
+        float cosThetaT;
+        V3 transmittance(1.0f - thinFilmReflectance(1.0f/d.ior, std::abs(e.wi.z), cosThetaT));
+        V3 sigmaA(d.sigma_a);
+        if (!(sigmaA == 0.0f) && cosThetaT > 0.0f) {
+            V3 a = -sigmaA*(thickness*2.0f/cosThetaT);
+            transmittance *= V3(mexp(a.x), mexp(a.y), mexp(a.z));
+        }
+        return transmittance;
+    }
+    case TGPU_BSDF_ROUGH_COAT: { // bsdfs/RoughCoatBsdf.cpp:159-198
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & bsdfLobes(d.substrate)) != 0;
+        if (!sampleT && !sampleR) return V3(0.0f);
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        V3 glossyR(0.0f);
+        if (sampleR) glossyR = rdEvalBase(e, true, false, roughness, d.ior, d.distribution);
+        V3 substrateR(0.0f);
+        if (sampleT) {
+            const V3 &wi = e.wi, &wo = e.wo;
+            float eta = 1.0f/d.ior;
+            float cosThetaTi, cosThetaTo;
+            float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+            float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+            if (Fi == 1.0f || Fo == 1.0f) return glossyR;
+            V3 wiSubstrate(wi.x*eta, wi.y*eta, std::copysign(cosThetaTi, wi.z));
+            V3 woSubstrate(wo.x*eta, wo.y*eta, std::copysign(cosThetaTo, wo.z));
+            float compressionProjection = eta*eta*wo.z/cosThetaTo;
+            V3 substrateF = bsdfEval(d.substrate, warped(e, wiSubstrate, woSubstrate));
+            V3 ssa(d.scaled_sigma_a);
+            if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/cosThetaTo - 1.0f/cosThetaTi); substrateF *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+            substrateR = compressionProjection*(1.0f - Fi)*(1.0f - Fo)*substrateF;
+        }
+        return glossyR + substrateR;
+    }
     case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:146-178
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
         uint32_t subLobes = bsdfLobes(d.substrate);
@@ -1928,6 +2049,53 @@ bool oracle_ctx::bsdfSample(int b, Event &e) const
         e.pdf = std::abs(e.wo.z)*INV_PI;
         e.weight = texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
         e.sampledLobe = DiffuseReflectionLobe;
+        return true;
+    }
+    case TGPU_BSDF_OREN_NAYAR: { // bsdfs/OrenNayarBsdf.cpp:41-61
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return false;
+        if (e.wi.z <= 0.0f) return false;
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        float ratio = clampf(roughness, 0.01f, 1.0f);
+        if (e.sampler->nextBoolean(ratio)) {
+            float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+            float phi = TWO_PI*xix; // SampleWarp::uniformHemisphere (SampleWarp.hpp:25-30)
+            float r = std::sqrt(fmax2(1.0f - xiy*xiy, 0.0f));
+            e.wo = V3(mcos(phi)*r, msin(phi)*r, xiy);
+        } else {
+            float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+            float phi = xix*TWO_PI;
+            float r = std::sqrt(xiy);
+            e.wo = V3(mcos(phi)*r, msin(phi)*r, std::sqrt(fmax2(1.0f - xiy, 0.0f)));
+        }
+        e.pdf = INV_TWO_PI*ratio + (std::abs(e.wo.z)*INV_PI)*(1.0f - ratio);
+        e.weight = bsdfEval(b, e)/e.pdf;
+        e.sampledLobe = DiffuseReflectionLobe;
+        return e.wo.z > 0.0f;
+    }
+    case TGPU_BSDF_PHONG: { // bsdfs/PhongBsdf.cpp:39-77
+        bool evalGlossy = (e.requestedLobe & GlossyReflectionLobe) != 0, evalDiffuse = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!evalGlossy && !evalDiffuse) return false;
+        if (e.wi.z <= 0.0f) return false;
+        bool sampleGlossy = (evalGlossy && evalDiffuse) ? e.sampler->nextBoolean(1.0f - d.diffuse_ratio) : evalGlossy;
+        if (sampleGlossy) {
+            float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+            float phi = xix*TWO_PI;
+            float cosTheta = mpow(xiy, 1.0f/(1.0f + d.exponent));
+            float sinTheta = std::sqrt(fmax2(0.0f, 1.0f - cosTheta*cosTheta));
+            V3 woLocal(mcos(phi)*sinTheta, msin(phi)*sinTheta, cosTheta);
+            Frame lobe = duffFrame(V3(-e.wi.x, -e.wi.y, e.wi.z));
+            e.wo = lobe.toGlobal(woLocal);
+            if (e.wo.z < 0.0f) return false;
+            e.sampledLobe = GlossyReflectionLobe;
+        } else {
+            float xix = e.sampler->next1D(), xiy = e.sampler->next1D();
+            float phi = xix*TWO_PI;
+            float r = std::sqrt(xiy);
+            e.wo = V3(mcos(phi)*r, msin(phi)*r, std::sqrt(fmax2(1.0f - xiy, 0.0f)));
+            e.sampledLobe = DiffuseReflectionLobe;
+        }
+        e.pdf = bsdfPdf(b, e);
+        e.weight = bsdfEval(b, e)/e.pdf;
         return true;
     }
     case TGPU_BSDF_ROUGH_CONDUCTOR: { // bsdfs/RoughConductorBsdf.cpp:60-91
@@ -2141,6 +2309,119 @@ bool oracle_ctx::bsdfSample(int b, Event &e) const
         e.weight *= dielectricEtaSq(d.ior, e.wi, e.wo);
         return true;
     }
+    case TGPU_BSDF_MIXED: { // bsdfs/MixedBsdf.cpp:17-30 (adjustedRatio), :72-102
+        bool sample0 = (e.requestedLobe & bsdfLobes(d.substrate)) != 0, sample1 = (e.requestedLobe & bsdfLobes(d.aux_bsdf)) != 0;
+        float ratio;
+        if (sample0 && sample1) ratio = texEval(d.aux_tex, e.info->uvx, e.info->uvy).x;
+        else if (sample0) ratio = 1.0f;
+        else if (sample1) ratio = 0.0f;
+        else return false;
+        if (e.sampler->nextBoolean(ratio)) {
+            if (!bsdfSample(d.substrate, e)) return false;
+            float pdf0 = e.pdf*ratio;
+            float pdf1 = bsdfPdf(d.aux_bsdf, e)*(1.0f - ratio);
+            V3 f = e.weight*e.pdf*ratio + bsdfEval(d.aux_bsdf, e)*(1.0f - ratio);
+            e.pdf = pdf0 + pdf1;
+            e.weight = f/e.pdf;
+        } else {
+            if (!bsdfSample(d.aux_bsdf, e)) return false;
+            float pdf0 = bsdfPdf(d.substrate, e)*ratio;
+            float pdf1 = e.pdf*(1.0f - ratio);
+            V3 f = bsdfEval(d.substrate, e)*ratio + e.weight*e.pdf*(1.0f - ratio);
+            e.pdf = pdf0 + pdf1;
+            e.weight = f/e.pdf;
+        }
+        e.weight *= texEval(d.albedo_tex, e.info->uvx, e.info->uvy);
+        return true;
+    }
+    case TGPU_BSDF_TRANSPARENCY: return bsdfSample(d.substrate, e); // bsdfs/TransparencyBsdf.cpp:42-45
+    case TGPU_BSDF_THINSHEET: { // bsdfs/ThinSheetBsdf.cpp:50-81
+        if (!(e.requestedLobe & SpecularReflectionLobe)) return false;
+        e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+        e.pdf = 1.0f;
+        e.sampledLobe = SpecularReflectionLobe;
+        V3 sigmaA(d.sigma_a);
+        if (sigmaA == 0.0f) { // fast path / early out
+            e.weight = V3(1.0f);
+            return true;
+        }
+        float thickness = texEval(d.aux_tex, e.info->uvx, e.info->uvy).x;
+        float cosThetaT;
+        e.weight = V3(thinFilmReflectance(1.0f/d.ior, std::abs(e.wi.z), cosThetaT));
+        V3 transmittance = V3(1.0f) - e.weight;
+        if (cosThetaT > 0.0f) {
+            V3 a = -sigmaA*(thickness*2.0f/cosThetaT);
+            transmittance *= V3(mexp(a.x), mexp(a.y), mexp(a.z));
+        }
+        e.weight /= 1.0f - transmittance.avg();
+        return true;
+    }
+    case TGPU_BSDF_ROUGH_COAT: { // bsdfs/RoughCoatBsdf.cpp:47-87 (substrateEvalAndPdf), :89-157
+        if (e.wi.z <= 0.0f) return false;
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & bsdfLobes(d.substrate)) != 0;
+        if (!sampleR && !sampleT) return false;
+        const V3 wi = e.wi;
+        float eta = 1.0f/d.ior;
+        float cosThetaTi;
+        float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+        float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability = specularWeight/(specularWeight + substrateWeight);
+        float roughness = texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x;
+        V3 ssa(d.scaled_sigma_a);
+        if (sampleR && (e.sampler->nextBoolean(specularProbability) || !sampleT)) {
+            if (!rdSampleBase(e, true, false, roughness, d.ior, d.distribution)) return false;
+            if (sampleT) {
+                V3 brdfSubstrate(0.0f), brdfSpecular = e.weight*e.pdf;
+                float pdfSubstrate = 0.0f, pdfSpecular = e.pdf*specularProbability;
+                { // substrateEvalAndPdf
+                    const V3 &wo = e.wo;
+                    float cosThetaTo;
+                    float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+                    if (!(Fi == 1.0f || Fo == 1.0f)) {
+                        V3 wiSubstrate(wi.x*eta, wi.y*eta, std::copysign(cosThetaTi, wi.z));
+                        V3 woSubstrate(wo.x*eta, wo.y*eta, std::copysign(cosThetaTo, wo.z));
+                        pdfSubstrate = bsdfPdf(d.substrate, warped(e, wiSubstrate, woSubstrate));
+                        pdfSubstrate *= eta*eta*std::abs(wo.z/cosThetaTo);
+                        float compressionProjection = eta*eta*wo.z/cosThetaTo;
+                        V3 substrateF = bsdfEval(d.substrate, warped(e, wiSubstrate, woSubstrate));
+                        if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/cosThetaTo - 1.0f/cosThetaTi); substrateF *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+                        brdfSubstrate = compressionProjection*(1.0f - Fi)*(1.0f - Fo)*substrateF;
+                    }
+                }
+                pdfSubstrate *= 1.0f - specularProbability;
+                e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+                e.pdf = pdfSpecular + pdfSubstrate;
+            }
+            return true;
+        } else {
+            V3 wiSubstrate(wi.x*eta, wi.y*eta, cosThetaTi);
+            e.wi = wiSubstrate;
+            bool success = bsdfSample(d.substrate, e);
+            e.wi = wi;
+            if (!success) return false;
+            float cosThetaTo;
+            float Fo = dielectricReflectance(d.ior, e.wo.z, cosThetaTo);
+            if (Fo == 1.0f) return false;
+            float cosThetaSubstrate = e.wo.z;
+            e.wo = V3(e.wo.x*d.ior, e.wo.y*d.ior, cosThetaTo);
+            e.weight *= (1.0f - Fi)*(1.0f - Fo);
+            if (ssa.max() > 0.0f) { V3 a = ssa*(-1.0f/cosThetaSubstrate - 1.0f/cosThetaTi); e.weight *= V3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+            e.weight *= wi.z/wiSubstrate.z;
+            e.pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+            if (sampleR) {
+                V3 brdfSubstrate = e.weight*e.pdf;
+                float pdfSubstrate = e.pdf*(1.0f - specularProbability);
+                V3 brdfSpecular = rdEvalBase(e, true, false, roughness, d.ior, d.distribution);
+                float pdfSpecular = rdPdfBase(e, true, false, roughness, d.ior, d.distribution);
+                pdfSpecular *= specularProbability;
+                e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+                e.pdf = pdfSpecular + pdfSubstrate;
+            }
+        }
+        return true;
+    }
     case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:41-100
         if (e.wi.z <= 0.0f) return false;
         uint32_t subLobes = bsdfLobes(d.substrate);
@@ -2202,6 +2483,26 @@ float oracle_ctx::bsdfPdf(int b, const Event &e) const
         if (!(e.requestedLobe & DiffuseReflectionLobe)) return 0.0f;
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
         return std::abs(e.wo.z)*INV_PI;
+    case TGPU_BSDF_OREN_NAYAR: { // bsdfs/OrenNayarBsdf.cpp:125-135
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return 0.0f;
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        float ratio = clampf(texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x, 0.01f, 1.0f);
+        return INV_TWO_PI*ratio + (std::abs(e.wo.z)*INV_PI)*(1.0f - ratio);
+    }
+    case TGPU_BSDF_PHONG: { // bsdfs/PhongBsdf.cpp:102-121
+        bool evalGlossy = (e.requestedLobe & GlossyReflectionLobe) != 0, evalDiffuse = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!evalGlossy && !evalDiffuse) return 0.0f;
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        const float pdfFactor = (d.exponent + 1.0f)*INV_TWO_PI;
+        float result = 0.0f;
+        if (evalGlossy) {
+            float cosTheta = V3(-e.wi.x, -e.wi.y, e.wi.z).dot(e.wo);
+            if (cosTheta > 0.0f) result += mpow(cosTheta, d.exponent)*pdfFactor;
+        }
+        if (evalDiffuse && evalGlossy) result = result*(1.0f - d.diffuse_ratio) + d.diffuse_ratio*(std::abs(e.wo.z)*INV_PI);
+        else if (evalDiffuse) result = std::abs(e.wo.z)*INV_PI;
+        return result;
+    }
     case TGPU_BSDF_ROUGH_CONDUCTOR: { // bsdfs/RoughConductorBsdf.cpp:127-143
         if (!(e.requestedLobe & GlossyReflectionLobe)) return 0.0f;
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
@@ -2294,6 +2595,47 @@ float oracle_ctx::bsdfPdf(int b, const Event &e) const
             if (reflect) pdf *= F; else pdf *= 1.0f - F;
         }
         return pdf;
+    }
+    case TGPU_BSDF_MIXED: { // bsdfs/MixedBsdf.cpp:125-131
+        bool sample0 = (e.requestedLobe & bsdfLobes(d.substrate)) != 0, sample1 = (e.requestedLobe & bsdfLobes(d.aux_bsdf)) != 0;
+        float ratio;
+        if (sample0 && sample1) ratio = texEval(d.aux_tex, e.info->uvx, e.info->uvy).x;
+        else if (sample0) ratio = 1.0f;
+        else if (sample1) ratio = 0.0f;
+        else return 0.0f;
+        return bsdfPdf(d.substrate, e)*ratio + bsdfPdf(d.aux_bsdf, e)*(1.0f - ratio);
+    }
+    case TGPU_BSDF_TRANSPARENCY: return bsdfPdf(d.substrate, e); // bsdfs/TransparencyBsdf.cpp:60-63
+    case TGPU_BSDF_THINSHEET: // bsdfs/ThinSheetBsdf.cpp:111-118
+        return ((e.requestedLobe & SpecularReflectionLobe) && checkReflectionConstraint(e.wi, e.wo)) ? 1.0f : 0.0f;
+    case TGPU_BSDF_ROUGH_COAT: { // bsdfs/RoughCoatBsdf.cpp:256-298
+        bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0;
+        bool sampleT = (e.requestedLobe & bsdfLobes(d.substrate)) != 0;
+        if (!sampleT && !sampleR) return 0.0f;
+        if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+        const V3 &wi = e.wi, &wo = e.wo;
+        float eta = 1.0f/d.ior;
+        float cosThetaTi, cosThetaTo;
+        float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+        float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+        float specularProbability;
+        if (sampleR && sampleT) {
+            float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            specularProbability = specularWeight/(specularWeight + substrateWeight);
+        } else {
+            specularProbability = sampleR ? 1.0f : 0.0f;
+        }
+        float glossyPdf = 0.0f;
+        if (sampleR) glossyPdf = rdPdfBase(e, true, false, texEval(d.roughness_tex, e.info->uvx, e.info->uvy).x, d.ior, d.distribution);
+        float substratePdf = 0.0f;
+        if (sampleT && Fi < 1.0f && Fo < 1.0f) {
+            V3 wiSubstrate(wi.x*eta, wi.y*eta, std::copysign(cosThetaTi, wi.z));
+            V3 woSubstrate(wo.x*eta, wo.y*eta, std::copysign(cosThetaTo, wo.z));
+            substratePdf = bsdfPdf(d.substrate, warped(e, wiSubstrate, woSubstrate));
+            substratePdf *= eta*eta*std::abs(wo.z/cosThetaTo);
+        }
+        return glossyPdf*specularProbability + substratePdf*(1.0f - specularProbability);
     }
     case TGPU_BSDF_SMOOTH_COAT: { // bsdfs/SmoothCoatBsdf.cpp:180-215
         if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
@@ -2388,7 +2730,7 @@ V3 oracle_ctx::shadowRay(Ray &ray, int medium, int endKind, uint32_t endIndex, i
 }
 
 V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, int medium, float expectedDist, Temp &data, Info &info, int bounce, bool startsOnSurface,
-                                  Ray &ray, Counters &c) const
+                                  Ray &ray, Counters &c, V3 *transmittance) const
 {   // TraceBase.cpp:144-174
     constexpr float fudgeFactor = 1.0f + 1e-3f;
     if (!lightIntersect(l, ray, data) || ray.farT*fudgeFactor < expectedDist) return V3(0.0f);
@@ -2397,11 +2739,12 @@ V3 oracle_ctx::attenuatedEmission(const tgpu_light &l, int medium, float expecte
     intersectionInfo(data, info);
     int endKind = l.kind == TGPU_LIGHT_ENV ? PRIM_ENV : (l.kind == TGPU_LIGHT_SPHERE ? PRIM_SPHERE : (l.kind == TGPU_LIGHT_DISK ? PRIM_DISK : PRIM_QUAD));
     V3 shadow = shadowRay(ray, medium, endKind, uint32_t(l.index), bounce, startsOnSurface, true, c);
+    if (transmittance) *transmittance = shadow; // the 'visibility' output buffer (TraceBase.cpp:168-169)
     if (shadow == 0.0f) return V3(0.0f);
     return shadow*primEvalDirect(data, info);
 }
 
-V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c) const
+V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int medium, int bounce, const Ray &parent, Counters &c, V3 *transmittance) const
 {   // TraceBase.cpp:246-285
     LightSample sample;
     if (!lightSampleDirect(l, event.info->p, *event.sampler, sample)) return V3(0.0f);
@@ -2419,7 +2762,7 @@ V3 oracle_ctx::lightSample(const tgpu_light &l, Event &event, int medium, int bo
     (void)parent;
     Temp data;
     Info info;
-    V3 e = attenuatedEmission(l, medium, sample.dist, data, info, bounce, true, ray, c);
+    V3 e = attenuatedEmission(l, medium, sample.dist, data, info, bounce, true, ray, c, transmittance);
     TRC("  neeL d=%08x %08x %08x dist=%08x pdf=%08x f=%08x %08x %08x e=%08x %08x %08x farT=%08x\n", HX3(sample.d), hx(sample.dist), hx(sample.pdf), HX3(f), HX3(e), hx(ray.farT));
     if (e == 0.0f) return V3(0.0f);
     V3 lightF = f*e/sample.pdf;
@@ -2501,7 +2844,7 @@ const tgpu_light *oracle_ctx::chooseLight(const V3 &p, Sampler &sampler, float &
     return light;
 }
 
-V3 oracle_ctx::estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c) const
+V3 oracle_ctx::estimateDirect(Event &event, int medium, int bounce, const Ray &parent, Counters &c, V3 *transmittance) const
 {   // TraceBase.cpp:483-494 -> sampleDirect :383-400
     float weight;
     const tgpu_light *light = chooseLight(event.info->p, *event.sampler, weight);
@@ -2510,13 +2853,13 @@ V3 oracle_ctx::estimateDirect(Event &event, int medium, int bounce, const Ray &p
     uint32_t lobes = bsdfLobes(event.info->bsdf);
     bool pureSpecular = lobes != 0 && (lobes & ~uint32_t(SpecularLobe)) == 0;
     if (pureSpecular || lobes == ForwardLobe) return V3(0.0f);
-    result += lightSample(*light, event, medium, bounce, parent, c);
+    result += lightSample(*light, event, medium, bounce, parent, c, transmittance);
     result += bsdfSampleNee(*light, event, medium, bounce, parent, c); // lights in scope are never Dirac
     return result*weight;
 }
 
 bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int &medium, int bounce, bool enableLightSampling, Ray &ray,
-                               V3 &throughput, V3 &emission, bool &wasSpecular, MediumStateO &state, Counters &c) const
+                               V3 &throughput, V3 &emission, bool &wasSpecular, MediumStateO &state, Counters &c, V3 *transmittance) const
 {   // TraceBase.cpp:516-568 (adjoint = false)
     c.surface++;
     Event fwd = event; // makeForwardEvent
@@ -2534,7 +2877,7 @@ bool oracle_ctx::handleSurface(Event &event, Temp &data, Info &info, int &medium
         throughput *= event.weight;
     } else {
         if (enableLightSampling && bounce < sc.settings.max_bounces - 1)
-            emission += estimateDirect(event, medium, bounce + 1, ray, c)*throughput;
+            emission += estimateDirect(event, medium, bounce + 1, ray, c, transmittance)*throughput;
         if (primEmissive(info.kind, info.index) && bounce >= sc.settings.min_bounces) {
             if (!enableLightSampling || wasSpecular || !primSamplable(info.kind, info.index))
                 emission += primEvalDirect(data, info)*throughput;
@@ -2891,8 +3234,8 @@ void oracle_ctx::cameraRay(uint32_t px, uint32_t py, float xi0, float xi1, Ray &
     ray.farT = INF;
 }
 
-V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c) const
-{   // integrators/path_tracer/PathTracer.cpp:14-149 (no AOV buffers; low_order_scattering = include_surfaces = true)
+V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c, AovSample *aov) const
+{   // integrators/path_tracer/PathTracer.cpp:14-149 (low_order_scattering = include_surfaces = true); aov: _trackOutputValues
     c.samples++;
     float xi0 = sampler.next1D(), xi1 = sampler.next1D();
     Ray ray;
@@ -2908,6 +3251,8 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
     state.reset();
     int medium = sc.n_media ? sc.camera.medium : -1;
 
+    bool recordedOutputValues = false;
+    float hitDistance = 0.0f;
     int mediumBounces = 0;
     int bounce = 0;
     c.extend++;
@@ -2927,8 +3272,20 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
             if (hitSurface && !didHit) break;
         }
         if (hitSurface) {
+            hitDistance += ray.farT;
             Event surfaceEvent = makeLocalScatterEvent(data, info, ray, &sampler);
-            bool terminate = !handleSurface(surfaceEvent, data, info, medium, bounce, nee, ray, throughput, emission, wasSpecular, state, c);
+            V3 transmittance(-1.0f);
+            bool terminate = !handleSurface(surfaceEvent, data, info, medium, bounce, nee, ray, throughput, emission, wasSpecular, state, c, &transmittance);
+            if (aov && !recordedOutputValues && (!wasSpecular || terminate)) { // PathTracer.cpp:78-96
+                aov->depth = hitDistance;
+                aov->normal = info.Ns;
+                const tgpu_bsdf &bd = sc.bsdfs[info.bsdf]; // a TransparencyBsdf shows its base's albedo
+                V3 albedo = texEval(bd.type == TGPU_BSDF_TRANSPARENCY ? sc.bsdfs[bd.substrate].albedo_tex : bd.albedo_tex, info.uvx, info.uvy);
+                if (primEmissive(info.kind, info.index)) albedo += primEvalDirect(data, info);
+                aov->albedo = albedo;
+                if (transmittance != -1.0f) aov->visibility = transmittance.avg();
+                recordedOutputValues = true;
+            }
             if (terminate) return emission;
         } else {
             mediumBounces++;
@@ -2956,6 +3313,8 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
         }
     }
     (void)mediumBounces;
+    bool lastIsInfinite = false; // info.primitive && info.primitive->isInfinite() after handleInfiniteLights
+    V3 infiniteEmission(0.0f);
     if (bounce >= minBounces && bounce < maxBounces) {
         // TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) / TraceableScene::intersectInfinites (:194-209)
         if (sc.env.present) {
@@ -2966,9 +3325,18 @@ V3 oracle_ctx::traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters 
             intersectionInfo(d2, i2);
             if (!nee || wasSpecular || !sc.env.samplable)
                 emission += throughput*primEvalDirect(d2, i2);
+            if (aov) {
+                lastIsInfinite = true;
+                infiniteEmission = primEvalDirect(d2, i2);
+            }
         }
     }
     if (std::isnan(throughput.sum() + emission.sum())) return V3(0.0f);
+    if (aov && !recordedOutputValues) { // PathTracer.cpp:133-140
+        if (bounce == 0) aov->depth = 0.0f;
+        aov->normal = -ray.dir;
+        if (lastIsInfinite) aov->albedo = infiniteEmission;
+    }
     TRC("ORC end bounce=%d em=%08x %08x %08x\n", bounce, HX3(emission));
     return emission;
 }
@@ -3014,6 +3382,64 @@ static void addSample(float *mean, uint32_t *count, const V3 &c) // cameras/Outp
     V3 m(mean);
     V3 r = m + (c - m)/float(sampleIdx + 1);
     mean[0] = r.x; mean[1] = r.y; mean[2] = r.z;
+}
+
+// OutputBuffer<T>::addSample (cameras/OutputBuffer.hpp:104-132) for T = float (channels 1) and T = Vec3f (channels 3, elementwise):
+// running means in one or two half buffers (two_buffer_variance), Welford sums against the combined mean (sample_variance)
+static void obAddSample(const oracle_outbuf &ob, int channels, size_t idx, const float *c)
+{
+    for (int k = 0; k < channels; ++k)
+        if (std::isnan(c[k]) || std::isinf(c[k])) return;
+    uint32_t sampleIdx = ob.count[idx]++;
+    float *A = ob.a + idx*channels, *B = ob.b ? ob.b + idx*channels : nullptr, *VAR = ob.variance ? ob.variance + idx*channels : nullptr;
+    for (int k = 0; k < channels; ++k) {
+        if (VAR) {
+            float curr;
+            if (B && sampleIdx > 0) {
+                uint32_t sampleCountA = (sampleIdx + 1)/2, sampleCountB = sampleIdx/2;
+                curr = (A[k]*float(sampleCountA) + B[k]*float(sampleCountB))/float(sampleIdx);
+            } else {
+                curr = A[k];
+            }
+            float delta = c[k] - curr;
+            curr += delta/float(sampleIdx + 1);
+            VAR[k] += delta*(c[k] - curr);
+        }
+        if (B) {
+            float *feature = (sampleIdx & 1) ? B : A;
+            uint32_t perBufferSampleCount = sampleIdx/2 + 1;
+            feature[k] += (c[k] - feature[k])/float(perBufferSampleCount);
+        } else {
+            A[k] += (c[k] - A[k])/float(sampleIdx + 1);
+        }
+    }
+}
+static const int kOutputChannels[TGPU_OUTPUT_COUNT] = {3, 1, 3, 3, 1};
+static void addOutputSamples(const oracle_ctx *ctx, size_t idx, const V3 &col, const AovSample &aov)
+{
+    const oracle_outbuf *ob = ctx->out;
+    if (ob[TGPU_OUTPUT_COLOR].a) { float c[3] = {col.x, col.y, col.z}; obAddSample(ob[TGPU_OUTPUT_COLOR], 3, idx, c); }
+    if (ob[TGPU_OUTPUT_DEPTH].a) obAddSample(ob[TGPU_OUTPUT_DEPTH], 1, idx, &aov.depth);
+    if (ob[TGPU_OUTPUT_NORMAL].a) { float c[3] = {aov.normal.x, aov.normal.y, aov.normal.z}; obAddSample(ob[TGPU_OUTPUT_NORMAL], 3, idx, c); }
+    if (ob[TGPU_OUTPUT_ALBEDO].a) { float c[3] = {aov.albedo.x, aov.albedo.y, aov.albedo.z}; obAddSample(ob[TGPU_OUTPUT_ALBEDO], 3, idx, c); }
+    if (ob[TGPU_OUTPUT_VISIBILITY].a) obAddSample(ob[TGPU_OUTPUT_VISIBILITY], 1, idx, &aov.visibility);
+}
+/* Known-answer entry for the output-buffer accumulation (tests/test_ref_kat3.py against tests/golden/ref_kat3.json, produced by the
+ * reference's own cameras/OutputBuffer.hpp): sample i goes to pixel pixel[i] with `channels` values; the part arrays are updated in place. */
+void oracle_kat_output_buffer(int channels, uint32_t n_samples, const uint32_t *pixel, const float *values, float *a, float *b, float *variance, uint32_t *count)
+{
+    oracle_outbuf ob{a, b, variance, count};
+    for (uint32_t i = 0; i < n_samples; ++i) obAddSample(ob, channels, pixel[i], values + size_t(i)*channels);
+}
+
+void oracle_bind_output_buffers(oracle_ctx *ctx, const oracle_outbuf *bufs)
+{
+    ctx->trackOutputs = false;
+    for (int i = 0; i < TGPU_OUTPUT_COUNT; ++i) {
+        ctx->out[i] = bufs ? bufs[i] : oracle_outbuf{nullptr, nullptr, nullptr, nullptr};
+        if (ctx->out[i].a) ctx->trackOutputs = true;
+    }
+    (void)kOutputChannels;
 }
 
 static void flushCounters(oracle_ctx *ctx, const oracle_ctx::Counters &c)
@@ -3066,8 +3492,10 @@ int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint
                             s.local = pathLocalPcg(s.scramble, spp_begin + i);
                             s.supplemental = &s.local;
                         }
-                        V3 col = ctx->traceSample(px, py, s, c);
+                        AovSample aov;
+                        V3 col = ctx->traceSample(px, py, s, c, ctx->trackOutputs ? &aov : nullptr);
                         addSample(rgb_mean + size_t(pixelIndex)*3, sample_count + pixelIndex, col);
+                        if (ctx->trackOutputs) addOutputSamples(ctx, pixelIndex, col, aov);
                     }
                 }
             }
@@ -3104,8 +3532,10 @@ int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t 
                     s.startPath(pixelIndex, spp_begin + i);
                     s.local = pathLocalPcg(s.scramble, spp_begin + i);
                     s.supplemental = &s.local;
-                    V3 col = ctx->traceSample(pixelIndex % W, pixelIndex/W, s, c);
+                    AovSample aov;
+                    V3 col = ctx->traceSample(pixelIndex % W, pixelIndex/W, s, c, ctx->trackOutputs ? &aov : nullptr);
                     addSample(rgb_mean + size_t(k)*3, sample_count + k, col);
+                    if (ctx->trackOutputs) addOutputSamples(ctx, k, col, aov);
                 }
             }
         }
@@ -3388,9 +3818,11 @@ extern "C" int oracle_render_shard_adaptive(oracle_ctx *ctx, const tgpu_shard_de
                         s.startPath(pixelIndex, vtIndex[vt] + i);
                         s.local = pathLocalPcg(s.scramble, vtIndex[vt] + i);
                         s.supplemental = &s.local;
-                        V3 col = ctx->traceSample(x, y, s, c);
+                        AovSample aov;
+                        V3 col = ctx->traceSample(x, y, s, c, ctx->trackOutputs ? &aov : nullptr);
                         record.addSample(col.luminance());
                         addSample(rgb_mean + size_t(k)*3, sample_count + k, col);
+                        if (ctx->trackOutputs) addOutputSamples(ctx, size_t(k), col, aov);
                     }
                 }
             records[vt] = tgpu_sample_record{record.sampleCount, record.mean, record.runningVariance};

@@ -45,6 +45,15 @@ void oracle_destroy(oracle_ctx *ctx);
 int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint32_t spp_count,
                         float *rgb_mean, uint32_t *sample_count, int n_threads);
 
+/* Output buffers of the render calls below (cameras/OutputBuffer.hpp; indexed by tgpu_output_type, pixel order as rgb_mean): the
+ * caller owns the zero-initialised arrays; a == NULL leaves that buffer out, b / variance select two_buffer_variance /
+ * sample_variance.  Binding any buffer makes traceSample track the auxiliary values (PathTracer.cpp:78-96,133-140). */
+typedef struct oracle_outbuf { float *a, *b, *variance; uint32_t *count; } oracle_outbuf;
+void oracle_bind_output_buffers(oracle_ctx *ctx, const oracle_outbuf *bufs /* TGPU_OUTPUT_COUNT entries, or NULL */);
+
+void oracle_kat_output_buffer(int channels, uint32_t n_samples, const uint32_t *pixel, const float *values, float *a, float *b /* or NULL */,
+                              float *variance /* or NULL */, uint32_t *count);
+
 /* Shard order (rng mode 1 only): same contract as tgpu_render_pass+tgpu_download. */
 int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t spp_begin, uint32_t spp_count,
                         float *rgb_mean, uint32_t *sample_count, int n_threads);

@@ -45,6 +45,8 @@ def lib():
         L.oracle_camera_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.oracle_tile_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.oracle_set_brute_force.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_bind_output_buffers.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_kat_output_buffer.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_get_stats.argtypes = [C.c_void_p, C.POINTER(OracleStats)]
         L.oracle_reset_stats.argtypes = [C.c_void_p]
         _lib = L
@@ -119,6 +121,36 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle_render_shard_adaptive needs rng mode 1")
         return rgb, cnt, records
+
+    def bind_output_buffers(self, n_pixels):
+        """Allocates the output buffers the scene's renderer settings request (tgpu_scene_desc.output_buffers: the colour buffer with
+        its optional parts, and the auxiliary depth / normal / albedo / visibility buffers) for `n_pixels` pixels in the order of the
+        render call that follows (shard order for render_shard*, image order for render_image), binds them, and returns
+        {name: {"a", "b", "variance", "count"}} with numpy arrays (absent parts are left out)."""
+        from tungsten_amd import _abi
+
+        class OutBuf(C.Structure):
+            _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("variance", C.c_void_p), ("count", C.c_void_p)]
+
+        settings = self._scene.desc.contents.output_buffers
+        table = (OutBuf*_abi.OUTPUT_COUNT)()
+        out = {}
+        for t, name in enumerate(_abi.OUTPUT_NAMES):
+            ob = settings[t]
+            if t != _abi.OUTPUT_COLOR and not ob.enabled:
+                continue
+            ch = _abi.OUTPUT_CHANNELS[t]
+            parts = {"a": np.zeros((n_pixels, ch), np.float32), "count": np.zeros(n_pixels, np.uint32)}
+            if ob.two_buffer_variance:
+                parts["b"] = np.zeros((n_pixels, ch), np.float32)
+            if ob.sample_variance:
+                parts["variance"] = np.zeros((n_pixels, ch), np.float32)
+            for key, arr in parts.items():
+                setattr(table[t], key, arr.ctypes.data)
+            out[name] = parts
+        self._outputs = (table, out)  # keeps the arrays alive while they are bound
+        lib().oracle_bind_output_buffers(self._h, C.cast(table, C.c_void_p))
+        return out
 
     def set_brute_force(self, on=True):
         """Triangle queries test every triangle (no BVH): the definition both BVH walks must reproduce."""

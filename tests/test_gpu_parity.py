@@ -50,6 +50,13 @@ def assert_bit_exact(got, ref, what):
     ("next/rough_plastic.json", (128, 72), 8, 8),
     ("next/dielectric_hg_medium.json", (128, 72), 8, 8),   # Henyey-Greenstein phase function
     ("next/sphere_disk.json", (128, 72), 8, 8),            # spheres, a disk, a sphere light next to the env light
+    ("next/oren_nayar.json", (128, 72), 8, 8),
+    ("next/phong.json", (128, 72), 8, 8),
+    # nested BSDFs and the general forward lobe (pass-through surfaces that tint radiance and shadow rays)
+    ("next/mixed.json", (128, 72), 8, 8),
+    ("next/rough_coat.json", (128, 72), 8, 8),
+    ("next/transparency.json", (128, 72), 8, 8),
+    ("next/thinsheet.json", (128, 72), 8, 8),
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)
@@ -657,3 +664,150 @@ def test_cli_renders_the_unmodified_non_exponential_scene(ta, oracle_py, tmp_pat
     ref, cnt, _ = oracle_py.Oracle(hs, **oracle_py.GPU).render_reference(64, spp_step=16, adaptive=True)
     assert cnt.min() < 64 < cnt.max()
     assert np.array_equal(img, ref)
+
+
+# ---- renderer "output_buffers": depth / normal / albedo / visibility (PathTracer.cpp:78-96,133-140) and the colour buffer's optional parts ----
+ALL_OUTPUTS = [("color", True, True), ("depth", True, True), ("normal", False, True), ("albedo", True, False), "visibility"]
+
+
+def _assert_outputs_bit_exact(ctx, ref_bufs, what):
+    for name, parts in ref_bufs.items():
+        for part, ref in parts.items():
+            got = ctx.download_output_buffer(name, part)
+            same = got.view(np.uint32) == ref.view(np.uint32)
+            assert same.all(), f"{what}: {name}.{part} differs in {int((~same).sum())} of {same.size} values"
+
+
+@pytest.mark.parametrize("scene,res,spp,step,outputs,tail_max", [
+    ("next/aov.json", (96, 54), 8, 4, None, None),                           # the scene's own list: glass (late records), escaping primary rays
+    ("next/aov.json", (96, 54), 8, 4, None, "0"),                            # ... through the wavefront kernels (lazy NEE resolve, retire epilogue)
+    ("cornell-box/scene_sobol.json", (64, 36), 9, 4, ALL_OUTPUTS, "0"),      # every part of every buffer, odd sample count, quad light
+    ("materialtest/c5.json", (64, 36), 8, 8, ALL_OUTPUTS, "0"),              # media: visibility is the light sample's transmittance
+    ("non-exponential/scene.json", (64, 64), 8, 8, ALL_OUTPUTS, "0"),        # forward-scattering walls: the shadow walk's transmittance
+    ("next/transparency.json", (64, 36), 8, 8, ALL_OUTPUTS, None),           # TransparencyBsdf shows its base's albedo
+    ("instances/inst_mesh.json", (64, 36), 8, 4, ["depth", "normal", "albedo", "visibility"], "0"),
+])
+def test_output_buffers_bit_exact(ta, oracle_py, scene, res, spp, step, outputs, tail_max, monkeypatch):
+    if tail_max is not None:
+        monkeypatch.setenv("TGPU_TAIL_MAX", tail_max)
+    hs = ta.HostScene(scene_path(scene), resolution=res, output_buffers=outputs)
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    o = oracle_py.Oracle(hs, **oracle_py.GPU)
+    ref_bufs = o.bind_output_buffers(shard.n_pixels)
+    ref = o.render_shard(shard, spp, spp_step=step)
+    assert len(ref_bufs) >= 4 and ref_bufs["depth"]["count"].max() > 0
+    ctx = ta.Context(0)
+    try:
+        got = render_gpu(ta, ctx, hs, shard, spp, step, 4096 if tail_max == "0" else 0)
+        # tgpu_download returns _bufferA of the colour buffer: the mean of the even samples when the buffer is split in two
+        assert_bit_exact(got, (ref_bufs["color"]["a"], ref_bufs["color"]["count"]), f"{scene} colour with output buffers")
+        if "b" not in ref_bufs["color"]:
+            assert_bit_exact(got, ref, f"{scene} colour")
+        _assert_outputs_bit_exact(ctx, ref_bufs, scene)
+        with pytest.raises(RuntimeError):
+            ctx.download_output_buffer("albedo", "variance" if "variance" not in ref_bufs["albedo"] else "b")  # a part nobody asked for
+    finally:
+        ctx.close()
+
+
+def test_output_buffers_immediate_and_queued_shadow_kernels_agree(ta, oracle_py, monkeypatch):
+    """The visibility buffer is completed where the shadow ray's result becomes known: in the shadow kernel itself (TGPU_SHADOW_Q=0) or
+    at the lazy resolve of the queued form."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(96, 54), output_buffers=["depth", "normal", "albedo", ("visibility", True, True)])
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    o = oracle_py.Oracle(hs, **oracle_py.GPU)
+    ref_bufs = o.bind_output_buffers(shard.n_pixels)
+    ref = o.render_shard(shard, 8, spp_step=8)
+    for q in ("0", "4"):
+        monkeypatch.setenv("TGPU_SHADOW_Q", q)
+        monkeypatch.setenv("TGPU_TAIL_MAX", "0")
+        ctx = ta.Context(0)
+        try:
+            got = render_gpu(ta, ctx, hs, shard, 8, 8, 8192)
+            assert_bit_exact(got, ref, f"c2 colour, shadow queue {q}")
+            _assert_outputs_bit_exact(ctx, ref_bufs, f"c2, shadow queue {q}")
+        finally:
+            ctx.close()
+
+
+def test_output_buffers_with_adaptive_sampling(ta, oracle_py, gpu_ctx):
+    """Adaptive passes hold a pixel's samples contiguously (k_accumulate_records): same buffers as the oracle's adaptive shard pass."""
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(64, 36), output_buffers=["depth", ("normal", True, False), "albedo", "visibility"])
+    assert hs.adaptive
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    var_w, var_h = (hs.res_x + 3)//4, (hs.res_y + 3)//4
+    idx = np.zeros(var_w*var_h, np.uint32)
+    counts = (1 + (np.arange(var_w*var_h) % 5)).astype(np.uint32)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render_pass(0, 4)                      # a uniform pass first (records routed through the same kernel)
+    gpu_ctx.render_pass_adaptive(idx + 4, counts)
+    gpu_ctx.wait()
+    got = gpu_ctx.download()
+    o = oracle_py.Oracle(hs, **oracle_py.GPU)
+    ref_bufs = o.bind_output_buffers(shard.n_pixels)
+    o_rgb = np.zeros((shard.n_pixels, 3), np.float32)
+    o_cnt = np.zeros(shard.n_pixels, np.uint32)
+    o_rec = np.zeros(var_w*var_h, ta.RECORD_DTYPE)
+    o.render_shard_adaptive(shard, idx, np.full(var_w*var_h, 4, np.uint32), o_rgb, o_cnt, o_rec)
+    o.render_shard_adaptive(shard, idx + 4, counts, o_rgb, o_cnt, o_rec)
+    assert_bit_exact(got, (o_rgb, o_cnt), "adaptive colour with output buffers")
+    _assert_outputs_bit_exact(gpu_ctx, ref_bufs, "adaptive")
+
+
+def test_cli_writes_output_buffers_and_resumes_them(ta, oracle_py, tmp_path):
+    """The C++ host: `output_buffers` files next to the image (Camera::saveOutputBuffers) and all buffers inside the resume file."""
+    import json
+    import subprocess
+    scene = json.load(open(scene_path("next/aov.json")))
+    for prim in scene["primitives"]:
+        for key in ("file", "emission"):
+            if isinstance(prim.get(key), str) and prim[key].startswith("../"):
+                prim[key] = os.path.abspath(os.path.join(os.path.dirname(scene_path("next/aov.json")), prim[key]))
+    scene["camera"]["resolution"] = [64, 36]
+    scene["renderer"].update(spp=8, spp_step=4, hdr_output_file="img.pfm", output_file="img.png", enable_resume_render=True,
+                             resume_render_file="state.dat", checkpoint_interval="0")
+    path = tmp_path/"aov.json"
+    path.write_text(json.dumps(scene))
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tungsten_amd", "tungsten_amd_cli")
+    r = subprocess.run([cli, "-d", str(tmp_path), str(path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    hs = ta.HostScene(str(path))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    o = oracle_py.Oracle(hs, **oracle_py.GPU)
+    bufs = o.bind_output_buffers(shard.n_pixels)
+    o.render_shard(shard, 8, spp_step=4)
+
+    def pfm(name, channels):
+        with open(tmp_path/name, "rb") as f:
+            magic = f.readline().strip()
+            w, h = map(int, f.readline().split())
+            f.readline()
+            assert magic == (b"Pf" if channels == 1 else b"PF")
+            return np.frombuffer(f.read(), np.float32).reshape(h, w, channels)[::-1]
+
+    def image_order(values, channels):
+        img = np.zeros((hs.res_y*hs.res_x, channels), np.float32)
+        img[np.asarray(shard.pixel_index)] = values
+        return img.reshape(hs.res_y, hs.res_x, channels)
+
+    assert np.array_equal(pfm("aov_depth.pfm", 1).view(np.uint32), image_order(bufs["depth"]["a"], 1).view(np.uint32))
+    assert np.array_equal(pfm("aov_albedo.pfm", 3).view(np.uint32), image_order(bufs["albedo"]["a"], 3).view(np.uint32))
+    assert np.array_equal(pfm("aov_visibility.pfm", 1).view(np.uint32), image_order(bufs["visibility"]["a"], 1).view(np.uint32))
+    assert np.array_equal(pfm("aov_normalA.pfm", 3).view(np.uint32), image_order(bufs["normal"]["a"], 3).view(np.uint32))
+    assert np.array_equal(pfm("aov_normalB.pfm", 3).view(np.uint32), image_order(bufs["normal"]["b"], 3).view(np.uint32))
+    var = bufs["depth"]["variance"][:, 0]/(bufs["depth"]["count"]*np.maximum(1, bufs["depth"]["count"].astype(np.int64) - 1)).astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert np.array_equal(pfm("aov_depthVariance.pfm", 1), image_order(var.astype(np.float32)[:, None], 1), equal_nan=True)
+    for name in ("aov_depth.png", "aov_normal.png", "aov_normalA.png", "aov_depthVariance.png"):
+        assert (tmp_path/name).stat().st_size > 100
+    # the resume file holds every part of every buffer in the reference's order; a resumed render of 8 more spp continues all of them
+    size = (tmp_path/"state.dat").stat().st_size
+    n = hs.res_x*hs.res_y
+    assert size > n*4*(3 + 1 + (1 + 1 + 1) + (3 + 3 + 1) + (3 + 1) + (1 + 1))
+    scene["renderer"]["spp"] = 16
+    path.write_text(json.dumps(scene))
+    r = subprocess.run([cli, "-d", str(tmp_path), str(path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Resume successful" in r.stdout, r.stdout + r.stderr
+    o.render_shard(shard, 8, spp_step=4, spp_begin=8)
+    assert np.array_equal(pfm("aov_depth.pfm", 1).view(np.uint32), image_order(bufs["depth"]["a"], 1).view(np.uint32))
+    assert np.array_equal(pfm("aov_normalB.pfm", 3).view(np.uint32), image_order(bufs["normal"]["b"], 3).view(np.uint32))

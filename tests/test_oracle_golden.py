@@ -30,6 +30,12 @@ CASES = [
     ("rough_plastic_128x72_4spp", "next/rough_plastic.json", (128, 72), 4),
     ("dielectric_hg_medium_128x72_4spp", "next/dielectric_hg_medium.json", (128, 72), 4),
     ("sphere_disk_128x72_4spp", "next/sphere_disk.json", (128, 72), 4),  # spheres, disk, sphere light + env light selection
+    ("oren_nayar_128x72_4spp", "next/oren_nayar.json", (128, 72), 4),
+    ("phong_128x72_4spp", "next/phong.json", (128, 72), 4),
+    ("mixed_128x72_4spp", "next/mixed.json", (128, 72), 4),                # nested: lambert + rough_conductor
+    ("rough_coat_128x72_4spp", "next/rough_coat.json", (128, 72), 4),      # nested: GGX coat over a substrate
+    ("transparency_128x72_4spp", "next/transparency.json", (128, 72), 4),  # forward lobe with an opacity: pass-through + shadow attenuation
+    ("thinsheet_128x72_4spp", "next/thinsheet.json", (128, 72), 4),        # forward lobe with an angle-dependent transmittance
 ]
 
 

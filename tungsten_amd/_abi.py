@@ -1,7 +1,7 @@
 """ctypes mirror of include/tungsten_amd.h (keep in sync; tests/test_abi.py checks sizes)."""
 import ctypes as C
 
-TGPU_ABI_VERSION = 2
+TGPU_ABI_VERSION = 3
 
 f32 = C.c_float
 i32 = C.c_int32
@@ -26,7 +26,7 @@ class Bsdf(C.Structure):
     _fields_ = [("type", i32), ("albedo_tex", i32), ("roughness_tex", i32), ("distribution", i32),
                 ("eta", f32*3), ("k", f32*3), ("ior", f32), ("thickness", f32), ("sigma_a", f32*3),
                 ("substrate", i32), ("scaled_sigma_a", f32*3), ("avg_transmittance", f32), ("enable_refraction", i32),
-                ("diffuse_fresnel", f32), ("substrate_weight", f32)]
+                ("diffuse_fresnel", f32), ("substrate_weight", f32), ("exponent", f32), ("diffuse_ratio", f32), ("aux_bsdf", i32), ("aux_tex", i32)]
 
 
 class Medium(C.Structure):
@@ -73,6 +73,16 @@ class Settings(C.Structure):
                 ("adaptive_sampling", i32), ("enable_volume_light_sampling", i32)]
 
 
+OUTPUT_COLOR, OUTPUT_DEPTH, OUTPUT_NORMAL, OUTPUT_ALBEDO, OUTPUT_VISIBILITY, OUTPUT_COUNT = range(6)
+PART_A, PART_B, PART_VARIANCE, PART_COUNT = range(4)
+OUTPUT_CHANNELS = (3, 1, 3, 3, 1)
+OUTPUT_NAMES = ("color", "depth", "normal", "albedo", "visibility")
+
+
+class OutputBuffer(C.Structure):
+    _fields_ = [("enabled", i32), ("two_buffer_variance", i32), ("sample_variance", i32)]
+
+
 class Light(C.Structure):
     _fields_ = [("kind", i32), ("index", i32)]
 
@@ -87,7 +97,7 @@ class Instances(C.Structure):
 
 
 class SceneDesc(C.Structure):
-    _fields_ = [("abi_version", u32), ("camera", Camera), ("settings", Settings),
+    _fields_ = [("abi_version", u32), ("camera", Camera), ("settings", Settings), ("output_buffers", OutputBuffer*5),
                 ("n_tris", u32), ("tri_pos", pf32), ("tri_normal", pf32), ("tri_uv", pf32), ("tri_bsdf", pi32),
                 ("tri_smooth", pu8), ("tri_media", C.POINTER(C.c_int16)),
                 ("n_quads", u32), ("quads", C.POINTER(Quad)),

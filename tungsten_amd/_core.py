@@ -49,6 +49,8 @@ def load_core(path):
         L.tgpu_render_pass_adaptive.argtypes = [vp, vp, vp, vp]
         L.tgpu_download_records.argtypes = [vp, vp]
         L.tgpu_upload_records.argtypes = [vp, vp]
+        L.tgpu_download_output_buffer.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.tgpu_upload_output_buffer.argtypes = [vp, C.c_int, C.c_int, vp]
     return L
 
 
@@ -65,7 +67,8 @@ EXPORTED_SYMBOLS = [
     "tgpu_init", "tgpu_destroy", "tgpu_last_error", "tgpu_upload_scene", "tgpu_render_pass", "tgpu_wait",
     "tgpu_abort", "tgpu_download", "tgpu_resolve_to_device", "tgpu_upload_framebuffer", "tgpu_trace_closest",
     "tgpu_trace_occluded", "tgpu_set_profiling", "tgpu_get_stats", "tgpu_reset_stats", "tgpu_eval_math",
-    "tgpu_render_pass_adaptive", "tgpu_download_records", "tgpu_upload_records",
+    "tgpu_render_pass_adaptive", "tgpu_download_records", "tgpu_upload_records", "tgpu_download_output_buffer",
+    "tgpu_upload_output_buffer",
 ]
 
 
@@ -135,6 +138,22 @@ class Context:
         cnt = np.zeros(n, np.uint32)
         self._check(self._lib.tgpu_download(self._h, rgb.ctypes.data, cnt.ctypes.data))
         return rgb, cnt
+
+    def download_output_buffer(self, name, part="a"):
+        """One part ("a", "b", "variance", "count") of an output buffer ("color", "depth", "normal", "albedo", "visibility") of the
+        shard: (n_pixels, channels) float32, or (n_pixels,) uint32 counts.  Raises for a buffer / part not requested at upload."""
+        t = _abi.OUTPUT_NAMES.index(name)
+        p = ("a", "b", "variance", "count").index(part)
+        n = self._shard.n_pixels
+        out = np.zeros(n, np.uint32) if p == _abi.PART_COUNT else np.zeros((n, _abi.OUTPUT_CHANNELS[t]), np.float32)
+        self._check(self._lib.tgpu_download_output_buffer(self._h, t, p, out.ctypes.data))
+        return out
+
+    def upload_output_buffer(self, name, part, values):
+        t = _abi.OUTPUT_NAMES.index(name)
+        p = ("a", "b", "variance", "count").index(part)
+        values = np.ascontiguousarray(values, np.uint32 if p == _abi.PART_COUNT else np.float32)
+        self._check(self._lib.tgpu_upload_output_buffer(self._h, t, p, values.ctypes.data))
 
     def resolve_to_device(self, device_ptr, stream=None):
         self._check(self._lib.tgpu_resolve_to_device(self._h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)))

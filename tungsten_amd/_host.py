@@ -25,6 +25,7 @@ def host_lib():
         lib.tgh_scene_set_bounces.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.tgh_scene_set_light_sampling.argtypes = [C.c_void_p, C.c_int]
         lib.tgh_scene_set_sobol.argtypes = [C.c_void_p, C.c_int]
+        lib.tgh_scene_add_output_buffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.tgh_scene_flatten.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         lib.tgh_scene_desc.restype = C.POINTER(_abi.SceneDesc)
         lib.tgh_scene_desc.argtypes = [C.c_void_p]
@@ -55,7 +56,9 @@ def host_lib():
 class HostScene:
     """Scene::load + makeTraceable bakes (reference: src/core/io/Scene.cpp:373-391)."""
 
-    def __init__(self, json_path, resolution=None, max_bounces=None, light_sampling=None, sobol=None):
+    def __init__(self, json_path, resolution=None, max_bounces=None, light_sampling=None, sobol=None, output_buffers=None):
+        """output_buffers: extra entries of the renderer's "output_buffers" list, each a name ("color", "depth", "normal", "albedo",
+        "visibility") or a tuple (name, two_buffer_variance, sample_variance)."""
         lib = host_lib()
         err = C.create_string_buffer(1024)
         self._h = lib.tgh_scene_load(os.fspath(json_path).encode(), err, len(err))
@@ -69,6 +72,9 @@ class HostScene:
             lib.tgh_scene_set_light_sampling(self._h, int(bool(light_sampling)))
         if sobol is not None:
             lib.tgh_scene_set_sobol(self._h, int(bool(sobol)))
+        for ob in output_buffers or ():
+            name, two, var = (ob, False, False) if isinstance(ob, str) else ob
+            lib.tgh_scene_add_output_buffer(self._h, _abi.OUTPUT_NAMES.index(name), int(bool(two)), int(bool(var)))
         if lib.tgh_scene_flatten(self._h, err, len(err)) != 0:
             msg = err.value.decode()
             lib.tgh_scene_free(self._h)

@@ -277,7 +277,8 @@ TG_DEV V3 bitmapEval(const DBitmap &bm, float ux, float uy) // textures/BitmapTe
     return bm.scale*l;
 }
 
-TG_DEV V3 texEval(const DScene &sc, int tex, float ux, float uy)
+template <class SC>
+TG_DEV V3 texEval(const SC &sc, int tex, float ux, float uy)
 {
     const tgpu_texture &t = sc.textures[tex];
     if (t.type == TGPU_TEX_CONSTANT) return V3(t.value);
@@ -654,12 +655,18 @@ TG_DEV bool checkReflectionConstraint(const V3 &wi, const V3 &wo) // bsdfs/Bsdf.
 
 TG_DEV uint32_t baseLobes(int type)
 {
-    return type == TGPU_BSDF_LAMBERT ? uint32_t(DiffuseReflectionLobe) : (type == TGPU_BSDF_ROUGH_CONDUCTOR ? uint32_t(GlossyReflectionLobe) : 0u);
+    if (type == TGPU_BSDF_LAMBERT || type == TGPU_BSDF_OREN_NAYAR) return uint32_t(DiffuseReflectionLobe);
+    if (type == TGPU_BSDF_PHONG) return uint32_t(GlossyReflectionLobe | DiffuseReflectionLobe);
+    return type == TGPU_BSDF_ROUGH_CONDUCTOR ? uint32_t(GlossyReflectionLobe) : 0u;
 }
 TG_DEV uint32_t bsdfLobes(const DScene &sc, const tgpu_bsdf &d)
 {
     if (d.type == TGPU_BSDF_SMOOTH_COAT) return SpecularReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);
     if (d.type == TGPU_BSDF_FORWARD) return uint32_t(ForwardLobe); // ForwardBsdf.cpp:9-12
+    if (d.type == TGPU_BSDF_MIXED) return baseLobes(sc.bsdfs[d.substrate].type) | baseLobes(sc.bsdfs[d.aux_bsdf].type); // MixedBsdf.cpp:133-136
+    if (d.type == TGPU_BSDF_ROUGH_COAT) return GlossyReflectionLobe | baseLobes(sc.bsdfs[d.substrate].type);           // RoughCoatBsdf.cpp:304
+    if (d.type == TGPU_BSDF_TRANSPARENCY) return ForwardLobe | baseLobes(sc.bsdfs[d.substrate].type);                  // TransparencyBsdf.cpp:66-69
+    if (d.type == TGPU_BSDF_THINSHEET) return uint32_t(SpecularReflectionLobe | ForwardLobe);                          // ThinSheetBsdf.cpp:24
     if (d.type == TGPU_BSDF_MIRROR || d.type == TGPU_BSDF_CONDUCTOR) return uint32_t(SpecularReflectionLobe);
     if (d.type == TGPU_BSDF_PLASTIC) return uint32_t(SpecularReflectionLobe | DiffuseReflectionLobe);
     if (d.type == TGPU_BSDF_ROUGH_PLASTIC) return uint32_t(GlossyReflectionLobe | DiffuseReflectionLobe);
@@ -749,7 +756,8 @@ TG_DEV float dielectricPdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, c
 
 // Lambert (bsdfs/LambertBsdf.cpp:27-68) and RoughConductor (bsdfs/RoughConductorBsdf.cpp:60-143):
 // the two leaf BSDFs; SmoothCoat layers on top of one of them.
-TG_DEV V3 baseEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+template <class SC>
+TG_DEV V3 baseEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
 {
     if (d.type == TGPU_BSDF_LAMBERT) {
         if (!(requested & DiffuseReflectionLobe)) return V3(0.0f);
@@ -769,10 +777,49 @@ TG_DEV V3 baseEval(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 
         float fr = (G*D*0.25f)/wi.z;
         return texEval(sc, d.albedo_tex, uvx, uvy)*(F*fr);
     }
+    if (d.type == TGPU_BSDF_OREN_NAYAR) { // bsdfs/OrenNayarBsdf.cpp:63-98
+        if (!(requested & DiffuseReflectionLobe)) return V3(0.0f);
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return V3(0.0f);
+        float thetaR = tgpu_acosf(wo.z);
+        float thetaI = tgpu_acosf(wi.z);
+        float alpha = fmax2(thetaR, thetaI);
+        float beta = fmin2(thetaR, thetaI);
+        float sinAlpha = tgpu_sinf(alpha);
+        float denom = (wi.x*wi.x + wi.y*wi.y)*(wo.x*wo.x + wo.y*wo.y);
+        float cosDeltaPhi = denom == 0.0f ? 1.0f : (wi.x*wo.x + wi.y*wo.y)/__builtin_sqrtf(denom);
+        const float RoughnessToSigma = 1.0f/__builtin_sqrtf(2.0f);
+        float sigma = RoughnessToSigma*texEval(sc, d.roughness_tex, uvx, uvy).x;
+        float sigmaSq = sigma*sigma;
+        float C1 = 1.0f - 0.5f*sigmaSq/(sigmaSq + 0.33f);
+        float C2 = 0.45f*sigmaSq/(sigmaSq + 0.09f);
+        const float b2 = (2.0f*INV_PI)*beta;
+        if (cosDeltaPhi >= 0.0f) C2 *= sinAlpha;
+        else C2 *= sinAlpha - b2*b2*b2;
+        const float ab = (4.0f*INV_PI*INV_PI)*alpha*beta;
+        float C3 = 0.125f*(sigmaSq/(sigmaSq + 0.09f))*(ab*ab);
+        float fr1 = (C1 + cosDeltaPhi*C2*tgpu_tanf(beta) + (1.0f - __builtin_fabsf(cosDeltaPhi))*C3*tgpu_tanf(0.5f*(alpha + beta)));
+        float fr2 = 0.17f*sigmaSq/(sigmaSq + 0.13f)*(1.0f - cosDeltaPhi*(b2*b2));
+        V3 diffuseAlbedo = texEval(sc, d.albedo_tex, uvx, uvy);
+        return (diffuseAlbedo*fr1 + diffuseAlbedo*diffuseAlbedo*fr2)*wo.z*INV_PI;
+    }
+    if (d.type == TGPU_BSDF_PHONG) { // bsdfs/PhongBsdf.cpp:79-100
+        bool evalGlossy = (requested & GlossyReflectionLobe) != 0, evalDiffuse = (requested & DiffuseReflectionLobe) != 0;
+        if (!evalGlossy && !evalDiffuse) return V3(0.0f);
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return V3(0.0f);
+        const float brdfFactor = (d.exponent + 2.0f)*INV_TWO_PI;
+        float result = 0.0f;
+        if (evalDiffuse) result += d.diffuse_ratio*INV_PI;
+        if (evalGlossy) {
+            float cosTheta = V3(-wi.x, -wi.y, wi.z).dot(wo);
+            if (cosTheta > 0.0f) result += tgpu_powf(cosTheta, d.exponent)*brdfFactor*(1.0f - d.diffuse_ratio);
+        }
+        return texEval(sc, d.albedo_tex, uvx, uvy)*wo.z*result;
+    }
     return V3(0.0f);
 }
 
-TG_DEV float basePdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+template <class SC>
+TG_DEV float basePdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
 {
     if (d.type == TGPU_BSDF_LAMBERT) {
         if (!(requested & DiffuseReflectionLobe)) return 0.0f;
@@ -787,11 +834,32 @@ TG_DEV float basePdf(const DScene &sc, const tgpu_bsdf &d, const V3 &wi, const V
         V3 hr = (wi + wo).normalized();
         return mfPdf(d.distribution, sampleAlpha, hr)*0.25f/wi.dot(hr);
     }
+    if (d.type == TGPU_BSDF_OREN_NAYAR) { // bsdfs/OrenNayarBsdf.cpp:125-135
+        if (!(requested & DiffuseReflectionLobe)) return 0.0f;
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+        float ratio = clampf(texEval(sc, d.roughness_tex, uvx, uvy).x, 0.01f, 1.0f);
+        return INV_TWO_PI*ratio + (__builtin_fabsf(wo.z)*INV_PI)*(1.0f - ratio);
+    }
+    if (d.type == TGPU_BSDF_PHONG) { // bsdfs/PhongBsdf.cpp:102-121
+        bool evalGlossy = (requested & GlossyReflectionLobe) != 0, evalDiffuse = (requested & DiffuseReflectionLobe) != 0;
+        if (!evalGlossy && !evalDiffuse) return 0.0f;
+        if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+        const float pdfFactor = (d.exponent + 1.0f)*INV_TWO_PI;
+        float result = 0.0f;
+        if (evalGlossy) {
+            float cosTheta = V3(-wi.x, -wi.y, wi.z).dot(wo);
+            if (cosTheta > 0.0f) result += tgpu_powf(cosTheta, d.exponent)*pdfFactor;
+        }
+        if (evalDiffuse && evalGlossy) result = result*(1.0f - d.diffuse_ratio) + d.diffuse_ratio*(__builtin_fabsf(wo.z)*INV_PI);
+        else if (evalDiffuse) result = __builtin_fabsf(wo.z)*INV_PI;
+        return result;
+    }
     return 0.0f;
 }
 
 // samples with incident direction e.wi; fills e.wo, e.pdf, e.weight, e.sampledLobe
-TG_DEV bool baseSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+template <class SC>
+TG_DEV bool baseSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
     if (d.type == TGPU_BSDF_LAMBERT) {
         if (!(e.requestedLobe & DiffuseReflectionLobe)) return false;
@@ -827,6 +895,50 @@ TG_DEV bool baseSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &
         e.pdf = pdf;
         e.weight = texEval(sc, d.albedo_tex, e.uvx, e.uvy)*(F*weight);
         e.sampledLobe = GlossyReflectionLobe;
+        return true;
+    }
+    if (d.type == TGPU_BSDF_OREN_NAYAR) { // bsdfs/OrenNayarBsdf.cpp:41-61
+        if (!(e.requestedLobe & DiffuseReflectionLobe)) return false;
+        if (e.wi.z <= 0.0f) return false;
+        float ratio = clampf(texEval(sc, d.roughness_tex, e.uvx, e.uvy).x, 0.01f, 1.0f);
+        const bool uniform = s.nextBoolean(ratio);
+        float xix = s.next1D(), xiy = s.next1D();
+        float sp, cp;
+        tgpu_sincosf(xix*TWO_PI, &sp, &cp);
+        if (uniform) { // SampleWarp::uniformHemisphere (SampleWarp.hpp:25-30)
+            float r = __builtin_sqrtf(fmax2(1.0f - xiy*xiy, 0.0f));
+            e.wo = V3(cp*r, sp*r, xiy);
+        } else {
+            float r = __builtin_sqrtf(xiy);
+            e.wo = V3(cp*r, sp*r, __builtin_sqrtf(fmax2(1.0f - xiy, 0.0f)));
+        }
+        e.pdf = INV_TWO_PI*ratio + (__builtin_fabsf(e.wo.z)*INV_PI)*(1.0f - ratio);
+        e.weight = baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)/e.pdf;
+        e.sampledLobe = DiffuseReflectionLobe;
+        return e.wo.z > 0.0f;
+    }
+    if (d.type == TGPU_BSDF_PHONG) { // bsdfs/PhongBsdf.cpp:39-77
+        bool evalGlossy = (e.requestedLobe & GlossyReflectionLobe) != 0, evalDiffuse = (e.requestedLobe & DiffuseReflectionLobe) != 0;
+        if (!evalGlossy && !evalDiffuse) return false;
+        if (e.wi.z <= 0.0f) return false;
+        bool sampleGlossy = (evalGlossy && evalDiffuse) ? s.nextBoolean(1.0f - d.diffuse_ratio) : evalGlossy;
+        float xix = s.next1D(), xiy = s.next1D();
+        float sp, cp;
+        tgpu_sincosf(xix*TWO_PI, &sp, &cp);
+        if (sampleGlossy) {
+            float cosTheta = tgpu_powf(xiy, 1.0f/(1.0f + d.exponent));
+            float sinTheta = __builtin_sqrtf(fmax2(0.0f, 1.0f - cosTheta*cosTheta));
+            Frame lobe = duffFrame(V3(-e.wi.x, -e.wi.y, e.wi.z));
+            e.wo = lobe.toGlobal(V3(cp*sinTheta, sp*sinTheta, cosTheta));
+            if (e.wo.z < 0.0f) return false;
+            e.sampledLobe = GlossyReflectionLobe;
+        } else {
+            float r = __builtin_sqrtf(xiy);
+            e.wo = V3(cp*r, sp*r, __builtin_sqrtf(fmax2(1.0f - xiy, 0.0f)));
+            e.sampledLobe = DiffuseReflectionLobe;
+        }
+        e.pdf = basePdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+        e.weight = baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)/e.pdf;
         return true;
     }
     return false;
@@ -1126,11 +1238,271 @@ TG_DEV bool specularSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampl
 }
 
 
+// ---- thin sheets and the forward ("pass straight through") lobe ---------------------------------------
+TG_DEV float thinFilmReflectance(float eta, float cosThetaI, float &cosThetaT) // bsdfs/Fresnel.hpp:15-28
+{
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    cosThetaT = __builtin_sqrtf(fmax2(1.0f - sinThetaTSq, 0.0f));
+    float a = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT), b = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
+    float Rs = a*a, Rp = b*b;
+    return 1.0f - ((1.0f - Rs)/(1.0f + Rs) + (1.0f - Rp)/(1.0f + Rp))*0.5f;
+}
+// bsdf.eval(event.makeForwardEvent()) of handleSurface / generalizedShadowRay (TraceBase.cpp:522-535, :84-96): what fraction of
+// the radiance passes straight through the surface.  ForwardBsdf: 1; TransparencyBsdf: 1 - alpha; ThinSheetBsdf: the film's
+// transmittance at this angle; every other BSDF: 0.
+template <class SC>
+TG_DEV V3 forwardTransparency(const SC &sc, const tgpu_bsdf &d, float wiz, float uvx, float uvy)
+{
+    if (d.type == TGPU_BSDF_FORWARD) return V3(1.0f);
+    if (d.type == TGPU_BSDF_TRANSPARENCY) return V3(1.0f - texEval(sc, d.aux_tex, uvx, uvy).x); // TransparencyBsdf.cpp:47-53
+    if (d.type == TGPU_BSDF_THINSHEET) { // ThinSheetBsdf.cpp:83-103
+        float thickness = texEval(sc, d.aux_tex, uvx, uvy).x;
+        float cosThetaT;
+        V3 transmittance(1.0f - thinFilmReflectance(1.0f/d.ior, __builtin_fabsf(wiz), cosThetaT));
+        V3 sigmaA(d.sigma_a);
+        if (!sigmaA.isZero() && cosThetaT > 0.0f) transmittance *= expV3(-sigmaA*(thickness*2.0f/cosThetaT));
+        return transmittance;
+    }
+    return V3(0.0f);
+}
+
+// RoughCoatBsdf (bsdfs/RoughCoatBsdf.cpp:47-307) over a base BSDF
+template <class SC>
+TG_DEV void roughCoatSubstrate(const SC &sc, const tgpu_bsdf &d, const tgpu_bsdf &sub, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy,
+                               float eta, float Fi, float cosThetaTi, float &pdf, V3 &brdf) // substrateEvalAndPdf :47-87
+{
+    float cosThetaTo;
+    float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+    if (Fi == 1.0f || Fo == 1.0f) {
+        pdf = 0.0f;
+        brdf = V3(0.0f);
+        return;
+    }
+    V3 wiSubstrate(wi.x*eta, wi.y*eta, __builtin_copysignf(cosThetaTi, wi.z));
+    V3 woSubstrate(wo.x*eta, wo.y*eta, __builtin_copysignf(cosThetaTo, wo.z));
+    pdf = basePdf(sc, sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
+    pdf *= eta*eta*__builtin_fabsf(wo.z/cosThetaTo);
+    float compressionProjection = eta*eta*wo.z/cosThetaTo;
+    V3 substrateF = baseEval(sc, sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
+    V3 ss(d.scaled_sigma_a);
+    if (ss.max() > 0.0f) substrateF *= expV3(ss*(-1.0f/cosThetaTo - 1.0f/cosThetaTi));
+    brdf = compressionProjection*(1.0f - Fi)*(1.0f - Fo)*substrateF;
+}
+template <class SC>
+TG_DEV V3 roughCoatEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{   // :159-198
+    const tgpu_bsdf &sub = sc.bsdfs[d.substrate];
+    bool sampleR = (requested & GlossyReflectionLobe) != 0, sampleT = (requested & baseLobes(sub.type)) != 0;
+    if (!sampleT && !sampleR) return V3(0.0f);
+    if (wi.z <= 0.0f || wo.z <= 0.0f) return V3(0.0f);
+    V3 glossyR(0.0f);
+    if (sampleR) glossyR = rdEvalBase(wi, wo, true, false, texEval(sc, d.roughness_tex, uvx, uvy).x, d.ior, d.distribution);
+    V3 substrateR(0.0f);
+    if (sampleT) {
+        float eta = 1.0f/d.ior;
+        float cosThetaTi, pdfUnused;
+        float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+        roughCoatSubstrate(sc, d, sub, wi, wo, requested, uvx, uvy, eta, Fi, cosThetaTi, pdfUnused, substrateR);
+    }
+    return glossyR + substrateR;
+}
+template <class SC>
+TG_DEV float roughCoatPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{   // :256-298
+    const tgpu_bsdf &sub = sc.bsdfs[d.substrate];
+    bool sampleR = (requested & GlossyReflectionLobe) != 0, sampleT = (requested & baseLobes(sub.type)) != 0;
+    if (!sampleT && !sampleR) return 0.0f;
+    if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+    float eta = 1.0f/d.ior;
+    float cosThetaTi, cosThetaTo;
+    float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+    float Fo = dielectricReflectance(eta, wo.z, cosThetaTo);
+    float specularProbability;
+    if (sampleR && sampleT) {
+        float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        specularProbability = specularWeight/(specularWeight + substrateWeight);
+    } else {
+        specularProbability = sampleR ? 1.0f : 0.0f;
+    }
+    float glossyPdf = 0.0f;
+    if (sampleR) glossyPdf = rdPdfBase(wi, wo, true, false, texEval(sc, d.roughness_tex, uvx, uvy).x, d.ior, d.distribution);
+    float substratePdf = 0.0f;
+    if (sampleT && Fi < 1.0f && Fo < 1.0f) {
+        V3 wiSubstrate(wi.x*eta, wi.y*eta, __builtin_copysignf(cosThetaTi, wi.z));
+        V3 woSubstrate(wo.x*eta, wo.y*eta, __builtin_copysignf(cosThetaTo, wo.z));
+        substratePdf = basePdf(sc, sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
+        substratePdf *= eta*eta*__builtin_fabsf(wo.z/cosThetaTo);
+    }
+    return glossyPdf*specularProbability + substratePdf*(1.0f - specularProbability);
+}
+template <class SC>
+TG_DEV bool roughCoatSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{   // :89-157
+    if (e.wi.z <= 0.0f) return false;
+    const tgpu_bsdf &sub = sc.bsdfs[d.substrate];
+    bool sampleR = (e.requestedLobe & GlossyReflectionLobe) != 0, sampleT = (e.requestedLobe & baseLobes(sub.type)) != 0;
+    if (!sampleR && !sampleT) return false;
+    const V3 wi = e.wi;
+    float eta = 1.0f/d.ior;
+    float cosThetaTi;
+    float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+    float substrateWeight = d.avg_transmittance*(1.0f - Fi);
+    float specularWeight = Fi;
+    float specularProbability = specularWeight/(specularWeight + substrateWeight);
+    const float roughness = texEval(sc, d.roughness_tex, e.uvx, e.uvy).x;
+    if (sampleR && (s.nextBoolean(specularProbability) || !sampleT)) {
+        if (!rdSampleBase(e, s, true, false, roughness, d.ior, d.distribution)) return false;
+        if (sampleT) {
+            V3 brdfSubstrate, brdfSpecular = e.weight*e.pdf;
+            float pdfSubstrate, pdfSpecular = e.pdf*specularProbability;
+            roughCoatSubstrate(sc, d, sub, wi, e.wo, e.requestedLobe, e.uvx, e.uvy, eta, Fi, cosThetaTi, pdfSubstrate, brdfSubstrate);
+            pdfSubstrate *= 1.0f - specularProbability;
+            e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+            e.pdf = pdfSpecular + pdfSubstrate;
+        }
+        return true;
+    }
+    V3 wiSubstrate(wi.x*eta, wi.y*eta, cosThetaTi);
+    e.wi = wiSubstrate;
+    bool success = baseSample(sc, sub, e, s);
+    e.wi = wi;
+    if (!success) return false;
+    float cosThetaTo;
+    float Fo = dielectricReflectance(d.ior, e.wo.z, cosThetaTo);
+    if (Fo == 1.0f) return false;
+    float cosThetaSubstrate = e.wo.z;
+    e.wo = V3(e.wo.x*d.ior, e.wo.y*d.ior, cosThetaTo);
+    e.weight *= (1.0f - Fi)*(1.0f - Fo);
+    V3 ss(d.scaled_sigma_a);
+    if (ss.max() > 0.0f) e.weight *= expV3(ss*(-1.0f/cosThetaSubstrate - 1.0f/cosThetaTi));
+    e.weight *= wi.z/wiSubstrate.z;
+    e.pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+    if (sampleR) {
+        V3 brdfSubstrate = e.weight*e.pdf;
+        float pdfSubstrate = e.pdf*(1.0f - specularProbability);
+        V3 brdfSpecular = rdEvalBase(e.wi, e.wo, true, false, roughness, d.ior, d.distribution);
+        float pdfSpecular = rdPdfBase(e.wi, e.wo, true, false, roughness, d.ior, d.distribution);
+        pdfSpecular *= specularProbability;
+        e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+        e.pdf = pdfSpecular + pdfSubstrate;
+    }
+    return true;
+}
+
+// MixedBsdf (bsdfs/MixedBsdf.cpp:17-30,72-136) of two base BSDFs
+template <class SC>
+TG_DEV bool mixedRatio(const SC &sc, const tgpu_bsdf &d, uint32_t requested, float uvx, float uvy, float &ratio)
+{
+    bool sample0 = (requested & baseLobes(sc.bsdfs[d.substrate].type)) != 0, sample1 = (requested & baseLobes(sc.bsdfs[d.aux_bsdf].type)) != 0;
+    if (sample0 && sample1) ratio = texEval(sc, d.aux_tex, uvx, uvy).x;
+    else if (sample0) ratio = 1.0f;
+    else if (sample1) ratio = 0.0f;
+    else return false;
+    return true;
+}
+template <class SC>
+TG_DEV bool mixedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{
+    float ratio;
+    if (!mixedRatio(sc, d, e.requestedLobe, e.uvx, e.uvy, ratio)) return false;
+    const tgpu_bsdf &b0 = sc.bsdfs[d.substrate], &b1 = sc.bsdfs[d.aux_bsdf];
+    if (s.nextBoolean(ratio)) {
+        if (!baseSample(sc, b0, e, s)) return false;
+        float pdf0 = e.pdf*ratio;
+        float pdf1 = basePdf(sc, b1, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*(1.0f - ratio);
+        V3 f = e.weight*e.pdf*ratio + baseEval(sc, b1, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*(1.0f - ratio);
+        e.pdf = pdf0 + pdf1;
+        e.weight = f/e.pdf;
+    } else {
+        if (!baseSample(sc, b1, e, s)) return false;
+        float pdf0 = basePdf(sc, b0, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*ratio;
+        float pdf1 = e.pdf*(1.0f - ratio);
+        V3 f = baseEval(sc, b0, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*ratio + e.weight*e.pdf*(1.0f - ratio);
+        e.pdf = pdf0 + pdf1;
+        e.weight = f/e.pdf;
+    }
+    e.weight *= texEval(sc, d.albedo_tex, e.uvx, e.uvy);
+    return true;
+}
+
+// ---- the nested BSDFs (mixtures, coats, cut-outs, thin sheets): rare, and large once their children are inlined.  The shade kernels
+// inline them; the tail kernels' translation units leave them out (TG_NO_NESTED_BSDFS: inlined into the whole-path kernel they
+// multiply its compile time, and out-of-line calls of functions this size fault on gfx950 with ROCm 7.2 -- measured, profiles/r02_ab_notes.txt),
+// and the launcher keeps scenes that use them out of the tail kernel (ctx->hasNested)
+template <class SC>
+TG_DEV V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    if (d.type == TGPU_BSDF_MIXED) { // MixedBsdf.cpp:104-108
+        float ratio = texEval(sc, d.aux_tex, uvx, uvy).x;
+        return texEval(sc, d.albedo_tex, uvx, uvy)*(baseEval(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy)*ratio +
+                                                      baseEval(sc, sc.bsdfs[d.aux_bsdf], wi, wo, requested, uvx, uvy)*(1.0f - ratio));
+    }
+    if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatEval(sc, d, wi, wo, requested, uvx, uvy);
+    if (d.type == TGPU_BSDF_TRANSPARENCY || d.type == TGPU_BSDF_THINSHEET) { // TransparencyBsdf.cpp:47-53, ThinSheetBsdf.cpp:83-103
+        if (requested == uint32_t(ForwardLobe)) { // BsdfLobes::isForward(): exactly the forward lobe
+            V3 nwi = -wi;
+            return (nwi.x == wo.x && nwi.y == wo.y && nwi.z == wo.z) ? forwardTransparency(sc, d, wi.z, uvx, uvy) : V3(0.0f);
+        }
+        if (d.type == TGPU_BSDF_THINSHEET) return V3(0.0f);
+        return baseEval(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy);
+    }
+    return V3(0.0f);
+}
+template <class SC>
+TG_DEV float nestedPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+{
+    if (d.type == TGPU_BSDF_MIXED) { // MixedBsdf.cpp:125-131
+        float ratio;
+        if (!mixedRatio(sc, d, requested, uvx, uvy, ratio)) return 0.0f;
+        return basePdf(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy)*ratio +
+               basePdf(sc, sc.bsdfs[d.aux_bsdf], wi, wo, requested, uvx, uvy)*(1.0f - ratio);
+    }
+    if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatPdf(sc, d, wi, wo, requested, uvx, uvy);
+    if (d.type == TGPU_BSDF_TRANSPARENCY) return basePdf(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy); // TransparencyBsdf.cpp:60-63
+    if (d.type == TGPU_BSDF_THINSHEET) return ((requested & SpecularReflectionLobe) && checkReflectionConstraint(wi, wo)) ? 1.0f : 0.0f; // :111-118
+    return 0.0f;
+}
+template <class SC>
+TG_DEV bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+{
+    if (d.type == TGPU_BSDF_MIXED) return mixedSample(sc, d, e, s);
+    if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatSample(sc, d, e, s);
+    if (d.type == TGPU_BSDF_TRANSPARENCY) return baseSample(sc, sc.bsdfs[d.substrate], e, s); // TransparencyBsdf.cpp:42-45
+    if (d.type == TGPU_BSDF_THINSHEET) { // ThinSheetBsdf.cpp:50-81
+        if (!(e.requestedLobe & SpecularReflectionLobe)) return false;
+        e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
+        e.pdf = 1.0f;
+        e.sampledLobe = SpecularReflectionLobe;
+        V3 sigmaA(d.sigma_a);
+        if (sigmaA.isZero()) {
+            e.weight = V3(1.0f);
+            return true;
+        }
+        float thickness = texEval(sc, d.aux_tex, e.uvx, e.uvy).x;
+        float cosThetaT;
+        e.weight = V3(thinFilmReflectance(1.0f/d.ior, __builtin_fabsf(e.wi.z), cosThetaT));
+        V3 transmittance = V3(1.0f) - e.weight;
+        if (cosThetaT > 0.0f) transmittance *= expV3(-sigmaA*(thickness*2.0f/cosThetaT));
+        e.weight /= 1.0f - transmittance.avg();
+        return true;
+    }
+    return false;
+}
 TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
+#ifdef TG_NO_NESTED_BSDFS
+    if (d.type >= TGPU_BSDF_MIXED) return V3(0.0f);
+#else
+    if (d.type >= TGPU_BSDF_MIXED) return nestedEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+#endif
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
-    if (d.type >= TGPU_BSDF_MIRROR) return specularEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:146-178
     if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return V3(0.0f);
@@ -1158,9 +1530,14 @@ TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 
 TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
+#ifdef TG_NO_NESTED_BSDFS
+    if (d.type >= TGPU_BSDF_MIXED) return 0.0f;
+#else
+    if (d.type >= TGPU_BSDF_MIXED) return nestedPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+#endif
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
-    if (d.type >= TGPU_BSDF_MIRROR) return specularPdf(d, e.wi, e.wo, e.requestedLobe);
+    if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularPdf(d, e.wi, e.wo, e.requestedLobe);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return basePdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     // bsdfs/SmoothCoatBsdf.cpp:180-215
     if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
@@ -1192,9 +1569,14 @@ TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 
 TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
+#ifdef TG_NO_NESTED_BSDFS
+    if (d.type >= TGPU_BSDF_MIXED) return false;
+#else
+    if (d.type >= TGPU_BSDF_MIXED) return nestedSample(sc, d, e, s);
+#endif
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticSample(sc, d, e, s);
-    if (d.type >= TGPU_BSDF_MIRROR) return specularSample(sc, d, e, s);
+    if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularSample(sc, d, e, s);
     if (d.type != TGPU_BSDF_SMOOTH_COAT) return baseSample(sc, d, e, s);
     // bsdfs/SmoothCoatBsdf.cpp:41-100
     if (e.wi.z <= 0.0f) return false;

@@ -83,6 +83,10 @@ typedef Strided<uint4, 8> RecU4;
 typedef Strided<uint32_t, 32> RecU1;
 #define TG_REC_F4 8 /* float4 slots per record */
 
+// One OutputBuffer<float | Vec3f> (cameras/OutputBuffer.hpp:21-27) of the shard: nPixels x channels floats per part
+struct DOutBuf { float *a, *b, *var; uint32_t *count; };
+enum { AOV_RECORDED = 1u, AOV_VIS_PENDING = 2u }; // results[ref].w while the path runs
+
 struct DState {
     RecF4 rayO;     // origin.xyz, tnear
     RecF4 rayD;     // dir.xyz, tfar
@@ -106,7 +110,12 @@ struct DState {
     RecF4 shE;      // throughput at the vertex.xyz, bits(has post-add)
     RecF4 shF;      // emitter term to add after the NEE term.xyz
     RecU1 sampleRef;     // per slot: index into `results` of the sample the slot is tracing
-    float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w unused)
+    float4 *results;     // TG_RING x nPixels x resultSpp: final radiance of every sample (w: AOV_* bits while the path runs)
+    // auxiliary output buffers (renderer "output_buffers"; null otherwise), one record per sample next to `results`:
+    //   aov0 = (depth, normal.xyz), aov1 = (albedo.xyz, visibility); NaN = the sample adds nothing to that buffer
+    // (OutputBuffer::addSample drops NaN anyway).  Until the path records its first non-specular vertex aov0.x carries hitDistance.
+    float4 *aov0, *aov1;
+    DOutBuf out[TGPU_OUTPUT_COUNT]; // the output buffers themselves (k_accumulate*); out[0].a / .count alias fbMean / fbCount
     uint32_t *lists[2][TG_LISTS];
     uint32_t *freeQ;     // idle slots that were dropped from the lists (no sample admitted / end of render)
     RecU1 state;         // per slot: bit 0 = NEE terms of the slot's last vertex still have to be folded into its radiance (shC..shF valid),
@@ -229,11 +238,29 @@ TG_DEV uint32_t listTotal(const ListCounts &lc, int first)
 // the path next (the next vertex's shade / volume step, the environment lookup of an escaped path, the retire step of an
 // ended one, the tail kernel) -- all of them read these records anyway -- in the reference's order
 //   emission += ((0 + L*vis_L) + B*vis_B)*w*throughput   (TraceBase.cpp:383-400,483-494,537-538), then the emitter term (:540-543)
+// 'visibility' output buffer: the vertex that recorded the sample's auxiliary values left the transmittance of its light sample
+// as if the shadow ray were clear (AOV_VIS_PENDING); here the shadow ray's result is in.  shadow: the walked transmittance of
+// scenes with forward-scattering surfaces (TraceBase.cpp:167-169), else null and `clear` says whether the ray was unoccluded.
+// (out of line with plain values for arguments: nothing of the caller's private state is passed by address)
+static __device__ __noinline__ void aovVisibilityCall(float4 *results, float4 *aov1, uint32_t ref, bool clear, bool walked, float walkedAverage)
+{
+    float *w = reinterpret_cast<float *>(&results[ref]) + 3;
+    if (!(__float_as_uint(*w) & AOV_VIS_PENDING)) return;
+    if (walked) reinterpret_cast<float *>(&aov1[ref])[3] = walkedAverage;
+    else if (!clear) reinterpret_cast<float *>(&aov1[ref])[3] = 0.0f;
+    *w = __uint_as_float(AOV_RECORDED);
+}
+TG_DEV void aovVisibility(const DState &st, uint32_t slot, bool clear, bool walked, const V3 &shadow)
+{
+    aovVisibilityCall(st.results, st.aov1, st.sampleRef[slot], clear, walked, walked ? shadow.avg() : 0.0f);
+}
+
 TG_DEV V3 resolveNeeTerms(const DState &st, uint32_t slot, V3 em)
 {
     // (plain loads: the non-temporal form of this triple trips an 'even aligned vector registers' backend error in the general shade kernels)
     const float4 c = st.shC[slot], d = st.shD[slot], e = st.shE[slot];
     const uint32_t vis = __float_as_uint(d.w);
+    if (st.aov0) aovVisibility(st, slot, (vis & 1u) != 0, false, V3(0.0f));
     // an occluded term enters as +0: x + 0 == x bit for bit, so this is ((0 + L*vis_L) + B*vis_B) without branches
     const V3 lTerm = (vis & 1u) ? xyz(c) : V3(0.0f), bTerm = (vis & 2u) ? xyz(d) : V3(0.0f);
     V3 result = (V3(0.0f) + lTerm) + bTerm;
@@ -325,7 +352,14 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
     st.tp[slot] = mk4u(V3(1.0f), packFlags(0, true, END_ALIVE));
     st.em[slot] = mk4u(V3(0.0f), smp.scramble);
     st.samp[slot] = make_uint4(smp.dimension, uint32_t(smp.pcg), uint32_t(smp.pcg >> 32), smp.index);
-    st.sampleRef[slot] = jobs.ringSlot[j]*st.resultSlice + e;
+    const uint32_t ref = jobs.ringSlot[j]*st.resultSlice + e;
+    st.sampleRef[slot] = ref;
+    if (st.aov0) { // recordedOutputValues = false; hitDistance = 0 (PathTracer.cpp:41-42)
+        const float nan = __uint_as_float(0x7FC00000u);
+        st.aov0[ref] = make_float4(0.0f, nan, nan, nan);
+        st.aov1[ref] = make_float4(nan, nan, nan, nan);
+        reinterpret_cast<float *>(&st.results[ref])[3] = 0.0f;
+    }
     st.state[slot] = packState(false, END_ALIVE);
     if (sc.nMedia) st.med[slot] = uint32_t(sc.cam.medium + 1) | (1u << 8); // cam().medium(), MediumState::reset()
 }
@@ -341,6 +375,7 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
 // in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
 TG_DEV int missPathEx(const DScene &sc, const DState &st, uint32_t path, V3 &emOut, float &tpSumOut);
+TG_DEV void aovFinish(const DScene &sc, const DState &st, uint32_t path, uint32_t ref, bool epilogue);
 
 // Per shaded slot this kernel reads the 4-byte state word (compact array); only ended paths cost record sectors (radiance, pending
 // NEE terms, sample reference), escaped ones the whole path record (environment lookup).
@@ -404,9 +439,10 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK) k_retire_regenerate(DS
                 if (end != END_ALIVE) {
                     needs[k] = true;
                     if (end != END_DEAD) {
-                        if (end == END_ZERO) c = V3(0.0f);
-                        else if (end == END_CHECKED && isnanf_(tpSum + c.sum())) c = V3(0.0f); // PathTracer.cpp:130-131
+                        const bool nanEnd = end == END_CHECKED && isnanf_(tpSum + c.sum()); // PathTracer.cpp:130-131
+                        if (end == END_ZERO || nanEnd) c = V3(0.0f);
                         uint32_t ref = st.sampleRef[slot[k]];
+                        if (st.aov0) aovFinish(sc, st, slot[k], ref, end == END_CHECKED && !nanEnd);
                         st.results[ref] = mk4(c, 0.0f);
                         ring = ref/st.resultSlice;
                     }
@@ -1571,6 +1607,35 @@ TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path)
     (void)missPathEx(sc, st, path, em, tpSum);
 }
 
+// The auxiliary values of a sample whose path ended without recording them at a surface.  epilogue: the path left traceSample's
+// loop through its end (PathTracer.cpp:133-140: depth 0 for a primary ray that escaped, the direction it left in as the normal, the
+// environment's radiance as the albedo when handleInfiniteLights looked it up, TraceBase.cpp:570-578); otherwise it returned early
+// and adds nothing.  Either way the running hitDistance in aov0.x is no depth sample.
+TG_DEV void aovFinish(const DScene &sc, const DState &st, uint32_t path, uint32_t ref, bool epilogue)
+{
+    if (__float_as_uint(st.results[ref].w) & AOV_RECORDED) return;
+    const float nan = __uint_as_float(0x7FC00000u);
+    float4 a0 = make_float4(nan, nan, nan, nan);
+    if (epilogue) {
+        const int bounce = flagsBounce(__float_as_uint(st.tp[path].w));
+        const V3 D = xyz(st.rayD[path]);
+        if (bounce == 0) a0.x = 0.0f;
+        a0.y = -D.x; a0.z = -D.y; a0.w = -D.z;
+        if (bounce >= sc.settings.min_bounces && bounce < sc.settings.max_bounces && sc.env.present) {
+            V3 E;
+            if (sc.envConstant) {
+                E = V3(sc.textures[sc.env.emission_tex].value);
+            } else {
+                float ux, uy;
+                directionToUV(sc, D, ux, uy, nullptr);
+                E = texEval(sc, sc.env.emission_tex, ux, uy);
+            }
+            st.aov1[ref] = make_float4(E.x, E.y, E.z, nan);
+        }
+    }
+    st.aov0[ref] = a0;
+}
+
 
 // =================================================================================================
 // K3 shade
@@ -2368,7 +2433,16 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         // handleSurface (TraceBase.cpp:516-568): the forward-lobe test draws from the supplemental stream for every surface
         // hit.  transparency = bsdf.eval(forward event): (1,1,1) for a ForwardBsdf (ForwardBsdf.cpp:26-29; avg() == 1.0f),
         // zero for every other BSDF in scope
-        const bool passThrough = smp.nextBoolean((lobes & ForwardLobe) ? 1.0f : 0.0f);
+        // zero for a BSDF without that lobe; 1 - alpha for a TransparencyBsdf; the film's transmittance for a ThinSheetBsdf
+        // auxiliary output buffers: is this sample still waiting for its first non-specular vertex (PathTracer.cpp:78)?
+        const uint32_t aovRef = st.aov0 ? st.sampleRef[path] : 0u;
+        const bool aovOpen = st.aov0 && !(__float_as_uint(st.results[aovRef].w) & AOV_RECORDED);
+        bool visDefined = false; // the light sample reached its shadow test: `transmittance` of handleSurface is set (TraceBase.cpp:167-169)
+        float visClear = 0.0f;   // ... to this value if the shadow ray turns out clear (scenes without forward-scattering surfaces)
+        V3 transparency(0.0f);
+        if (lobes & ForwardLobe) transparency = forwardTransparency(sc, bsdf, ev.wi.z, info.uvx, info.uvy);
+        const float transparencyScalar = transparency.avg();
+        const bool passThrough = smp.nextBoolean(transparencyScalar);
         const bool fwdScene = MEDIA && sc.hasForward != 0; // shadow rays may cross surfaces: the shadow kernel applies the media
         int mediumL = -1, mediumB = -1;
 
@@ -2422,18 +2496,31 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
                                 lit = finiteLightHit(sc, light, info.p, ls.d, eps, ls.dist, farT, E, lightPdfUnused);
                             }
                             // generalizedShadowRay: the medium on the light's side attenuates the unoccluded segment (:261-262, :100-108)
+                            V3 clearShadow(1.0f);
                             if (media) {
                                 mediumL = overridesMedia ? (ls.d.dot(info.Ng) < 0.0f ? info.intMedium : info.extMedium) : curMedium;
-                                if (!fwdScene) E = neeTransmittance(sc, mediumL, farT, true)*E;
+                                if (!fwdScene) {
+                                    clearShadow = neeTransmittance(sc, mediumL, farT, true);
+                                    E = clearShadow*E;
+                                }
                             }
-                            if (lit && shadowPasses && !E.isZero()) {
-                                V3 lightF = f*E/ls.pdf;
-                                const float mis = powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
-                                lightF *= mis;
-                                L = lightF;
+                            if (lit) {
+                                visDefined = true;
+                                visClear = clearShadow.avg();
+                            }
+                            // the reference traces the shadow ray whatever E is; here a ray that cannot add radiance is only traced
+                            // when the 'visibility' buffer may want its result
+                            if (lit && shadowPasses && (!E.isZero() || aovOpen)) {
+                                if (!E.isZero()) { // (e == 0 returns before f*e/pdf, TraceBase.cpp:276-279)
+                                    V3 lightF = f*E/ls.pdf;
+                                    const float mis = powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
+                                    lightF *= mis;
+                                    L = lightF;
+                                    misL = mis;
+                                }
                                 dL = ls.d;
                                 tfarL = farT;
-                                fL = f; EL = E; pdfL = ls.pdf; misL = mis;
+                                fL = f; EL = E; pdfL = ls.pdf;
                             }
                         }
                     }
@@ -2497,10 +2584,10 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         bool sampled = !passThrough && bsdfSample(sc, bsdf, ev, smp);
         V3 wo(0.0f);
         bool alive = sampled;
-        if (passThrough) { // wo = ray.dir(); weight = transparency/transparencyScalar = 1; sampledLobe = ForwardLobe
+        if (passThrough) { // wo = ray.dir(); weight = transparency/transparencyScalar; sampledLobe = ForwardLobe
             wo = D;
             alive = true;
-            ev.weight = V3(1.0f);
+            ev.weight = transparency/transparencyScalar;
         }
         if (sampled) {
             wo = ev.frame.toGlobal(ev.wo);
@@ -2540,6 +2627,22 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
                     bounce++;
                     if (bounce >= maxBounces) end = END_CHECKED;
                 }
+            }
+        }
+        if (aovOpen) { // PathTracer.cpp:64,78-96 (wasSpecular as handleSurface left it; terminate = !alive)
+            const float hitDistance = st.aov0[aovRef].x + hw.x;
+            if (!wasSpecular || !alive) {
+                const tgpu_bsdf &shown = bsdf.type == TGPU_BSDF_TRANSPARENCY ? sc.bsdfs[bsdf.substrate] : bsdf; // :85-88
+                V3 albedo = texEval(sc, shown.albedo_tex, info.uvx, info.uvy);
+                if (info.emissive) albedo += info.backSide ? V3(0.0f) : texEval(sc, info.emissionTex, info.uvx, info.uvy);
+                float vis = __uint_as_float(0x7FC00000u);
+                const bool pending = visDefined && tfarL >= 0.0f;
+                if (visDefined) vis = pending ? visClear : 0.0f; // a shadow ray below min_bounces returns 0 (TraceBase.cpp:113-116)
+                st.aov0[aovRef] = mk4(V3(hitDistance, info.Ns.x, info.Ns.y), info.Ns.z);
+                st.aov1[aovRef] = mk4(albedo, vis);
+                reinterpret_cast<float *>(&st.results[aovRef])[3] = __uint_as_float(AOV_RECORDED | (pending ? AOV_VIS_PENDING : 0u));
+            } else {
+                reinterpret_cast<float *>(&st.aov0[aovRef])[0] = hitDistance;
             }
         }
         // NEE rays start at info.p.  For scene primitives that has the bits of the scatter origin (ray.hitpoint());
@@ -2653,8 +2756,16 @@ TG_DEV V3 shadowWalk(const DScene &sc, uint32_t *stack, V3 O, const V3 &D, float
                 if (!front || tc2 != t) backSide = true;
             }
             if (inst != INST_NONE) { intMedium = extMedium = -1; }
-            if (!(bsdfLobes(sc, sc.bsdfs[bsdf]) & ForwardLobe)) return V3(0.0f);
-            // transparency = eval(forward event) = 1
+            const tgpu_bsdf &bd = sc.bsdfs[bsdf];
+            if (!(bsdfLobes(sc, bd) & ForwardLobe)) return V3(0.0f);
+            if (bd.type != TGPU_BSDF_FORWARD) { // transparency = eval(forward event) (TraceBase.cpp:84-92); 1 for a ForwardBsdf
+                HitInfo hi;
+                fetchHitInfo(sc, prim, O, D, t, u, v, hi);
+                if (inst != INST_NONE) applyInstance(sc, inst, prim, O, D, t, hi);
+                const V3 transparency = forwardTransparency(sc, bd, duffFrame(hi.Ns).normal.dot(-D), hi.uvx, hi.uvy);
+                if (transparency.isZero()) return V3(0.0f);
+                throughput *= transparency;
+            }
             bounce++;
             if (bounce >= sc.settings.max_bounces) return V3(0.0f);
         }
@@ -2683,7 +2794,9 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
         const int bounce = int(__float_as_uint(ldStream(&st.shF[path]).w));
         const float4 g = ldStream(&st.shG[path]), h = ldStream(&st.shH[path]);
         if (a.w >= 0.0f) { // lightSample: e = shadow*E; lightF = f*e/pdf; lightF *= mis (TraceBase.cpp:272-283)
-            V3 eL = shadowWalk<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, mediumL, startsOnSurface, bounce, tc, rays)*xyz(g);
+            const V3 shadowL = shadowWalk<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, mediumL, startsOnSurface, bounce, tc, rays);
+            if (st.aov0) aovVisibility(st, path, false, true, shadowL);
+            V3 eL = shadowL*xyz(g);
             if (!eL.isZero()) {
                 V3 lightF = xyz(c)*eL/g.w;
                 lightF *= h.x;
@@ -2701,7 +2814,9 @@ TG_DEV void shadowPath(const DScene &sc, const DState &st, uint32_t *stack, uint
     } else {
         if (a.w >= 0.0f) {
             rays++;
-            if (!occluded<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc)) result += xyz(c);
+            const bool clear = !occluded<COUNT, INST>(sc, stack, O, xyz(a), ro.w, a.w, endCap, tc);
+            if (clear) result += xyz(c);
+            if (st.aov0) aovVisibility(st, path, clear, false, V3(0.0f));
         }
         if (b.w >= 0.0f) {
             rays++;
@@ -3301,9 +3416,10 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
             int end = flagsEnd(__float_as_uint(tpw.w));
             if (end != END_DEAD) { // retire (k_retire_regenerate's rules)
                 V3 c = xyz(st.em[slot]);
-                if (end == END_ZERO) c = V3(0.0f);
-                else if (end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum())) c = V3(0.0f);
+                const bool nanEnd = end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum());
+                if (end == END_ZERO || nanEnd) c = V3(0.0f);
                 uint32_t ref = st.sampleRef[slot];
+                if (st.aov0) aovFinish(sc, st, slot, ref, end == END_CHECKED && !nanEnd);
                 st.results[ref] = mk4(c, 0.0f);
                 ring = ref/st.resultSlice;
                 st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
@@ -3340,22 +3456,98 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
 // K7 accumulate: OutputBuffer::addSample in sample order (cameras/OutputBuffer.hpp:104-132)
 // =================================================================================================
 #ifdef TG_TU_MAIN
+// One pixel of one OutputBuffer in registers.  Buffers of one channel use .x only (the arithmetic is elementwise).
+struct ObAcc { V3 a, b, var; uint32_t n; };
+TG_DEV void obLoad(const DOutBuf &ob, int channels, uint32_t k, ObAcc &s)
+{
+    s.a = s.b = s.var = V3(0.0f);
+    s.n = ob.count[k];
+    if (channels == 3) {
+        s.a = V3(ob.a + size_t(k)*3);
+        if (ob.b) s.b = V3(ob.b + size_t(k)*3);
+        if (ob.var) s.var = V3(ob.var + size_t(k)*3);
+    } else {
+        s.a.x = ob.a[k];
+        if (ob.b) s.b.x = ob.b[k];
+        if (ob.var) s.var.x = ob.var[k];
+    }
+}
+TG_DEV void obStore(const DOutBuf &ob, int channels, uint32_t k, const ObAcc &s)
+{
+    ob.count[k] = s.n;
+    for (int c = 0; c < channels; ++c) {
+        const float a = c == 0 ? s.a.x : (c == 1 ? s.a.y : s.a.z), b = c == 0 ? s.b.x : (c == 1 ? s.b.y : s.b.z), v = c == 0 ? s.var.x : (c == 1 ? s.var.y : s.var.z);
+        ob.a[size_t(k)*channels + c] = a;
+        if (ob.b) ob.b[size_t(k)*channels + c] = b;
+        if (ob.var) ob.var[size_t(k)*channels + c] = v;
+    }
+}
+TG_DEV void obAdd(const DOutBuf &ob, ObAcc &s, const V3 &c) // OutputBuffer::addSample (cameras/OutputBuffer.hpp:104-132)
+{
+    if (isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) return;
+    const uint32_t sampleIdx = s.n++;
+    if (ob.var) {
+        V3 curr = s.a;
+        if (ob.b && sampleIdx > 0) {
+            const uint32_t sampleCountA = (sampleIdx + 1u)/2u, sampleCountB = sampleIdx/2u;
+            curr = (s.a*float(sampleCountA) + s.b*float(sampleCountB))/float(sampleIdx);
+        }
+        const V3 delta = c - curr;
+        curr += delta/float(sampleIdx + 1u);
+        s.var += delta*(c - curr);
+    }
+    if (ob.b) {
+        const float perBufferSampleCount = float(sampleIdx/2u + 1u);
+        if (sampleIdx & 1u) s.b += (c - s.b)/perBufferSampleCount;
+        else s.a += (c - s.a)/perBufferSampleCount;
+    } else {
+        s.a += (c - s.a)/float(sampleIdx + 1u);
+    }
+}
+// what sample `idx` of the ring slice adds to buffer `type` (one-channel values in .x)
+TG_DEV V3 outputSample(const DState &st, int type, size_t idx)
+{
+    if (type == TGPU_OUTPUT_COLOR) return xyz(st.results[idx]);
+    if (type == TGPU_OUTPUT_DEPTH) return V3(st.aov0[idx].x, 0.0f, 0.0f);
+    if (type == TGPU_OUTPUT_NORMAL) { const float4 v = st.aov0[idx]; return V3(v.y, v.z, v.w); }
+    if (type == TGPU_OUTPUT_ALBEDO) return xyz(st.aov1[idx]);
+    return V3(st.aov1[idx].w, 0.0f, 0.0f);
+}
+TG_DEV int outputChannels(int type) { return (type == TGPU_OUTPUT_DEPTH || type == TGPU_OUTPUT_VISIBILITY) ? 1 : 3; }
+// pixel k's samples of the job into every output buffer from `firstType` on: sample s sits at base + first + s*step
+TG_DEV void accumulateOutputs(const DState &st, int firstType, uint32_t k, size_t base, size_t first, size_t step, uint32_t count)
+{
+    for (int type = firstType; type < TGPU_OUTPUT_COUNT; ++type) {
+        const DOutBuf &ob = st.out[type];
+        if (!ob.a) continue;
+        const int channels = outputChannels(type);
+        ObAcc acc;
+        obLoad(ob, channels, k, acc);
+        for (uint32_t s = 0; s < count; ++s) obAdd(ob, acc, outputSample(st, type, base + first + size_t(s)*step));
+        obStore(ob, channels, k, acc);
+    }
+}
+
 static __global__ void __launch_bounds__(256) k_accumulate(DState st, uint32_t ringSlot, uint32_t sppCount)
 {
     const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
+    const bool plainColor = !st.out[TGPU_OUTPUT_COLOR].b && !st.out[TGPU_OUTPUT_COLOR].var;
     for (uint32_t k = blockIdx.x*blockDim.x + threadIdx.x; k < st.nPixels; k += gridDim.x*blockDim.x) {
-        V3 mean(st.fbMean + size_t(k)*3);
-        uint32_t n = st.fbCount[k];
-        for (uint32_t s = 0; s < sppCount; ++s) {
-            V3 c = xyz(res[size_t(s)*st.nPixels + k]);
-            if (isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) continue;
-            mean = mean + (c - mean)/float(n + 1u);
-            n++;
+        if (plainColor) {
+            V3 mean(st.fbMean + size_t(k)*3);
+            uint32_t n = st.fbCount[k];
+            for (uint32_t s = 0; s < sppCount; ++s) {
+                V3 c = xyz(res[size_t(s)*st.nPixels + k]);
+                if (isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) continue;
+                mean = mean + (c - mean)/float(n + 1u);
+                n++;
+            }
+            st.fbMean[size_t(k)*3 + 0] = mean.x;
+            st.fbMean[size_t(k)*3 + 1] = mean.y;
+            st.fbMean[size_t(k)*3 + 2] = mean.z;
+            st.fbCount[k] = n;
         }
-        st.fbMean[size_t(k)*3 + 0] = mean.x;
-        st.fbMean[size_t(k)*3 + 1] = mean.y;
-        st.fbMean[size_t(k)*3 + 2] = mean.z;
-        st.fbCount[k] = n;
+        if (!plainColor || st.aov0) accumulateOutputs(st, plainColor ? 1 : 0, k, size_t(ringSlot)*st.resultSlice, k, st.nPixels, sppCount);
     }
 }
 #endif
@@ -3369,6 +3561,7 @@ static __global__ void __launch_bounds__(256) k_accumulate_records(DState st, ui
 {
     const float4 *res = st.results + size_t(ringSlot)*st.resultSlice;
     const uint32_t *off = st.jobOffset + size_t(ringSlot)*(st.nPixels + 1u);
+    const bool plainColor = !st.out[TGPU_OUTPUT_COLOR].b && !st.out[TGPU_OUTPUT_COLOR].var;
     for (uint32_t vt = blockIdx.x*blockDim.x + threadIdx.x; vt < st.nVt; vt += gridDim.x*blockDim.x) {
         uint32_t sampleCount = st.recCount[vt];
         float mean = st.recMean[vt], runningVariance = st.recVar[vt];
@@ -3385,14 +3578,18 @@ static __global__ void __launch_bounds__(256) k_accumulate_records(DState st, ui
                 float delta = x - mean;
                 mean += delta/float(sampleCount);
                 runningVariance += delta*(x - mean);
-                if (isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) continue;
+                if (!plainColor || isnanf_(c.x) || isnanf_(c.y) || isnanf_(c.z) || isinff_(c.x) || isinff_(c.y) || isinff_(c.z)) continue;
                 pm = pm + (c - pm)/float(n + 1u);
                 n++;
             }
-            st.fbMean[size_t(k)*3 + 0] = pm.x;
-            st.fbMean[size_t(k)*3 + 1] = pm.y;
-            st.fbMean[size_t(k)*3 + 2] = pm.z;
-            st.fbCount[k] = n;
+            if (plainColor) {
+                st.fbMean[size_t(k)*3 + 0] = pm.x;
+                st.fbMean[size_t(k)*3 + 1] = pm.y;
+                st.fbMean[size_t(k)*3 + 2] = pm.z;
+                st.fbCount[k] = n;
+            }
+            if (!plainColor || st.aov0)
+                accumulateOutputs(st, plainColor ? 1 : 0, k, size_t(ringSlot)*st.resultSlice, adaptive ? size_t(first) : size_t(k), adaptive ? 1u : st.nPixels, cnt);
         }
         st.recCount[vt] = sampleCount;
         st.recMean[vt] = mean;
@@ -3453,10 +3650,8 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shadow<true, false, true>(DScene, DState, int); \
     PFX template __global__ void k_shadow<true, true, false>(DScene, DState, int); \
     PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
-#define TG_KERNELS_TAIL(PFX, I) \
-    PFX template __global__ void k_tail<false, I, false>(DScene, DState, int, uint32_t); \
-    PFX template __global__ void k_tail<false, I, true>(DScene, DState, int, uint32_t); \
-    PFX template __global__ void k_tail<true, I, false>(DScene, DState, int, uint32_t); \
-    PFX template __global__ void k_tail<true, I, true>(DScene, DState, int, uint32_t);
+#define TG_KERNELS_TAIL(PFX, C, I) \
+    PFX template __global__ void k_tail<C, I, false>(DScene, DState, int, uint32_t); \
+    PFX template __global__ void k_tail<C, I, true>(DScene, DState, int, uint32_t);
 
 } // namespace tg

@@ -29,8 +29,10 @@ TG_KERNELS_SHADE(extern, false)
 TG_KERNELS_SHADE(extern, true)
 TG_KERNELS_SHADOW(extern)
 TG_KERNELS_INSTQ(extern)
-TG_KERNELS_TAIL(extern, false)
-TG_KERNELS_TAIL(extern, true)
+TG_KERNELS_TAIL(extern, false, false)
+TG_KERNELS_TAIL(extern, false, true)
+TG_KERNELS_TAIL(extern, true, false)
+TG_KERNELS_TAIL(extern, true, true)
 }
 
 namespace {
@@ -86,6 +88,7 @@ struct tgpu_ctx {
     uint32_t nCur = 0, freeCount = 0;
     uint32_t listCount[TG_LISTS] = {0};
     uint64_t tailMax = 65536; // switch to the tail kernel below this many live paths
+    bool hasNested = false;   // the scene uses BSDF types the tail kernel is compiled without
     uint32_t tailSpread = 2;  // lanes per path in the tail kernel (power of two; TGPU_TAIL_SPREAD)
     uint64_t aliveCount = 0, hostExtendRays = 0;
     int curQ = 0;
@@ -199,12 +202,29 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
         const tgpu_bsdf &b = s->bsdfs[i];
         if (b.type < 0 || b.type >= TGPU_BSDF_NUM_TYPES) { fail(ctx, "bsdf %u has type %d outside the hot-path scope", i, b.type); return TGPU_ERR_UNSUPPORTED; }
         if (!texOk(b.albedo_tex)) { fail(ctx, "bsdf %u: bad albedo texture", i); return TGPU_ERR_INVALID; }
-        if (b.type == TGPU_BSDF_ROUGH_CONDUCTOR && !texOk(b.roughness_tex)) { fail(ctx, "bsdf %u: bad roughness texture", i); return TGPU_ERR_INVALID; }
+        if ((b.type == TGPU_BSDF_ROUGH_CONDUCTOR || b.type == TGPU_BSDF_OREN_NAYAR) && !texOk(b.roughness_tex)) { fail(ctx, "bsdf %u: bad roughness texture", i); return TGPU_ERR_INVALID; }
         if (b.type == TGPU_BSDF_ROUGH_CONDUCTOR && b.distribution == TGPU_DIST_PHONG) { fail(ctx, "bsdf %u: phong microfacet distribution is outside the hot-path scope", i); return TGPU_ERR_UNSUPPORTED; }
-        if (b.type == TGPU_BSDF_SMOOTH_COAT) {
-            if (b.substrate < 0 || uint32_t(b.substrate) >= s->n_bsdfs) { fail(ctx, "bsdf %u: bad substrate", i); return TGPU_ERR_INVALID; }
-            int st = s->bsdfs[b.substrate].type;
-            if (st != TGPU_BSDF_LAMBERT && st != TGPU_BSDF_ROUGH_CONDUCTOR) { fail(ctx, "bsdf %u: smooth_coat substrate must be lambert or rough_conductor", i); return TGPU_ERR_UNSUPPORTED; }
+        // nested BSDFs (coats, mixtures, cut-outs): the children are the single-layer opaque reflectors
+        auto childOk = [&](int c, const char *what) {
+            if (c < 0 || uint32_t(c) >= s->n_bsdfs) { fail(ctx, "bsdf %u: bad %s", i, what); return TGPU_ERR_INVALID; }
+            const int st = s->bsdfs[c].type;
+            if (st != TGPU_BSDF_LAMBERT && st != TGPU_BSDF_ROUGH_CONDUCTOR && st != TGPU_BSDF_OREN_NAYAR && st != TGPU_BSDF_PHONG) {
+                fail(ctx, "bsdf %u: %s must be lambert, rough_conductor, oren_nayar or phong", i, what);
+                return TGPU_ERR_UNSUPPORTED;
+            }
+            return TGPU_OK;
+        };
+        if (b.type == TGPU_BSDF_SMOOTH_COAT || b.type == TGPU_BSDF_ROUGH_COAT || b.type == TGPU_BSDF_TRANSPARENCY || b.type == TGPU_BSDF_MIXED)
+            if (int rc = childOk(b.substrate, b.type == TGPU_BSDF_MIXED ? "first mixture component" : (b.type == TGPU_BSDF_TRANSPARENCY ? "base" : "substrate"))) return rc;
+        if (b.type == TGPU_BSDF_MIXED)
+            if (int rc = childOk(b.aux_bsdf, "second mixture component")) return rc;
+        if ((b.type == TGPU_BSDF_MIXED || b.type == TGPU_BSDF_TRANSPARENCY || b.type == TGPU_BSDF_THINSHEET) && !texOk(b.aux_tex)) {
+            fail(ctx, "bsdf %u: bad ratio / alpha / thickness texture", i);
+            return TGPU_ERR_INVALID;
+        }
+        if (b.type == TGPU_BSDF_ROUGH_COAT) {
+            if (!texOk(b.roughness_tex)) { fail(ctx, "bsdf %u: bad roughness texture", i); return TGPU_ERR_INVALID; }
+            if (b.distribution == TGPU_DIST_PHONG) { fail(ctx, "bsdf %u: phong microfacet distribution is outside the hot-path scope", i); return TGPU_ERR_UNSUPPORTED; }
         }
     }
     auto bsdfOk = [&](int b) { return b >= 0 && uint32_t(b) < s->n_bsdfs; };
@@ -590,8 +610,13 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (uint32_t i = 0; i < s->n_lights; ++i) if (s->lights[i].kind == TGPU_LIGHT_SPHERE || s->lights[i].kind == TGPU_LIGHT_DISK) ctx->generalShading = true;
     ctx->classMask = 0;
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) ctx->classMask |= 1u << std::min<uint32_t>(uint32_t(s->bsdfs[i].type), uint32_t(TG_CLASS_OTHER));
-    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type == TGPU_BSDF_FORWARD) sc.hasForward = 1;
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) { // every BSDF with a ForwardLobe lets shadow rays through
+        const int t = s->bsdfs[i].type;
+        if (t == TGPU_BSDF_FORWARD || t == TGPU_BSDF_TRANSPARENCY || t == TGPU_BSDF_THINSHEET) sc.hasForward = 1;
+    }
     if (sc.hasForward) ctx->generalShading = true; // the shadow walk needs the NEE factors the general shade kernels store
+    ctx->hasNested = false; // mixtures, coats, cut-outs, thin sheets: shaded by the wavefront kernels only (device.h, TG_NO_NESTED_BSDFS)
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type >= TGPU_BSDF_MIXED) ctx->hasNested = true;
     sc.textures = dTex;
     sc.lights = dLights; sc.nLights = s->n_lights;
     {   // media + the table of fmath::exp_ps (fmath.hpp:106-126: a = n/logf(2), b = logf(2)/n, tbl[i] = mantissa(pow(2.0f, i/n)))
@@ -705,6 +730,26 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if ((rc = upload<float>(ctx, ctx->stateAllocs, nullptr, size_t(shard->n_pixels)*3, &dMean))) return rc;
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, shard->n_pixels, &dCnt))) return rc;
     st.pixelIndex = dPix; st.scramble = dScr; st.fbMean = dMean; st.fbCount = dCnt;
+    // renderer "output_buffers" (Camera::requestOutputBuffers, Camera.cpp:148-166): the colour buffer's optional parts and the
+    // auxiliary buffers
+    bool anyAux = false;
+    for (int t = 0; t < TGPU_OUTPUT_COUNT; ++t) {
+        const tgpu_output_buffer &ob = s->output_buffers[t];
+        DOutBuf &d = st.out[t];
+        d = DOutBuf{nullptr, nullptr, nullptr, nullptr};
+        if (t != TGPU_OUTPUT_COLOR && !ob.enabled) continue;
+        const size_t n = size_t(shard->n_pixels)*((t == TGPU_OUTPUT_DEPTH || t == TGPU_OUTPUT_VISIBILITY) ? 1 : 3);
+        if (t == TGPU_OUTPUT_COLOR) {
+            d.a = dMean;
+            d.count = dCnt;
+        } else {
+            anyAux = true;
+            if ((rc = upload<float>(ctx, ctx->stateAllocs, nullptr, n, &d.a))) return rc;
+            if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, shard->n_pixels, &d.count))) return rc;
+        }
+        if (ob.two_buffer_variance && (rc = upload<float>(ctx, ctx->stateAllocs, nullptr, n, &d.b))) return rc;
+        if (ob.sample_variance && (rc = upload<float>(ctx, ctx->stateAllocs, nullptr, n, &d.var))) return rc;
+    }
 
     // ---- variance tiles (4x4 pixel blocks, PathTraceIntegrator.hpp:27-29) of the shard ----
     ctx->trackRecords = s->settings.adaptive_sampling != 0;
@@ -805,6 +850,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     st.resultSlice = shard->n_pixels*ctx->resultSpp;
     if (ctx->trackRecords) st.resultSlice += st.resultSlice/2 + 64; // adaptive passes move samples between regions/ranks
     if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, size_t(st.resultSlice)*TG_RING, &st.results))) return rc;
+    if (anyAux) { // _trackOutputValues (PathTracer.cpp:11): one auxiliary record per sample next to its radiance
+        if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, size_t(st.resultSlice)*TG_RING, &st.aov0))) return rc;
+        if ((rc = upload<float4>(ctx, ctx->stateAllocs, nullptr, size_t(st.resultSlice)*TG_RING, &st.aov1))) return rc;
+    }
 
     ctx->stats = tgpu_stats{};
     ctx->uploaded = true;
@@ -904,7 +953,7 @@ static int driveIteration(tgpu_ctx *ctx)
     }
     // tail mode: nothing left to start and only a few long paths alive -> one launch finishes them all
     bool tail = false;
-    if (nCur > 0 && ctx->aliveCount > 0 && ctx->aliveCount <= ctx->tailMax && ctx->sampleBase == limit) {
+    if (nCur > 0 && ctx->aliveCount > 0 && ctx->aliveCount <= ctx->tailMax && !ctx->hasNested && ctx->sampleBase == limit) {
         std::lock_guard<std::mutex> lk(ctx->mtx);
         tail = ctx->pending.empty();
     }
@@ -1312,6 +1361,43 @@ int tgpu_upload_framebuffer(tgpu_ctx *ctx, const float *rgb, const uint32_t *cnt
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->st.fbMean, rgb, size_t(ctx->nPixels)*3*sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->st.fbCount, cnt, size_t(ctx->nPixels)*sizeof(uint32_t), hipMemcpyHostToDevice));
+    return TGPU_OK;
+}
+
+static int outputPart(tgpu_ctx *ctx, int type, int part, void **ptr, size_t *bytes)
+{
+    if (!ctx) return TGPU_ERR_INVALID;
+    if (!ctx->uploaded) { fail(ctx, "output buffer access before tgpu_upload_scene"); return TGPU_ERR_STATE; }
+    if (type < 0 || type >= TGPU_OUTPUT_COUNT || part < 0 || part > TGPU_PART_COUNT) { fail(ctx, "no output buffer %d / part %d", type, part); return TGPU_ERR_INVALID; }
+    const DOutBuf &d = ctx->st.out[type];
+    const size_t channels = (type == TGPU_OUTPUT_DEPTH || type == TGPU_OUTPUT_VISIBILITY) ? 1 : 3;
+    *ptr = part == TGPU_PART_A ? static_cast<void *>(d.a) : part == TGPU_PART_B ? static_cast<void *>(d.b) : part == TGPU_PART_VARIANCE ? static_cast<void *>(d.var)
+                                                                                                                                       : static_cast<void *>(d.count);
+    *bytes = size_t(ctx->nPixels)*(part == TGPU_PART_COUNT ? sizeof(uint32_t) : channels*sizeof(float));
+    if (!*ptr) { fail(ctx, "output buffer %d has no part %d (not requested at upload)", type, part); return TGPU_ERR_INVALID; }
+    (void)waitIdle(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGPU_OK;
+}
+
+int tgpu_download_output_buffer(tgpu_ctx *ctx, int type, int part, void *dst)
+{
+    void *p;
+    size_t bytes;
+    if (!dst) return TGPU_ERR_INVALID;
+    if (int rc = outputPart(ctx, type, part, &p, &bytes)) return rc;
+    HIP_TRY(ctx, hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    return TGPU_OK;
+}
+
+int tgpu_upload_output_buffer(tgpu_ctx *ctx, int type, int part, const void *src)
+{
+    void *p;
+    size_t bytes;
+    if (!src) return TGPU_ERR_INVALID;
+    if (int rc = outputPart(ctx, type, part, &p, &bytes)) return rc;
+    HIP_TRY(ctx, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     return TGPU_OK;
 }
 

@@ -3,5 +3,5 @@
 #include "kernels.h"
 
 namespace tg {
-TG_KERNELS_TAIL(, false, true)
+TG_KERNELS_TAIL(, true, true)
 }

@@ -45,6 +45,15 @@ void tgh_scene_set_bounces(tgh_scene *s, int minBounces, int maxBounces)
 }
 void tgh_scene_set_light_sampling(tgh_scene *s, int enable) { s->scene.settings.enable_light_sampling = enable; }
 void tgh_scene_set_sobol(tgh_scene *s, int enable) { s->scene.renderer.useSobol = enable != 0; }
+// one more entry of renderer "output_buffers" (before tgh_scene_flatten); type: tgpu_output_type
+void tgh_scene_add_output_buffer(tgh_scene *s, int type, int twoBufferVariance, int sampleVariance)
+{
+    OutputBufferSettings b;
+    b.type = type;
+    b.twoBufferVariance = twoBufferVariance != 0;
+    b.sampleVariance = sampleVariance != 0;
+    s->scene.renderer.outputs.push_back(b);
+}
 
 int tgh_scene_flatten(tgh_scene *s, char *err, int errLen)
 {

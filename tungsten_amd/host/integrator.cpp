@@ -2,8 +2,10 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <sstream>
 #include <stdexcept>
 
@@ -13,6 +15,121 @@ static void check(tgpu_ctx *ctx, int rc, const char *what)
 {
     if (rc != TGPU_OK)
         throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + tgpu_last_error(ctx));
+}
+
+static int outputChannels(int type) { return (type == TGPU_OUTPUT_DEPTH || type == TGPU_OUTPUT_VISIBILITY) ? 1 : 3; }
+
+bool Integrator::hasOutputPart(int type, int part) const
+{
+    const tgpu_output_buffer &b = _scene->desc().output_buffers[type];
+    if (type != TGPU_OUTPUT_COLOR && !b.enabled) return false;
+    if (part == TGPU_PART_B) return b.two_buffer_variance != 0;
+    if (part == TGPU_PART_VARIANCE) return b.sample_variance != 0;
+    return true;
+}
+
+void Integrator::outputBufferMean(int type, std::vector<float> &values)
+{
+    const int channels = outputChannels(type);
+    std::vector<uint32_t> a, b, n;
+    downloadOutputPart(type, TGPU_PART_A, a);
+    values.resize(a.size());
+    std::memcpy(values.data(), a.data(), a.size()*sizeof(float));
+    if (!hasOutputPart(type, TGPU_PART_B)) return;
+    downloadOutputPart(type, TGPU_PART_B, b);
+    downloadOutputPart(type, TGPU_PART_COUNT, n);
+    for (size_t i = 0; i < n.size(); ++i) {
+        const uint32_t sampleIdx = n[i], sampleCountA = (sampleIdx + 1)/2, sampleCountB = sampleIdx/2;
+        for (int c = 0; c < channels; ++c) {
+            float fa, fb;
+            std::memcpy(&fa, &a[i*channels + c], 4);
+            std::memcpy(&fb, &b[i*channels + c], 4);
+            values[i*channels + c] = (fa*float(sampleCountA) + fb*float(sampleCountB))/float(std::max(sampleIdx, 1u));
+        }
+    }
+}
+
+// OutputBuffer::saveLdr (OutputBuffer.hpp:57-88): depth is rescaled to its finite maximum, normals from [-1, 1], the rest as is
+static void saveOutputLdr(int type, const float *hdr, int channels, int w, int h, const std::string &path, bool rescale)
+{
+    const size_t pixelCount = size_t(w)*h;
+    float minimum[3] = {0.0f, 0.0f, 0.0f}, maximum[3] = {0.0f, 0.0f, 0.0f};
+    auto average = [&](const float *p) { return channels == 1 ? p[0] : (p[0] + p[1] + p[2])*(1.0f/3.0f); };
+    if (type == TGPU_OUTPUT_DEPTH) {
+        for (size_t i = 0; i < pixelCount; ++i)
+            if (average(hdr + i*channels) != std::numeric_limits<float>::infinity())
+                for (int c = 0; c < channels; ++c) maximum[c] = std::max(maximum[c], hdr[i*channels + c]);
+    } else if (type == TGPU_OUTPUT_NORMAL) {
+        for (int c = 0; c < 3; ++c) { minimum[c] = -1.0f; maximum[c] = 1.0f; }
+    } else {
+        rescale = false;
+    }
+    std::vector<uint8_t> ldr(pixelCount*3);
+    for (size_t i = 0; i < pixelCount; ++i) {
+        float f[3] = {0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < channels; ++c) {
+            f[c] = hdr[i*channels + c];
+            if (rescale) f[c] = (f[c] - minimum[c])/(maximum[c] - minimum[c]);
+        }
+        const float avg = average(f);
+        for (int c = 0; c < 3; ++c) {
+            const float v = f[channels == 1 ? 0 : c];
+            ldr[i*3 + c] = (std::isnan(avg) || std::isinf(avg)) ? uint8_t(255) : uint8_t(std::min(std::max(int(v*255.0f), 0), 255));
+        }
+    }
+    if (!savePng(path, ldr.data(), w, h)) throw std::runtime_error("Unable to write " + path);
+}
+
+static void saveOutputHdr(const std::string &path, const float *img, int w, int h, int channels)
+{
+    if (path.size() < 4 || path.substr(path.size() - 4) != ".pfm")
+        throw std::runtime_error("hdr_output_file '" + path + "': only .pfm is supported (no OpenEXR here, as in the reference build)");
+    if (!savePfm(path, img, w, h, channels)) throw std::runtime_error("Unable to write " + path);
+}
+
+void Integrator::saveOutputBuffers()
+{
+    const int w = int(_scene->resX), h = int(_scene->resY);
+    auto withTag = [](const std::string &file, const char *tag) { // Path::stripExtension() + tag + Path::extension()
+        size_t dot = file.find_last_of('.');
+        return dot == std::string::npos ? file + tag : file.substr(0, dot) + tag + file.substr(dot);
+    };
+    for (int type = 0; type < TGPU_OUTPUT_COUNT; ++type) { // colour, depth, normal, albedo, visibility (Camera.cpp:213-220)
+        const OutputBufferSettings *settings = nullptr;
+        for (const OutputBufferSettings &b : _scene->renderer.outputs)
+            if (b.type == type) settings = &b;
+        if (!settings) continue;
+        const int channels = outputChannels(type);
+        std::vector<float> mean;
+        outputBufferMean(type, mean);
+        const std::string &ldrFile = settings->ldrOutputFile, &hdrFile = settings->hdrOutputFile;
+        if (!hdrFile.empty()) saveOutputHdr(hdrFile, mean.data(), w, h, channels);
+        if (!ldrFile.empty()) saveOutputLdr(type, mean.data(), channels, w, h, ldrFile, true);
+        if (hasOutputPart(type, TGPU_PART_B)) {
+            for (int part : {TGPU_PART_A, TGPU_PART_B}) {
+                std::vector<uint32_t> words;
+                downloadOutputPart(type, part, words);
+                const float *half = reinterpret_cast<const float *>(words.data());
+                const char *tag = part == TGPU_PART_A ? "A" : "B";
+                if (!hdrFile.empty()) saveOutputHdr(withTag(hdrFile, tag), half, w, h, channels);
+                if (!ldrFile.empty()) saveOutputLdr(type, half, channels, w, h, withTag(ldrFile, tag), true);
+            }
+        }
+        if (hasOutputPart(type, TGPU_PART_VARIANCE)) {
+            std::vector<uint32_t> var, n;
+            downloadOutputPart(type, TGPU_PART_VARIANCE, var);
+            downloadOutputPart(type, TGPU_PART_COUNT, n);
+            std::vector<float> scaled(var.size());
+            for (size_t i = 0; i < n.size(); ++i)
+                for (int c = 0; c < channels; ++c) {
+                    float v;
+                    std::memcpy(&v, &var[i*channels + c], 4);
+                    scaled[i*channels + c] = v/float(n[i]*std::max(1u, n[i] - 1u));
+                }
+            if (!hdrFile.empty()) saveOutputHdr(withTag(hdrFile, "Variance"), scaled.data(), w, h, channels);
+            if (!ldrFile.empty()) saveOutputLdr(type, scaled.data(), channels, w, h, withTag(ldrFile, "Variance"), false);
+        }
+    }
 }
 
 void Integrator::writeBuffers(const std::string &suffix, bool /*overwrite*/)
@@ -35,6 +152,7 @@ void Integrator::writeBuffers(const std::string &suffix, bool /*overwrite*/)
             throw std::runtime_error("hdr_output_file: only .pfm is supported (no OpenEXR here, as in the reference build)");
         if (!savePfm(withSuffix(r.hdrOutputFile), hdr.data(), w, h)) throw std::runtime_error("Unable to write " + r.hdrOutputFile);
     }
+    if (suffix.empty() && !r.outputs.empty()) saveOutputBuffers(); // Integrator.cpp:78-79
 }
 
 // the scene text without its top-level "renderer" member (the reference leaves the renderer settings out of the hash so that spp or
@@ -89,11 +207,15 @@ void Integrator::saveRenderResumeData()
     out.write(h.c_str(), std::streamsize(h.size() + 1)); // FileUtils::streamWrite<std::string>: the characters and a NUL
     const uint64_t hash = sceneHash(*_scene);
     out.write(reinterpret_cast<const char *>(&hash), sizeof(hash));
-    std::vector<float> rgb;
-    std::vector<uint32_t> counts;
-    downloadOutputBuffer(rgb, counts);
-    out.write(reinterpret_cast<const char *>(rgb.data()), std::streamsize(rgb.size()*sizeof(float)));
-    out.write(reinterpret_cast<const char *>(counts.data()), std::streamsize(counts.size()*sizeof(uint32_t)));
+    // Camera::serializeOutputBuffers (Camera.cpp:222-229): colour, depth, normal, albedo, visibility; of each the parts it has, in the
+    // order of OutputBuffer::serialize (OutputBuffer.hpp:216-226)
+    std::vector<uint32_t> words;
+    for (int type = 0; type < TGPU_OUTPUT_COUNT; ++type)
+        for (int part : {TGPU_PART_A, TGPU_PART_B, TGPU_PART_VARIANCE, TGPU_PART_COUNT}) {
+            if (!hasOutputPart(type, part)) continue;
+            downloadOutputPart(type, part, words);
+            out.write(reinterpret_cast<const char *>(words.data()), std::streamsize(words.size()*sizeof(uint32_t)));
+        }
     saveState(out);
 }
 
@@ -120,13 +242,17 @@ bool Integrator::resumeRender(bool *hashMismatch)
     if (!in) return false;
     if (jsonHash != sceneHash(*_scene) && hashMismatch) *hashMismatch = true; // see the header comment: a warning, not a refusal
     const size_t nPixels = size_t(_scene->resX)*_scene->resY;
-    std::vector<float> rgb(nPixels*3);
-    std::vector<uint32_t> counts(nPixels);
-    in.read(reinterpret_cast<char *>(rgb.data()), std::streamsize(rgb.size()*sizeof(float)));
-    in.read(reinterpret_cast<char *>(counts.data()), std::streamsize(counts.size()*sizeof(uint32_t)));
-    if (!in) return false; // another resolution
+    struct Part { int type, part; std::vector<uint32_t> words; };
+    std::vector<Part> parts;
+    for (int type = 0; type < TGPU_OUTPUT_COUNT; ++type)
+        for (int part : {TGPU_PART_A, TGPU_PART_B, TGPU_PART_VARIANCE, TGPU_PART_COUNT}) {
+            if (!hasOutputPart(type, part)) continue;
+            parts.push_back(Part{type, part, std::vector<uint32_t>(nPixels*(part == TGPU_PART_COUNT ? 1 : outputChannels(type)))});
+            in.read(reinterpret_cast<char *>(parts.back().words.data()), std::streamsize(parts.back().words.size()*sizeof(uint32_t)));
+        }
+    if (!in) return false; // another resolution or another set of output buffers
     if (!loadState(in)) return false;
-    uploadOutputBuffer(rgb, counts);
+    for (const Part &p : parts) uploadOutputPart(p.type, p.part, p.words);
     _currentSpp = uint32_t(jsonSpp);
     advanceSpp();
     return true;
@@ -243,6 +369,10 @@ void PathTraceIntegrator::abortRender()
 
 void PathTraceIntegrator::frameBuffer(std::vector<float> &rgb)
 {
+    if (hasOutputPart(TGPU_OUTPUT_COLOR, TGPU_PART_B)) { // Camera::getLinear reads OutputBuffer::operator[]
+        outputBufferMean(TGPU_OUTPUT_COLOR, rgb);
+        return;
+    }
     rgb.assign(size_t(_scene->resX)*_scene->resY*3, 0.0f);
     std::vector<float> local;
     for (Device &d : _devices) {
@@ -282,6 +412,31 @@ void PathTraceIntegrator::uploadOutputBuffer(const std::vector<float> &rgb, cons
             localCnt[i] = counts[d.shard.pixelIndex[i]];
         }
         check(d.ctx, tgpu_upload_framebuffer(d.ctx, local.data(), localCnt.data()), "tgpu_upload_framebuffer");
+    }
+}
+
+void PathTraceIntegrator::downloadOutputPart(int type, int part, std::vector<uint32_t> &words)
+{
+    const size_t channels = part == TGPU_PART_COUNT ? 1 : size_t(outputChannels(type));
+    words.assign(size_t(_scene->resX)*_scene->resY*channels, 0u);
+    std::vector<uint32_t> local;
+    for (Device &d : _devices) {
+        local.resize(d.shard.pixelIndex.size()*channels);
+        check(d.ctx, tgpu_download_output_buffer(d.ctx, type, part, local.data()), "tgpu_download_output_buffer");
+        for (size_t i = 0; i < d.shard.pixelIndex.size(); ++i)
+            std::memcpy(&words[size_t(d.shard.pixelIndex[i])*channels], &local[i*channels], channels*sizeof(uint32_t));
+    }
+}
+
+void PathTraceIntegrator::uploadOutputPart(int type, int part, const std::vector<uint32_t> &words)
+{
+    const size_t channels = part == TGPU_PART_COUNT ? 1 : size_t(outputChannels(type));
+    std::vector<uint32_t> local;
+    for (Device &d : _devices) {
+        local.resize(d.shard.pixelIndex.size()*channels);
+        for (size_t i = 0; i < d.shard.pixelIndex.size(); ++i)
+            std::memcpy(&local[i*channels], &words[size_t(d.shard.pixelIndex[i])*channels], channels*sizeof(uint32_t));
+        check(d.ctx, tgpu_upload_output_buffer(d.ctx, type, part, local.data()), "tgpu_upload_output_buffer");
     }
 }
 

@@ -49,6 +49,15 @@ public:
     // OutputBuffer::_bufferA / _sampleCount in image order, out and back in (serialize / deserialize, OutputBuffer.hpp:191-211)
     virtual void downloadOutputBuffer(std::vector<float> &rgb, std::vector<uint32_t> &counts) = 0;
     virtual void uploadOutputBuffer(const std::vector<float> &rgb, const std::vector<uint32_t> &counts) = 0;
+    // Any part (tgpu_output_part) of any output buffer (tgpu_output_type) as 4-byte words in image order: pixels x channels floats,
+    // or pixels uint32 counts.  hasOutputPart: was it requested (renderer "output_buffers"; colour A / COUNT always are)?
+    bool hasOutputPart(int type, int part) const;
+    virtual void downloadOutputPart(int type, int part, std::vector<uint32_t> &words) = 0;
+    virtual void uploadOutputPart(int type, int part, const std::vector<uint32_t> &words) = 0;
+    // OutputBuffer::operator[] for every pixel (OutputBuffer.hpp:134-144): the mean, of both half buffers where there are two
+    void outputBufferMean(int type, std::vector<float> &values);
+    // Camera::saveOutputBuffers -> OutputBuffer::save (Camera.cpp:213-220, OutputBuffer.hpp:146-189)
+    void saveOutputBuffers();
 
 protected:
     virtual void saveState(std::ostream &out) = 0;  // Integrator.hpp:33-34
@@ -76,6 +85,8 @@ public:
     void frameBuffer(std::vector<float> &rgb) override;
     void downloadOutputBuffer(std::vector<float> &rgb, std::vector<uint32_t> &counts) override;
     void uploadOutputBuffer(const std::vector<float> &rgb, const std::vector<uint32_t> &counts) override;
+    void downloadOutputPart(int type, int part, std::vector<uint32_t> &words) override;
+    void uploadOutputPart(int type, int part, const std::vector<uint32_t> &words) override;
     bool supportsResumeRender() const override { return true; }
 
     // SampleRecords (adaptive.hpp), one per 4x4 variance tile of the whole image

@@ -277,12 +277,13 @@ bool loadRadianceHdr(const std::string &path, int &w, int &h, std::vector<float>
     return true;
 }
 
-bool savePfm(const std::string &path, const float *rgb, int w, int h) // ImageIO.cpp:528-545
+bool savePfm(const std::string &path, const float *img, int w, int h, int channels) // ImageIO.cpp:528-545
 {
+    if (channels != 1 && channels != 3) return false;
     FILE *f = std::fopen(path.c_str(), "wb");
     if (!f) return false;
-    std::fprintf(f, "PF\n%d %d\n-1\n", w, h);
-    for (int y = h - 1; y >= 0; --y) std::fwrite(rgb + size_t(y)*w*3, sizeof(float), size_t(w)*3, f);
+    std::fprintf(f, "%s\n%d %d\n-1\n", channels == 1 ? "Pf" : "PF", w, h);
+    for (int y = h - 1; y >= 0; --y) std::fwrite(img + size_t(y)*w*channels, sizeof(float), size_t(w)*channels, f);
     std::fclose(f);
     return true;
 }
@@ -494,6 +495,8 @@ int Scene::parseBsdf(const Json &v)
     if (v["bump"]) throw std::runtime_error("bump maps are outside the hot-path scope");
     b.roughness_tex = -1;
     b.substrate = -1;
+    b.aux_bsdf = -1;
+    b.aux_tex = -1;
     if (type == "lambert") {
         b.type = TGPU_BSDF_LAMBERT;
     } else if (type == "null") {
@@ -551,6 +554,83 @@ int Scene::parseBsdf(const Json &v)
             if (at.type != TGPU_TEX_CONSTANT) throw std::runtime_error("rough_plastic with a textured albedo is outside the hot-path scope");
             float sum = at.value[0]; sum += at.value[1]; sum += at.value[2]; // ConstantTexture::average() = _value, Vec::avg()
             b.substrate_weight = sum*(1.0f/3.0f);
+        }
+    } else if (type == "oren_nayar") { // OrenNayarBsdf.cpp:14-31 (roughness default 1)
+        b.type = TGPU_BSDF_OREN_NAYAR;
+        if (v["roughness"])
+            b.roughness_tex = fetchTexture(v["roughness"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 1.0;
+            b.roughness_tex = fetchTexture(r, true);
+        }
+    } else if (type == "phong") { // PhongBsdf.cpp:16-30
+        b.type = TGPU_BSDF_PHONG;
+        b.exponent = 64.0f;
+        b.diffuse_ratio = 0.2f;
+        v.getField("exponent", b.exponent);
+        v.getField("diffuse_ratio", b.diffuse_ratio);
+    } else if (type == "mixed") { // MixedBsdf.cpp:47-58
+        b.type = TGPU_BSDF_MIXED;
+        if (!v["bsdf0"] || !v["bsdf1"]) throw JsonLoadException("mixed: bsdf0 and bsdf1 are required");
+        b.substrate = fetchBsdf(v["bsdf0"]);
+        b.aux_bsdf = fetchBsdf(v["bsdf1"]);
+        if (v["ratio"])
+            b.aux_tex = fetchTexture(v["ratio"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 0.5;
+            b.aux_tex = fetchTexture(r, true);
+        }
+    } else if (type == "rough_coat") { // RoughCoatBsdf.cpp:14-33,300-305
+        b.type = TGPU_BSDF_ROUGH_COAT;
+        b.ior = 1.3f;
+        b.thickness = 1.0f;
+        b.sigma_a[0] = b.sigma_a[1] = b.sigma_a[2] = 0.0f;
+        v.getField("ior", b.ior);
+        v.getField("thickness", b.thickness);
+        v.getVec("sigma_a", b.sigma_a, 3);
+        std::string dist = "ggx";
+        v.getField("distribution", dist);
+        if (dist == "beckmann") b.distribution = TGPU_DIST_BECKMANN;
+        else if (dist == "phong") b.distribution = TGPU_DIST_PHONG;
+        else if (dist == "ggx") b.distribution = TGPU_DIST_GGX;
+        else throw JsonLoadException("Unknown microfacet distribution '" + dist + "'");
+        if (v["roughness"])
+            b.roughness_tex = fetchTexture(v["roughness"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 0.02;
+            b.roughness_tex = fetchTexture(r, true);
+        }
+        if (!v["substrate"]) throw std::runtime_error("rough_coat without substrate (the default rough_conductor) is outside the hot-path scope");
+        b.substrate = fetchBsdf(v["substrate"]);
+        for (int i = 0; i < 3; ++i) b.scaled_sigma_a[i] = b.thickness*b.sigma_a[i];
+        {
+            float sum = b.scaled_sigma_a[0]; sum += b.scaled_sigma_a[1]; sum += b.scaled_sigma_a[2];
+            b.avg_transmittance = std::exp(-2.0f*(sum*(1.0f/3.0f)));
+        }
+    } else if (type == "transparency") { // TransparencyBsdf.cpp:12-32
+        b.type = TGPU_BSDF_TRANSPARENCY;
+        if (!v["base"]) throw std::runtime_error("transparency without base is outside the hot-path scope");
+        b.substrate = fetchBsdf(v["base"]);
+        if (v["alpha"])
+            b.aux_tex = fetchTexture(v["alpha"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 1.0;
+            b.aux_tex = fetchTexture(r, true);
+        }
+    } else if (type == "thinsheet") { // ThinSheetBsdf.cpp:16-38
+        b.type = TGPU_BSDF_THINSHEET;
+        b.ior = 1.5f;
+        b.sigma_a[0] = b.sigma_a[1] = b.sigma_a[2] = 0.0f;
+        v.getField("ior", b.ior);
+        v.getVec("sigma_a", b.sigma_a, 3);
+        bool interference = false;
+        v.getField("enable_interference", interference);
+        if (interference) throw std::runtime_error("thinsheet with enable_interference is outside the hot-path scope");
+        if (v["thickness"])
+            b.aux_tex = fetchTexture(v["thickness"], true);
+        else {
+            Json r; r.type = Json::Number; r.num = 0.5;
+            b.aux_tex = fetchTexture(r, true);
         }
     } else if (type == "mirror") {
         b.type = TGPU_BSDF_MIRROR;
@@ -1011,6 +1091,24 @@ Scene Scene::load(const std::string &jsonPath, const std::string &inputDirectory
         if (r.getField("spp_step", v)) s.renderer.sppStep = uint32_t(v);
         if (r["checkpoint_interval"].isString()) s.renderer.checkpointInterval = r["checkpoint_interval"].asString();
         if (r["timeout"].isString()) s.renderer.timeout = r["timeout"].asString();
+        if (const Json &outputs = r["output_buffers"]) { // RendererSettings.hpp:69-74, OutputBufferSettings.cpp:8-32
+            for (size_t i = 0; i < outputs.size(); ++i) {
+                const Json &o = outputs[i];
+                OutputBufferSettings b;
+                std::string type;
+                if (!o.getField("type", type)) throw std::runtime_error("output_buffers: entry without \"type\"");
+                static const char *names[TGPU_OUTPUT_COUNT] = {"color", "depth", "normal", "albedo", "visibility"};
+                b.type = -1;
+                for (int t = 0; t < TGPU_OUTPUT_COUNT; ++t)
+                    if (type == names[t]) b.type = t;
+                if (b.type < 0) throw std::runtime_error("Invalid output buffer type: '" + type + "'");
+                o.getField("ldr_output_file", b.ldrOutputFile);
+                o.getField("hdr_output_file", b.hdrOutputFile);
+                o.getField("two_buffer_variance", b.twoBufferVariance);
+                o.getField("sample_variance", b.sampleVariance);
+                s.renderer.outputs.push_back(b);
+            }
+        }
     }
     return s;
 }
@@ -1174,6 +1272,10 @@ void Scene::flatten()
     _desc.settings = settings;
     _desc.settings.use_sobol = renderer.useSobol ? 1 : 0;
     _desc.settings.adaptive_sampling = renderer.useAdaptiveSampling ? 1 : 0;
+    for (tgpu_output_buffer &b : _desc.output_buffers) b = tgpu_output_buffer{0, 0, 0};
+    _desc.output_buffers[TGPU_OUTPUT_COLOR].enabled = 1;
+    for (const OutputBufferSettings &b : renderer.outputs) // Camera::requestOutputBuffers (Camera.cpp:148-161): a later entry of a type replaces an earlier one
+        _desc.output_buffers[b.type] = tgpu_output_buffer{1, b.twoBufferVariance ? 1 : 0, b.sampleVariance ? 1 : 0};
 
     // ---- meshes: world-space bake (TriangleMesh.cpp:524-552) ----
     _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear(); _triMedia.clear();

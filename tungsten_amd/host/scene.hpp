@@ -15,6 +15,13 @@
 namespace tungsten_amd {
 
 // RendererSettings (src/core/renderer/RendererSettings.hpp:34-76)
+// cameras/OutputBufferSettings.hpp:13-50: one entry of renderer "output_buffers"
+struct OutputBufferSettings {
+    int type = TGPU_OUTPUT_COLOR; // "color" | "depth" | "normal" | "albedo" | "visibility"
+    std::string ldrOutputFile, hdrOutputFile;
+    bool twoBufferVariance = false, sampleVariance = false;
+};
+
 struct RendererSettings {
     std::string outputFile = "TungstenRender.png";
     std::string hdrOutputFile;
@@ -28,6 +35,7 @@ struct RendererSettings {
     uint32_t sppStep = 16;
     std::string checkpointInterval = "0";
     std::string timeout = "0";
+    std::vector<OutputBufferSettings> outputs; // "output_buffers" (RendererSettings.hpp:69-74)
 };
 
 struct MeshData {
@@ -174,7 +182,7 @@ struct Pcg32 {
 // Image / mesh I/O used by the host (formats: SURVEY.md Appendix B)
 bool loadWo3(const std::string &path, std::vector<float> &verts, std::vector<uint32_t> &tris);
 bool loadRadianceHdr(const std::string &path, int &w, int &h, std::vector<float> &rgb);
-bool savePfm(const std::string &path, const float *rgb, int w, int h);
+bool savePfm(const std::string &path, const float *img, int w, int h, int channels = 3);
 bool loadPfm(const std::string &path, int &w, int &h, std::vector<float> &rgb);
 bool savePng(const std::string &path, const uint8_t *rgb, int w, int h);
 // Camera::tonemap + LDR quantisation (Tonemap.hpp:25-48, Integrator.cpp:56-80)

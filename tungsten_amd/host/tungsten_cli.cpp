@@ -81,6 +81,10 @@ int main(int argc, char **argv)
                 if (!scene.renderer.outputFile.empty()) scene.renderer.outputFile = outDir + "/" + scene.renderer.outputFile;
                 if (!scene.renderer.hdrOutputFile.empty()) scene.renderer.hdrOutputFile = outDir + "/" + scene.renderer.hdrOutputFile;
                 if (!scene.renderer.resumeRenderFile.empty()) scene.renderer.resumeRenderFile = outDir + "/" + scene.renderer.resumeRenderFile;
+                for (OutputBufferSettings &b : scene.renderer.outputs) { // OutputBufferSettings::setOutputDirectory (RendererSettings.hpp:119-120)
+                    if (!b.ldrOutputFile.empty()) b.ldrOutputFile = outDir + "/" + b.ldrOutputFile;
+                    if (!b.hdrOutputFile.empty()) b.hdrOutputFile = outDir + "/" + b.hdrOutputFile;
+                }
             }
             scene.flatten();
             std::vector<int> contexts; // one entry per pool: GPU g appears `pools` times

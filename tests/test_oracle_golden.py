@@ -142,7 +142,7 @@ def test_golden_fixtures_match_their_manifest():
     on_disk = set()
     for root, _, files in os.walk(GOLDEN):
         for f in files:
-            if f.endswith((".pfm", ".dat")) or f in ("ref_kat.json", "ref_kat2.json"):
+            if f.endswith((".pfm", ".dat")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json"):
                 on_disk.add(os.path.relpath(os.path.join(root, f), GOLDEN))
     assert on_disk == set(manifest), f"fixtures without manifest entry or vice versa: {sorted(on_disk ^ set(manifest))}"
     for name, digest in manifest.items():

@@ -255,12 +255,14 @@ TG_DEV void aovVisibility(const DState &st, uint32_t slot, bool clear, bool walk
     aovVisibilityCall(st.results, st.aov1, st.sampleRef[slot], clear, walked, walked ? shadow.avg() : 0.0f);
 }
 
+// AOV = false: the lean shade kernels, which never run with auxiliary output buffers (the launcher picks the general ones then)
+template <bool AOV = true>
 TG_DEV V3 resolveNeeTerms(const DState &st, uint32_t slot, V3 em)
 {
     // (plain loads: the non-temporal form of this triple trips an 'even aligned vector registers' backend error in the general shade kernels)
     const float4 c = st.shC[slot], d = st.shD[slot], e = st.shE[slot];
     const uint32_t vis = __float_as_uint(d.w);
-    if (st.aov0) aovVisibility(st, slot, (vis & 1u) != 0, false, V3(0.0f));
+    if (AOV && st.aov0) aovVisibility(st, slot, (vis & 1u) != 0, false, V3(0.0f));
     // an occluded term enters as +0: x + 0 == x bit for bit, so this is ((0 + L*vis_L) + B*vis_B) without branches
     const V3 lTerm = (vis & 1u) ? xyz(c) : V3(0.0f), bTerm = (vis & 2u) ? xyz(d) : V3(0.0f);
     V3 result = (V3(0.0f) + lTerm) + bTerm;
@@ -2383,7 +2385,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
     bool wasSpecular = flagsSpecular(flags);
     int end = END_ALIVE;
     if (stateNee(st.state[path])) // NEE terms of the previous vertex (k_shadow_q left the visibility bits)
-        em = MEDIA ? resolveNeeTermsCall(st, path, em) : resolveNeeTerms(st, path, em);
+        em = MEDIA ? resolveNeeTermsCall(st, path, em) : resolveNeeTerms<false>(st, path, em);
 
     // afterMedium: volumePath ran the check before the distance sampling and scaled tp by the medium weight since
     if (!afterMedium && bounce > 0 && isnanf_(tp.sum() + em.sum())) {
@@ -2435,8 +2437,10 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
         // zero for every other BSDF in scope
         // zero for a BSDF without that lobe; 1 - alpha for a TransparencyBsdf; the film's transmittance for a ThinSheetBsdf
         // auxiliary output buffers: is this sample still waiting for its first non-specular vertex (PathTracer.cpp:78)?
-        const uint32_t aovRef = st.aov0 ? st.sampleRef[path] : 0u;
-        const bool aovOpen = st.aov0 && !(__float_as_uint(st.results[aovRef].w) & AOV_RECORDED);
+        // (general instantiation only: requesting auxiliary buffers selects it at upload, the lean kernels carry none of this)
+        const bool aovTrack = MEDIA && st.aov0 != nullptr;
+        const uint32_t aovRef = aovTrack ? st.sampleRef[path] : 0u;
+        const bool aovOpen = aovTrack && !(__float_as_uint(st.results[aovRef].w) & AOV_RECORDED);
         bool visDefined = false; // the light sample reached its shadow test: `transmittance` of handleSurface is set (TraceBase.cpp:167-169)
         float visClear = 0.0f;   // ... to this value if the shadow ray turns out clear (scenes without forward-scattering surfaces)
         V3 transparency(0.0f);

@@ -615,6 +615,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         if (t == TGPU_BSDF_FORWARD || t == TGPU_BSDF_TRANSPARENCY || t == TGPU_BSDF_THINSHEET) sc.hasForward = 1;
     }
     if (sc.hasForward) ctx->generalShading = true; // the shadow walk needs the NEE factors the general shade kernels store
+    for (int t = TGPU_OUTPUT_DEPTH; t < TGPU_OUTPUT_COUNT; ++t) // only the general shade kernels record the auxiliary output values
+        if (s->output_buffers[t].enabled) ctx->generalShading = true;
     ctx->hasNested = false; // mixtures, coats, cut-outs, thin sheets: shaded by the wavefront kernels only (device.h, TG_NO_NESTED_BSDFS)
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type >= TGPU_BSDF_MIXED) ctx->hasNested = true;
     sc.textures = dTex;

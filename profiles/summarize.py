@@ -3,8 +3,10 @@
    profiles/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc.json and profiles/pmc_extend.json
    (per-launch HBM-side traffic of k_extend, read by bench.py's roofline.traffic).
    Counter handling follows MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB and come from the L2's
-   fabric-side request counters; on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of wide (16 B/lane) loads,
-   which is what every load in these kernels is -> the read side is doubled."""
+   fabric-side request counters; on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of wide (16 B/lane) loads.
+   The other access widths of these kernels were calibrated on known byte counts (profiles/micro/fetch_calib.hip ->
+   profiles/r02_fetch_calib.txt): every L2 miss is one fabric request = one 128-byte line fill, tallied at 64 B, whatever
+   the width of the access that caused it -> the read side is doubled for every kernel."""
 import csv, glob, json, os, shutil, sys, collections
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -30,6 +32,10 @@ for k, t in tot.items():
     out[k] = {"launches": calls[k], "fetch_bytes_per_launch": fetch/n, "write_bytes_per_launch": write/n,
               "hbm_bytes_per_launch": (fetch + write)/n, "l2_hit_rate": hit/max(1.0, hit + miss)}
 json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+# what bench.py's roofline.traffic reads (per kernel, per launch); `_source` is quoted next to the number
+latest = dict(out)
+latest["_source"] = f"profiles/{tag}_pmc.json"
+json.dump(latest, open(os.path.join(here, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
 ext = next((v for k, v in out.items() if k.startswith("k_extend_q<false")), None)
 if ext:
     json.dump({"kernel": "k_extend_q<false, 4>", "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",

@@ -117,6 +117,7 @@ struct DState {
     float4 *aov0, *aov1;
     DOutBuf out[TGPU_OUTPUT_COUNT]; // the output buffers themselves (k_accumulate*); out[0].a / .count alias fbMean / fbCount
     uint32_t *lists[2][TG_LISTS];
+    uint8_t *endFlag[2]; // per set: the end state (END_*) the shade / volume step left for every entry of the concatenated lists
     uint32_t *freeQ;     // idle slots that were dropped from the lists (no sample admitted / end of render)
     RecU1 state;         // per slot: bit 0 = NEE terms of the slot's last vertex still have to be folded into its radiance (shC..shF valid),
                          // bits [7:4] = a copy of the end state of tp.w.  (A compact 4-byte array instead was slower: a random access costs a
@@ -224,6 +225,13 @@ TG_DEV bool listFetch(const DState &st, const ListCounts &lc, int set, int first
         idx -= n;
     }
     return false;
+}
+// position of list `l`'s first entry in the concatenation of the set's lists
+TG_DEV uint32_t listBase(const DState &st, int set, int l)
+{
+    uint32_t n = 0;
+    for (int j = 0; j < l; ++j) n += st.counters[CNT(CNT_LIST0 + set*TG_LISTS + j)];
+    return n;
 }
 TG_DEV uint32_t listTotal(const ListCounts &lc, int first)
 {
@@ -379,8 +387,8 @@ TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
 TG_DEV int missPathEx(const DScene &sc, const DState &st, uint32_t path, V3 &emOut, float &tpSumOut);
 TG_DEV void aovFinish(const DScene &sc, const DState &st, uint32_t path, uint32_t ref, bool epilogue);
 
-// Per shaded slot this kernel reads the 4-byte state word (compact array); only ended paths cost record sectors (radiance, pending
-// NEE terms, sample reference), escaped ones the whole path record (environment lookup).
+// Per shaded entry this kernel reads one byte of the end-state array the shade / volume step wrote next to the lists (coalesced); only
+// ended paths cost record lines (radiance, pending NEE terms, sample reference), escaped ones the whole path record (environment lookup).
 #ifdef TG_TU_MAIN
 #ifndef TG_RETIRE_K
 #define TG_RETIRE_K 1 /* list entries per thread and block round (1 / 2 / 4 with 1024 / 512 / 256-thread blocks measured the same within noise) */
@@ -414,7 +422,7 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK) k_retire_regenerate(DS
 #pragma unroll
         for (int k = 0; k < TG_RETIRE_K; ++k) {
             const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
-            stw[k] = (have[k] && q >= lc.n[0]) ? st.state[slot[k]] : 0u;
+            stw[k] = (have[k] && q >= lc.n[0]) ? uint32_t(st.endFlag[set][q]) : 0u; // END_* of the entry, written by its shade / volume step
         }
         uint32_t mine = 0; // entries of this thread that ask for a sample, over all k
 #pragma unroll
@@ -431,10 +439,10 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK) k_retire_regenerate(DS
                     // that their record is read and written once, not by a miss kernel first and by this one again
                     end = missPathEx(sc, st, slot[k], c, tpSum);
                 } else {
-                    end = stateEnd(stw[k]);
+                    end = int(stw[k]);
                     if (end != END_ALIVE && end != END_DEAD) { // a path that goes on is left alone: its NEE terms ride with its next vertex
                         c = xyz(st.em[slot[k]]);
-                        if (stateNee(stw[k])) c = resolveNeeTerms(st, slot[k], c);
+                        if (stateNee(st.state[slot[k]])) c = resolveNeeTerms(st, slot[k], c);
                         if (end == END_CHECKED) tpSum = st.tpSum[slot[k]];
                     }
                 }
@@ -2096,7 +2104,7 @@ TG_DEV V3 neeTransmittance(const DScene &sc, int medium, float farT, bool startO
 }
 
 template <int CLASS, bool MEDIA>
-TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium = false);
+TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium = false); // returns the path's end state
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
 
 // phase functions: IsotropicPhaseFunction.cpp:24-44, HenyeyGreensteinPhaseFunction.cpp:19-23,40-66 (eval == pdf, weight 1)
@@ -2149,12 +2157,12 @@ TG_DEV void closeVertex(const DState &st, uint32_t path, bool nee, int end, floa
 // TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect (:323-381, :402-414, :470-481) and the loop
 // tail of traceSample (PathTracer.cpp:108-126).  The NEE rays go through the ordinary shadow kernel: their
 // transmittance is known here (the segment length is the light's distance) and folded into the contributions.
-TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
+TG_DEV int volumePath(const DScene &sc, const DState &st, uint32_t path) // returns the path's end state
 {
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
     float4 tpw = st.tp[path];
     uint32_t flags = __float_as_uint(tpw.w);
-    if (flagsEnd(flags) != END_ALIVE) { closeVertex(st, path, false, flagsEnd(flags), xyz(tpw).sum()); return; }
+    if (flagsEnd(flags) != END_ALIVE) { closeVertex(st, path, false, flagsEnd(flags), xyz(tpw).sum()); return flagsEnd(flags); }
     float4 ro = st.rayO[path], rd = st.rayD[path], hw = st.hit[path], emw = st.em[path];
     uint4 sw = st.samp[path];
     V3 O = xyz(ro), D = xyz(rd), tp = xyz(tpw), em = xyz(emw);
@@ -2168,7 +2176,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     if (bounce > 0 && isnanf_(tp.sum() + em.sum())) { // PathTracer.cpp:121-122 for the previous vertex
         st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, END_ZERO));
         closeVertex(st, path, false, END_ZERO, tp.sum());
-        return;
+        return END_ZERO;
     }
     Sampler smp;
     smp.matrices = sc.sobol;
@@ -2218,7 +2226,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     if (!ok) { // `return emission`
         st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, END_RAW));
         closeVertex(st, path, false, END_RAW, tp.sum());
-        return;
+        return END_RAW;
     }
     tp *= weight;
     if (exited) {
@@ -2227,11 +2235,11 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
         st.med[path] = uint32_t(medium + 1) | (firstScatter ? 1u << 8 : 0u) | (stateBounce << 9);
         if (!didHit) { // `break`: handleInfiniteLights and the final NaN check
             closeVertex(st, path, false, END_ALIVE, tp.sum());
-            missPath(sc, st, path);
-        } else {
-            shadePath<-1, true>(sc, st, path, true);
+            V3 emUnused;
+            float tpSumUnused;
+            return missPathEx(sc, st, path, emUnused, tpSumUnused);
         }
-        return;
+        return shadePath<-1, true>(sc, st, path, true);
     }
 
     // ---- handleVolume ----
@@ -2364,6 +2372,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
     st.em[path] = mk4u(em, smp.scramble);
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
     closeVertex(st, path, pushShadow, end, tp.sum());
+    return end;
 }
 
 // One surface vertex of one path (the body of the shade kernels; the tail kernel calls it too):
@@ -2372,7 +2381,7 @@ TG_DEV void volumePath(const DScene &sc, const DState &st, uint32_t path)
 // code of the other BSDFs; MEDIA = false is the lean instantiation: no medium bookkeeping, only environment and quad
 // lights (the launcher picks the general one for scenes with media or sphere / disk lights).
 template <int CLASS, bool MEDIA>
-TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium)
+TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium)
 {
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
     const bool neeEnabled = sc.settings.enable_light_sampling != 0;
@@ -2683,6 +2692,7 @@ TG_DEV void shadePath(const DScene &sc, const DState &st, uint32_t path, bool af
     }
     st.tp[path] = mk4u(tp, packFlags(bounce, wasSpecular, end));
     closeVertex(st, path, pushShadow, end, tp.sum());
+    return end;
 }
 
 template <int CLASS, bool MEDIA>
@@ -2692,7 +2702,10 @@ __global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
     const uint32_t *list = st.lists[set][1 + CLASS];
     const uint32_t stride = gridDim.x*blockDim.x;
     constexpr int KNOWN = CLASS < TG_CLASS_OTHER ? CLASS : -1; // the shared list holds several BSDF types
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) shadePath<KNOWN, MEDIA>(sc, st, list[q]);
+    // the end state of every entry also goes to a byte array parallel to the concatenated lists: the retire step reads it coalesced and
+    // only touches the records of paths that ended (a 4-byte state word per slot cost it a 128-byte line fill each, profiles/r02_ab_notes.txt)
+    uint8_t *endFlag = st.endFlag[set] + listBase(st, set, 1 + CLASS);
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += stride) endFlag[q] = uint8_t(shadePath<KNOWN, MEDIA>(sc, st, list[q]));
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&st.stats[5], (unsigned long long)count);
 }
 
@@ -2702,7 +2715,8 @@ static __global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, 
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + TG_CLASS_VOLUME)];
     const uint32_t *list = st.lists[set][1 + TG_CLASS_VOLUME];
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) volumePath(sc, st, list[q]);
+    uint8_t *endFlag = st.endFlag[set] + listBase(st, set, 1 + TG_CLASS_VOLUME);
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) endFlag[q] = uint8_t(volumePath(sc, st, list[q]));
 }
 #endif
 

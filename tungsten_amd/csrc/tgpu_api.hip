@@ -839,6 +839,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (int set = 0; set < 2; ++set)
         for (int l = 0; l < TG_LISTS; ++l)
             if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, cap, &st.lists[set][l]))) return rc;
+    for (int set = 0; set < 2; ++set) // one byte per entry of the set's concatenated lists (their lengths add up to <= cap)
+        if ((rc = upload<uint8_t>(ctx, ctx->stateAllocs, nullptr, cap + 256, &st.endFlag[set]))) return rc;
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL*TG_CNT_STRIDE, &st.counters))) return rc;
     if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8, &st.stats))) return rc;
     {

@@ -147,3 +147,68 @@ def test_golden_fixtures_match_their_manifest():
     assert on_disk == set(manifest), f"fixtures without manifest entry or vice versa: {sorted(on_disk ^ set(manifest))}"
     for name, digest in manifest.items():
         assert hashlib.sha256(open(os.path.join(GOLDEN, name), "rb").read()).hexdigest() == digest, name
+
+
+def _load_pfm_any(path):
+    """PF (3 channels) or Pf (1 channel) -> (h, w, channels) float32, top row first."""
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        w, h = map(int, f.readline().split())
+        f.readline()
+        ch = 1 if magic == b"Pf" else 3
+        return np.frombuffer(f.read(), np.float32).reshape(h, w, ch)[::-1]
+
+
+@pytest.mark.parametrize("name,scene,res,spp", [
+    ("aov", "next/aov.json", (128, 72), 4),                       # late records behind glass, escaping primary rays, environment albedo
+    ("cornell", "cornell-box/scene_sobol.json", (96, 54), 5),     # quad light: emissive albedo, finite-light visibility, odd sample count
+])
+def test_oracle_output_buffers_match_reference(ta, oracle_py, name, scene, res, spp):
+    """renderer "output_buffers" as the compiled reference wrote them (tests/golden/aov/, make_aov_golden.py): depth with
+    sample_variance, normal with two_buffer_variance, albedo, visibility with both -- the values of PathTracer.cpp:78-96,133-140
+    accumulated by cameras/OutputBuffer.hpp and saved by OutputBuffer::save (mean, A / B halves, scaled variance)."""
+    outputs = [("depth", False, True), ("normal", True, False), ("albedo", False, False), ("visibility", True, True)]
+    hs = ta.HostScene(scene_path(scene), resolution=res, output_buffers=outputs)
+    o = oracle_py.Oracle(hs, **oracle_py.REF_RCP)
+    bufs = o.bind_output_buffers(hs.res_x*hs.res_y)
+    img, cnt = o.render_image(spp, spp_step=spp)
+    exact_host = intel_rcp(oracle_py)
+    checked = 0
+
+    def compare(file, values, channels):
+        nonlocal checked
+        ref = _load_pfm_any(os.path.join(GOLDEN, "aov", file))
+        got = np.asarray(values, np.float32).reshape(hs.res_y, hs.res_x, channels)
+        assert ref.shape == got.shape, file
+        both_nan = np.isnan(ref) & np.isnan(got)
+        same = (ref == got) | both_nan
+        finite = np.isfinite(ref) & np.isfinite(got)
+        assert (np.isfinite(ref) == np.isfinite(got)).mean() > 0.999, file
+        assert float(np.sqrt(((ref - got)[finite]**2).mean())) < 1e-3*max(1.0, float(np.abs(ref[finite]).max())), file
+        if exact_host:
+            assert same.all(axis=2).mean() > 0.999, f"{file}: only {same.all(axis=2).mean():.5f} of the pixels are bit-identical"
+        checked += 1
+
+    def mean_of(b, channels):
+        if "b" not in b:
+            return b["a"]
+        n = b["count"].astype(np.float32)[:, None]
+        return (b["a"]*((b["count"] + 1)//2).astype(np.float32)[:, None] + b["b"]*(b["count"]//2).astype(np.float32)[:, None])/np.maximum(n, np.float32(1))
+
+    def scaled_variance(b):
+        n = b["count"]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return b["variance"]/(n*np.maximum(1, n.astype(np.int64) - 1)).astype(np.float32)[:, None]
+
+    compare(f"{name}_color.pfm", img, 3)
+    compare(f"{name}_depth.pfm", bufs["depth"]["a"], 1)
+    compare(f"{name}_depthVariance.pfm", scaled_variance(bufs["depth"]), 1)
+    compare(f"{name}_normal.pfm", mean_of(bufs["normal"], 3), 3)
+    compare(f"{name}_normalA.pfm", bufs["normal"]["a"], 3)
+    compare(f"{name}_normalB.pfm", bufs["normal"]["b"], 3)
+    compare(f"{name}_albedo.pfm", bufs["albedo"]["a"], 3)
+    compare(f"{name}_visibility.pfm", mean_of(bufs["visibility"], 1), 1)
+    compare(f"{name}_visibilityA.pfm", bufs["visibility"]["a"], 1)
+    compare(f"{name}_visibilityB.pfm", bufs["visibility"]["b"], 1)
+    compare(f"{name}_visibilityVariance.pfm", scaled_variance(bufs["visibility"]), 1)
+    assert checked == 11

@@ -378,11 +378,11 @@ TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs,
 //  - alive paths are left alone;
 //  - an ended path is retired: its radiance, with traceSample's exit rules applied (PathTracer.cpp:119-131),
 //    goes to the result ring and the job's completion counter is bumped;
-//  - ended and idle slots then claim the next sample in global order; when one is admitted (< limit) the
+//  - ended and idle slots then claim the next samples; when one is admitted (< limit) the
 //    slot starts it and simply stays in its list (the next extend traces its camera ray), otherwise the
 //    slot is marked idle and the next extend drops it onto the free list.
-// Claims are aggregated per block round (256 threads x TG_RETIRE_K entries: one global atomic per 1024 entries), job counters per block
-// in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
+// Claims: ONE global atomic per block for everything it will ask for (counted first from the list lengths and the end-state bytes), job
+// counters per block in LDS (flushed once at the end): a single hot counter word only sustains ~88 atomics/us on this chip.
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
 TG_DEV int missPathEx(const DScene &sc, const DState &st, uint32_t path, V3 &emOut, float &tpSumOut);
 TG_DEV void aovFinish(const DScene &sc, const DState &st, uint32_t path, uint32_t ref, bool epilogue);
@@ -390,9 +390,7 @@ TG_DEV void aovFinish(const DScene &sc, const DState &st, uint32_t path, uint32_
 // Per shaded entry this kernel reads one byte of the end-state array the shade / volume step wrote next to the lists (coalesced); only
 // ended paths cost record lines (radiance, pending NEE terms, sample reference), escaped ones the whole path record (environment lookup).
 #ifdef TG_TU_MAIN
-#ifndef TG_RETIRE_K
-#define TG_RETIRE_K 1 /* list entries per thread and block round (1 / 2 / 4 with 1024 / 512 / 256-thread blocks measured the same within noise) */
-#endif
+#define TG_RETIRE_K 1
 #ifndef TG_RETIRE_BLOCK
 #define TG_RETIRE_BLOCK 256
 #endif
@@ -404,99 +402,84 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK) k_retire_regenerate(DS
     __shared__ uint32_t sBase;
     const ListCounts lc = loadListCounts(st, set);
     const uint32_t total = listTotal(lc, 0);
-    const uint32_t span = blockDim.x*TG_RETIRE_K;
-    const uint32_t rounded = (total + span - 1u)/span*span;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
+    const uint8_t *endFlag = st.endFlag[set];
+    // a wave owns every (waves in the grid)-th group of 64 entries: escaped paths (list 0, the expensive entries) spread over all waves
+    const uint32_t first = (blockIdx.x*(blockDim.x >> 6) + uint32_t(wave))*64u, stride = gridDim.x*blockDim.x;
     if (threadIdx.x < TG_RING) sHist[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t q0 = blockIdx.x*span; q0 < rounded; q0 += gridDim.x*span) {
-        uint32_t slot[TG_RETIRE_K], stw[TG_RETIRE_K];
-        bool have[TG_RETIRE_K], needs[TG_RETIRE_K];
-#pragma unroll
-        for (int k = 0; k < TG_RETIRE_K; ++k) {
-            const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
-            slot[k] = 0;
-            have[k] = q < total && listFetch(st, lc, set, 0, q, slot[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < TG_RETIRE_K; ++k) {
-            const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
-            stw[k] = (have[k] && q >= lc.n[0]) ? uint32_t(st.endFlag[set][q]) : 0u; // END_* of the entry, written by its shade / volume step
-        }
-        uint32_t mine = 0; // entries of this thread that ask for a sample, over all k
-#pragma unroll
-        for (int k = 0; k < TG_RETIRE_K; ++k) {
-            const uint32_t q = q0 + uint32_t(k)*blockDim.x + threadIdx.x;
-            uint32_t ring = 0xFFFFFFFFu;
-            needs[k] = false;
-            if (have[k]) {
-                int end;
-                V3 c(0.0f);
-                float tpSum = 0.0f;
-                if (q < lc.n[0]) {
-                    // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so
-                    // that their record is read and written once, not by a miss kernel first and by this one again
-                    end = missPathEx(sc, st, slot[k], c, tpSum);
-                } else {
-                    end = int(stw[k]);
-                    if (end != END_ALIVE && end != END_DEAD) { // a path that goes on is left alone: its NEE terms ride with its next vertex
-                        c = xyz(st.em[slot[k]]);
-                        if (stateNee(st.state[slot[k]])) c = resolveNeeTerms(st, slot[k], c);
-                        if (end == END_CHECKED) tpSum = st.tpSum[slot[k]];
-                    }
-                }
-                if (end != END_ALIVE) {
-                    needs[k] = true;
-                    if (end != END_DEAD) {
-                        const bool nanEnd = end == END_CHECKED && isnanf_(tpSum + c.sum()); // PathTracer.cpp:130-131
-                        if (end == END_ZERO || nanEnd) c = V3(0.0f);
-                        uint32_t ref = st.sampleRef[slot[k]];
-                        if (st.aov0) aovFinish(sc, st, slot[k], ref, end == END_CHECKED && !nanEnd);
-                        st.results[ref] = mk4(c, 0.0f);
-                        ring = ref/st.resultSlice;
-                    }
-                }
-            }
-            unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
-            while (todo) { // one LDS atomic per distinct job present in the wave
-                int leader = __builtin_ctzll(todo);
-                uint32_t r = __shfl(ring, leader);
-                unsigned long long m = __ballot(ring == r);
-                if (lane == leader) atomicAdd(&sHist[r], uint32_t(__builtin_popcountll(m)));
-                todo &= ~m;
-            }
-            if (needs[k]) mine++;
-        }
-        // claims: one global atomic per block round; thread order inside the wave by prefix sum over the lanes
-        uint32_t incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) sWave[wave] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t sum = 0;
-            for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { uint32_t n = sWave[w]; sWave[w] = sum; sum += n; }
-            sBase = sum ? atomicAdd(&st.counters[CNT(CNT_REGEN)], sum) : 0u;
-        }
-        __syncthreads();
-        unsigned long long g = sampleBase + sBase + sWave[wave] + (incl - mine);
-#pragma unroll
-        for (int k = 0; k < TG_RETIRE_K; ++k) {
-            if (!needs[k]) continue;
-            if (g < limit) {
-                startSample(sc, st, jobs, g, slot[k]);
-            } else { // idle: the next extend drops the slot onto the free list (it reads tp.w)
-                reinterpret_cast<uint32_t *>(&st.tp[slot[k]])[3] = packFlags(0, false, END_DEAD);
-                st.state[slot[k]] = packState(false, END_DEAD);
-            }
-            ++g;
-        }
-        __syncthreads();
+    // pass 1: how many samples this block will ask for -- every entry of list 0 and every entry whose path ended -- from the list lengths
+    // and the end-state bytes alone; ONE global claim per block (a claim per block round cost a dependent atomic and two barriers each)
+    uint32_t mine = 0;
+    for (uint32_t q0 = first; q0 < total; q0 += stride) {
+        const uint32_t q = q0 + uint32_t(lane);
+        const bool need = q < total && (q < lc.n[0] || endFlag[q] != END_ALIVE);
+        mine += uint32_t(__builtin_popcountll(__ballot(need)));
     }
-    (void)below;
+    if (lane == 0) sWave[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { uint32_t n = sWave[w]; sWave[w] = sum; sum += n; }
+        sBase = sum ? atomicAdd(&st.counters[CNT(CNT_REGEN)], sum) : 0u;
+    }
+    __syncthreads();
+    unsigned long long next = sampleBase + sBase + sWave[wave]; // the wave's claims, in the order pass 2 meets them
+    // pass 2
+    for (uint32_t q0 = first; q0 < total; q0 += stride) {
+        const uint32_t q = q0 + uint32_t(lane);
+        uint32_t slot = 0, ring = 0xFFFFFFFFu;
+        const bool have = q < total && listFetch(st, lc, set, 0, q, slot);
+        bool needs = false;
+        if (have) {
+            int end;
+            V3 c(0.0f);
+            float tpSum = 0.0f;
+            if (q < lc.n[0]) {
+                // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so
+                // that their record is read and written once, not by a miss kernel first and by this one again
+                end = missPathEx(sc, st, slot, c, tpSum);
+            } else {
+                end = int(endFlag[q]); // END_* of the entry, written by its shade / volume step
+                if (end != END_ALIVE && end != END_DEAD) { // a path that goes on is left alone: its NEE terms ride with its next vertex
+                    c = xyz(st.em[slot]);
+                    if (stateNee(st.state[slot])) c = resolveNeeTerms(st, slot, c);
+                    if (end == END_CHECKED) tpSum = st.tpSum[slot];
+                }
+            }
+            if (end != END_ALIVE) {
+                needs = true;
+                if (end != END_DEAD) {
+                    const bool nanEnd = end == END_CHECKED && isnanf_(tpSum + c.sum()); // PathTracer.cpp:130-131
+                    if (end == END_ZERO || nanEnd) c = V3(0.0f);
+                    uint32_t ref = st.sampleRef[slot];
+                    if (st.aov0) aovFinish(sc, st, slot, ref, end == END_CHECKED && !nanEnd);
+                    st.results[ref] = mk4(c, 0.0f);
+                    ring = ref/st.resultSlice;
+                }
+            }
+        }
+        unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
+        while (todo) { // one LDS atomic per distinct job present in the wave
+            int leader = __builtin_ctzll(todo);
+            uint32_t r = __shfl(ring, leader);
+            unsigned long long m = __ballot(ring == r);
+            if (lane == leader) atomicAdd(&sHist[r], uint32_t(__builtin_popcountll(m)));
+            todo &= ~m;
+        }
+        const unsigned long long asking = __ballot(needs);
+        if (needs) {
+            const unsigned long long g = next + uint32_t(__builtin_popcountll(asking & below));
+            if (g < limit) {
+                startSample(sc, st, jobs, g, slot);
+            } else { // idle: the next extend drops the slot onto the free list (it reads tp.w)
+                reinterpret_cast<uint32_t *>(&st.tp[slot])[3] = packFlags(0, false, END_DEAD);
+                st.state[slot] = packState(false, END_DEAD);
+            }
+        }
+        next += uint32_t(__builtin_popcountll(asking));
+    }
+    __syncthreads();
     if (threadIdx.x < TG_RING && sHist[threadIdx.x]) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + threadIdx.x)], sHist[threadIdx.x]);
 }
 #endif
@@ -3410,7 +3393,13 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
         uint32_t slot = 0, ring = 0xFFFFFFFFu;
         const bool have = g % spread == 0 && q < total && listFetch(st, lc, set, 0, q, slot);
         if (have) {
+            uint32_t vertex = 0; // COUNT: when (10 ns ticks since this lane started) the slowest path reached its n-th vertex -> stats[8 + n]
+            const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
             while (flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE) {
+                if (COUNT) {
+                    atomicMax(&st.stats[8 + min(vertex, 127u)], wall_clock64() - t0);
+                    ++vertex;
+                }
                 float4 ro = st.rayO[slot], rd = st.rayD[slot];
                 float tfar = rd.w, u = 0.0f, v = 0.0f;
                 uint32_t inst;

@@ -842,7 +842,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     for (int set = 0; set < 2; ++set) // one byte per entry of the set's concatenated lists (their lengths add up to <= cap)
         if ((rc = upload<uint8_t>(ctx, ctx->stateAllocs, nullptr, cap + 256, &st.endFlag[set]))) return rc;
     if ((rc = upload<uint32_t>(ctx, ctx->stateAllocs, nullptr, CNT_TOTAL*TG_CNT_STRIDE, &st.counters))) return rc;
-    if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8, &st.stats))) return rc;
+    if ((rc = upload<unsigned long long>(ctx, ctx->stateAllocs, nullptr, 8 + 128, &st.stats))) return rc; // [8..135]: tail-kernel timeline (profiling build)
     {
         uint32_t freeInit = uint32_t(cap);
         HIP_TRY(ctx, hipMemcpy(st.counters + CNT(CNT_FREE), &freeInit, sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -984,6 +984,15 @@ static int driveIteration(tgpu_ctx *ctx)
         // every listed slot ends on the free list: both list sets are empty afterwards
         (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0), 0, 2*TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
         ctx->stats.tail_launches++;
+        if (count && getenv("TGPU_TAIL_TIMELINE")) { // per-vertex timeline of the tail kernel's slowest path (profiling build only)
+            unsigned long long tl[128];
+            if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(tl, st.stats + 8, sizeof(tl), hipMemcpyDeviceToHost) == hipSuccess) {
+                std::fprintf(stderr, "tail timeline (%u paths, spread %u), us at vertex n:", nCur, spread);
+                for (int i = 0; i < 128 && (i == 0 || tl[i]); ++i) std::fprintf(stderr, " %.1f", double(tl[i])*0.01);
+                std::fprintf(stderr, "\n");
+                (void)hipMemset(st.stats + 8, 0, sizeof(tl));
+            }
+        }
     } else if (nCur > 0) {
         int grid = gridFor(ctx, nCur);
         {

@@ -118,7 +118,11 @@ enum { TGPU_TRANS_EXPONENTIAL = 0,        /* ExponentialTransmittance.cpp:26-55 
        TGPU_TRANS_LINEAR = 1,             /* LinearTransmittance.cpp:30-76            */
        TGPU_TRANS_QUADRATIC = 2,          /* QuadraticTransmittance.cpp:30-65         */
        TGPU_TRANS_DOUBLE_EXPONENTIAL = 3, /* DoubleExponentialTransmittance.cpp:34-65 */
-       TGPU_TRANS_PULSE = 4 };            /* PulseTransmittance.cpp:43-105            */
+       TGPU_TRANS_PULSE = 4,              /* PulseTransmittance.cpp:43-105            */
+       TGPU_TRANS_ERLANG = 5,             /* ErlangTransmittance.cpp:32-67: param[0] = rate                     */
+       TGPU_TRANS_DAVIS = 6,              /* DavisTransmittance.cpp:31-60: param[0] = alpha (clamped to > 1)     */
+       TGPU_TRANS_DAVIS_WEINSTEIN = 7,    /* DavisWeinsteinTransmittance.cpp:34-117: param[0] = h in [0.5, 1], param[1] = c */
+       TGPU_TRANS_INTERPOLATED = 8 };     /* InterpolatedTransmittance.cpp:43-83: tr_a / tr_b blended with tr_ratio */
 
 typedef struct tgpu_medium {
     float   sigma_a[3], sigma_s[3], sigma_t[3];
@@ -128,6 +132,10 @@ typedef struct tgpu_medium {
     float   param[3];
     int32_t phase;               /* 0 isotropic (IsotropicPhaseFunction.cpp:17-44), 1 Henyey-Greenstein (HenyeyGreensteinPhaseFunction.cpp:19-90) */
     float   phase_g;
+    /* TGPU_TRANS_INTERPOLATED only: the two models it blends (any type but INTERPOLATED) and the ratio        */
+    int32_t tr_a_type;  float tr_a_param[3];
+    int32_t tr_b_type;  float tr_b_param[3];
+    float   tr_ratio;
 } tgpu_medium;
 
 /* ---- analytic primitives ------------------------------------------------ */

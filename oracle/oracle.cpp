@@ -336,6 +336,10 @@ struct oracle_ctx {
     V3 transForm(const tgpu_medium &m, int form, const V3 &tau) const; // 0 surfaceSurface 1 surfaceMedium 2 mediumSurface 3 mediumMedium
     float transSigmaBar(const tgpu_medium &m) const;
     float transSample(const tgpu_medium &m, Sampler &sampler, bool startOnSurface) const;
+    // one model (type + parameters); the medium-level functions above add InterpolatedTransmittance on top
+    V3 modelForm(int type, const float *param, int form, const V3 &tau) const;
+    float modelSigmaBar(int type, const float *param) const;
+    float modelSample(int type, const float *param, Sampler &sampler, bool startOnSurface) const;
     int selectMedium(const Info &info, int current, bool geometricBackside) const;
     float phaseEval(const tgpu_medium &m, const V3 &wi, const V3 &wo) const;
     V3 phaseSample(const tgpu_medium &m, Sampler &sampler, const V3 &wi, float &pdf) const;
@@ -2939,8 +2943,74 @@ V3 oracle_ctx::fastExp(const V3 &v) const
 // ---- transmittances (transmittances/*.cpp; Transmittance.hpp:22-42 picks the form from where the segment starts / ends)
 V3 oracle_ctx::transForm(const tgpu_medium &m, int form, const V3 &tau) const
 {
+    if (m.transmittance != TGPU_TRANS_INTERPOLATED) return modelForm(m.transmittance, m.param, form, tau);
+    // InterpolatedTransmittance.cpp:43-71
+    auto lerpV = [](const V3 &a, const V3 &b, float t) { return a*(1.0f - t) + b*t; }; // math/MathUtil.hpp lerp
+    const float u = m.tr_ratio;
+    const float sbA = modelSigmaBar(m.tr_a_type, m.tr_a_param), sbB = modelSigmaBar(m.tr_b_type, m.tr_b_param);
+    const float sigmaBar = transSigmaBar(m);
+    if (form == 0) return sigmaBar*lerpV(modelForm(m.tr_a_type, m.tr_a_param, 0, tau)/sbA, modelForm(m.tr_b_type, m.tr_b_param, 0, tau)/sbB, u);
+    if (form == 1 || form == 2) {
+        V3 ms = lerpV(modelForm(m.tr_a_type, m.tr_a_param, 2, tau), modelForm(m.tr_b_type, m.tr_b_param, 2, tau), u);
+        return form == 1 ? ms*sigmaBar : ms;
+    }
+    V3 pdfA = modelForm(m.tr_a_type, m.tr_a_param, 3, tau), pdfB = modelForm(m.tr_b_type, m.tr_b_param, 3, tau), result;
+    auto isDirac = [](int type) { return type == TGPU_TRANS_LINEAR || type == TGPU_TRANS_PULSE; }; // LinearTransmittance / PulseTransmittance::isDirac
+    for (int i = 0; i < 3; ++i) {
+        bool diracA = isDirac(m.tr_a_type) && pdfA[i] > 0.0f;
+        bool diracB = isDirac(m.tr_b_type) && pdfB[i] > 0.0f;
+        if (diracA ^ diracB) result[i] = diracA ? pdfA[i] : pdfB[i];
+        else result[i] = pdfA[i]*(1.0f - u) + pdfB[i]*u;
+    }
+    return result;
+}
+
+V3 oracle_ctx::modelForm(int type, const float *param, int form, const V3 &tau) const
+{
+    struct { const float *param; } m{param};
     auto vmin1 = [](const V3 &a) { return V3(fmin2(a.x, 1.0f), fmin2(a.y, 1.0f), fmin2(a.z, 1.0f)); }; // min(a, Vec3f(1))
-    switch (m.transmittance) {
+    auto ex = [&](const V3 &v) { return V3(mexp(v.x), mexp(v.y), mexp(v.z)); };          // std::exp(Vec3f): per component
+    auto pw = [&](const V3 &v, float e) { return V3(mpow(v.x, e), mpow(v.y, e), mpow(v.z, e)); }; // std::pow(Vec3f, float)
+    switch (type) {
+    case TGPU_TRANS_ERLANG: { // ErlangTransmittance.cpp:32-47
+        const float lambda = param[0];
+        if (form == 0) return 0.5f*ex(-lambda*tau)*(V3(2.0f) + lambda*tau);
+        V3 ms = ex(-lambda*tau)*(V3(1.0f) + lambda*tau);
+        if (form == 1) return ms*lambda*0.5f;
+        if (form == 2) return ms;
+        return (lambda*lambda)*tau*ex(-lambda*tau);
+    }
+    case TGPU_TRANS_DAVIS: { // DavisTransmittance.cpp:31-46
+        const float alpha = param[0];
+        if (form == 0) return pw(V3(1.0f) + tau/alpha, -alpha);
+        if (form == 1 || form == 2) return pw(V3(1.0f) + tau/alpha, -(alpha + 1.0f));
+        return (1.0f + 1.0f/alpha)*pw(V3(1.0f) + tau/alpha, -(alpha + 2.0f));
+    }
+    case TGPU_TRANS_DAVIS_WEINSTEIN: { // DavisWeinsteinTransmittance.cpp:28-80: the first channel only
+        const float h = param[0], c = param[1];
+        const float beta = 2.0f*h - 1.0f;
+        const float t = tau.x;
+        const float alpha = mpow(t, 1 - beta)/(mpow(c, 1 + beta)); // computeAlpha
+        const float base = 1.0f + t/alpha;
+        float Tr;
+        if (form == 0) {
+            Tr = mpow(base, -alpha);
+        } else if (form == 1 || form == 2) {
+            float trSurface = mpow(base, -alpha);
+            Tr = trSurface*(beta/base - (beta - 1.0f)*alpha/t*mlog(base));
+        } else {
+            float logBase = mlog(base);
+            float trSurface = mpow(base, -alpha);
+            float term1 = beta*(-1.0f + beta*(1.0f + t) + (-1.0f + 2.0f*beta)*t/alpha)/(t*base*base);
+            float term2 = ((-1.0f + beta)*beta*alpha/(t*t)*(2.0f*t + base)*logBase)/base;
+            float term3 = (beta - 1.0f)*alpha/t*logBase;
+            Tr = trSurface*(term1 - term2 + term3*term3);
+        }
+        return V3(std::isnan(Tr) ? 0.0f : Tr);
+    }
+    default: break;
+    }
+    switch (type) {
     case TGPU_TRANS_EXPONENTIAL: return fastExp(-tau); // all four forms (ExponentialTransmittance.cpp:26-41)
     case TGPU_TRANS_LINEAR: { // LinearTransmittance.cpp:30-59
         const float maxT = m.param[0];
@@ -3011,12 +3081,21 @@ V3 oracle_ctx::transForm(const tgpu_medium &m, int form, const V3 &tau) const
 
 float oracle_ctx::transSigmaBar(const tgpu_medium &m) const
 {
-    switch (m.transmittance) {
+    if (m.transmittance != TGPU_TRANS_INTERPOLATED) return modelSigmaBar(m.transmittance, m.param);
+    // InterpolatedTransmittance.cpp:73-76: 1/lerp(1/sigmaBarA, 1/sigmaBarB, u)
+    const float a = 1.0f/modelSigmaBar(m.tr_a_type, m.tr_a_param), b = 1.0f/modelSigmaBar(m.tr_b_type, m.tr_b_param);
+    return 1.0f/(a*(1.0f - m.tr_ratio) + b*m.tr_ratio);
+}
+float oracle_ctx::modelSigmaBar(int type, const float *param) const
+{
+    struct { const float *param; } m{param};
+    switch (type) {
     case TGPU_TRANS_LINEAR: return 1.0f/m.param[0];
     case TGPU_TRANS_QUADRATIC: return 2.0f/m.param[0];
     case TGPU_TRANS_DOUBLE_EXPONENTIAL: return 0.5f*(m.param[0] + m.param[1]);
     case TGPU_TRANS_PULSE: return 2.0f/(m.param[1] - m.param[0]);
-    default: return 1.0f;
+    case TGPU_TRANS_ERLANG: return m.param[0]*0.5f; // ErlangTransmittance.cpp:49-52
+    default: return 1.0f;                            // exponential, Davis, Davis-Weinstein
     }
 }
 
@@ -3029,7 +3108,49 @@ V3 oracle_ctx::transEval(const tgpu_medium &m, const V3 &tau, bool startOnSurfac
 
 float oracle_ctx::transSample(const tgpu_medium &m, Sampler &sampler, bool startOnSurface) const
 {   // Transmittance::sample -> sampleSurface / sampleMedium
-    switch (m.transmittance) {
+    if (m.transmittance != TGPU_TRANS_INTERPOLATED) return modelSample(m.transmittance, m.param, sampler, startOnSurface);
+    // InterpolatedTransmittance.cpp:78-85
+    return sampler.nextBoolean(m.tr_ratio) ? modelSample(m.tr_b_type, m.tr_b_param, sampler, startOnSurface)
+                                           : modelSample(m.tr_a_type, m.tr_a_param, sampler, startOnSurface);
+}
+float oracle_ctx::modelSample(int type, const float *param, Sampler &sampler, bool startOnSurface) const
+{
+    struct { const float *param; } m{param};
+    switch (type) {
+    case TGPU_TRANS_ERLANG: { // ErlangTransmittance.cpp:54-67
+        const float lambda = param[0];
+        if (!startOnSurface) {
+            float xi0 = sampler.next1D(), xi1 = sampler.next1D(); // (evaluation order of the two draws: see the test)
+            return -1.0f/lambda*mlog(xi0*xi1);
+        }
+        float xi = sampler.next1D();
+        float x = 0.5f;
+        for (int i = 0; i < 10; ++i) { // Newton iterations on the CDF 1 - surfaceSurface
+            x += (xi - (1.0f - modelForm(type, param, 0, V3(x)).x))/modelForm(type, param, 1, V3(x)).x;
+            x = fmax2(x, 0.0f);
+        }
+        return x;
+    }
+    case TGPU_TRANS_DAVIS: { // DavisTransmittance.cpp:53-60
+        const float alpha = param[0];
+        return startOnSurface ? alpha*(mpow(1.0f - sampler.next1D(), -1.0f/alpha) - 1.0f)
+                              : alpha*(mpow(1.0f - sampler.next1D(), -1.0f/(1.0f + alpha)) - 1.0f);
+    }
+    case TGPU_TRANS_DAVIS_WEINSTEIN: { // DavisWeinsteinTransmittance.cpp:87-117: bisection on the CDF
+        float xi = sampler.next1D();
+        float step = 1e6;
+        float result = step*2;
+        while (step > 1e-6) {
+            float cdf = 1.0f - modelForm(type, param, startOnSurface ? 0 : 2, V3(result)).x;
+            if (cdf > xi) result -= step;
+            else result += step;
+            step /= 2;
+        }
+        return result;
+    }
+    default: break;
+    }
+    switch (type) {
     case TGPU_TRANS_LINEAR: return startOnSurface ? m.param[0]*sampler.next1D() : m.param[0];
     case TGPU_TRANS_QUADRATIC:
         return startOnSurface ? m.param[0]*(1.0f - std::sqrt(1.0f - sampler.next1D())) : m.param[0]*sampler.next1D();
@@ -3430,6 +3551,31 @@ void oracle_kat_output_buffer(int channels, uint32_t n_samples, const uint32_t *
 {
     oracle_outbuf ob{a, b, variance, count};
     for (uint32_t i = 0; i < n_samples; ++i) obAddSample(ob, channels, pixel[i], values + size_t(i)*channels);
+}
+
+/* Known-answer entry for the transmittance models (tests/test_ref_kat4.py against tests/golden/ref_kat4.json, produced by the reference's own
+ * transmittances/*.cpp): the four forms at n optical depths (forms_out: n x 4 x 3 floats), sigmaBar, and n_samples draws each of
+ * sampleSurface / sampleMedium from UniformPathSampler(seed) / (seed + 1).  math_mode 0 = glibc (the reference), 1 = include/tgpu_math.h. */
+void oracle_kat_transmittance(int type, const float *param3, int math_mode, const float *tau3, uint32_t n, float *forms_out, float *sigma_bar,
+                              uint32_t seed, uint32_t n_samples, float *surface_out, float *medium_out)
+{
+    oracle_ctx ctx;
+    ctx.mathMode = math_mode;
+    ctx.buildExpTable();
+    for (uint32_t i = 0; i < n; ++i)
+        for (int form = 0; form < 4; ++form) {
+            V3 f = ctx.modelForm(type, param3, form, V3(tau3 + size_t(i)*3));
+            float *o = forms_out + (size_t(i)*4 + form)*3;
+            o[0] = f.x; o[1] = f.y; o[2] = f.z;
+        }
+    *sigma_bar = ctx.modelSigmaBar(type, param3);
+    for (int start = 0; start < 2; ++start) {
+        Pcg32 pcg(seed + uint32_t(start)); // UniformPathSampler(seed): state = seed, sequence 0 (sampling/UniformSampler.hpp:22-26)
+        Sampler s;
+        s.sobol = false;
+        s.supplemental = &pcg;
+        for (uint32_t i = 0; i < n_samples; ++i) (start == 0 ? surface_out : medium_out)[i] = ctx.modelSample(type, param3, s, start == 0);
+    }
 }
 
 void oracle_bind_output_buffers(oracle_ctx *ctx, const oracle_outbuf *bufs)

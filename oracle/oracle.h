@@ -51,6 +51,8 @@ int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint
 typedef struct oracle_outbuf { float *a, *b, *variance; uint32_t *count; } oracle_outbuf;
 void oracle_bind_output_buffers(oracle_ctx *ctx, const oracle_outbuf *bufs /* TGPU_OUTPUT_COUNT entries, or NULL */);
 
+void oracle_kat_transmittance(int type, const float *param3, int math_mode, const float *tau3, uint32_t n, float *forms_out, float *sigma_bar,
+                              uint32_t seed, uint32_t n_samples, float *surface_out, float *medium_out);
 void oracle_kat_output_buffer(int channels, uint32_t n_samples, const uint32_t *pixel, const float *values, float *a, float *b /* or NULL */,
                               float *variance /* or NULL */, uint32_t *count);
 

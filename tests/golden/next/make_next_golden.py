@@ -12,11 +12,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 REF_BIN = os.environ.get("TUNGSTEN_REF_BIN", "/tmp/tungsten-build/tungsten")
+OUT = os.path.dirname(HERE)  # tests/golden/: the rows these fixtures belong to are built by now
 
 FIXTURES = [  # name, scene, resolution, spp, renderer overrides, integrator overrides
 ] + [(f"{n}_128x72_4spp", f"next/{n}.json", (128, 72), 4, {"adaptive_sampling": False}, {}) for n in (
     "dielectric", "mirror", "conductor", "plastic", "rough_plastic", "rough_coat", "thinsheet", "oren_nayar", "phong",
-    "transparency", "mixed", "dielectric_hg_medium", "sphere_disk")]
+    "transparency", "mixed", "dielectric_hg_medium", "sphere_disk")] + [
+    # the remaining transmittance models of the fork (transmittances/TransmittanceFactory.cpp:14-24) in the Cornell box's camera medium
+    (f"{n}_96x54_8spp", f"next/{n}.json", (96, 54), 8, {"adaptive_sampling": False}, {}) for n in (
+    "trans_erlang", "trans_davis", "trans_davis_weinstein", "trans_interpolated", "trans_interpolated2")]
 
 
 def main():
@@ -35,13 +39,13 @@ def main():
         tmp = os.path.join(os.path.dirname(src), f"_tmp_{name}.json")
         json.dump(d, open(tmp, "w"))
         try:
-            r = subprocess.run([REF_BIN, "-t", "8", "-d", HERE, tmp], capture_output=True, text=True)
+            r = subprocess.run([REF_BIN, "-t", "8", "-d", OUT, tmp], capture_output=True, text=True)
         finally:
             os.remove(tmp)
-        png = os.path.join(HERE, name + ".png")
+        png = os.path.join(OUT, name + ".png")
         if os.path.exists(png):
             os.remove(png)
-        ok = r.returncode == 0 and os.path.exists(os.path.join(HERE, name + ".pfm"))
+        ok = r.returncode == 0 and os.path.exists(os.path.join(OUT, name + ".pfm"))
         print(("wrote " if ok else "FAILED ") + name, "" if ok else (r.stdout + r.stderr)[-300:])
 
 

@@ -57,6 +57,12 @@ def assert_bit_exact(got, ref, what):
     ("next/rough_coat.json", (128, 72), 8, 8),
     ("next/transparency.json", (128, 72), 8, 8),
     ("next/thinsheet.json", (128, 72), 8, 8),
+    # the fork's remaining transmittance models in the Cornell box's camera medium
+    ("next/trans_erlang.json", (96, 54), 8, 8),
+    ("next/trans_davis.json", (96, 54), 8, 8),
+    ("next/trans_davis_weinstein.json", (96, 54), 8, 8),
+    ("next/trans_interpolated.json", (96, 54), 8, 8),
+    ("next/trans_interpolated2.json", (96, 54), 8, 8),
 ])
 def test_framebuffer_bit_exact(ta, oracle_py, gpu_ctx, scene, res, spp, step):
     hs = ta.HostScene(scene_path(scene), resolution=res)

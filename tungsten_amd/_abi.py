@@ -31,7 +31,8 @@ class Bsdf(C.Structure):
 
 class Medium(C.Structure):
     _fields_ = [("sigma_a", f32*3), ("sigma_s", f32*3), ("sigma_t", f32*3), ("absorption_only", i32), ("max_bounce", i32),
-                ("transmittance", i32), ("param", f32*3), ("phase", i32), ("phase_g", f32)]
+                ("transmittance", i32), ("param", f32*3), ("phase", i32), ("phase_g", f32),
+                ("tr_a_type", i32), ("tr_a_param", f32*3), ("tr_b_type", i32), ("tr_b_param", f32*3), ("tr_ratio", f32)]
 
 
 class Quad(C.Structure):

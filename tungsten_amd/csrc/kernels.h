@@ -1961,9 +1961,51 @@ TG_DEV V3 fastExp(const DScene &sc, const V3 &v)
 // ---- transmittance models (transmittances/*.cpp).  form: 0 surfaceSurface, 1 surfaceMedium, 2 mediumSurface,
 // 3 mediumMedium; Transmittance.hpp:22-42 picks the form from where the segment starts and ends
 TG_DEV V3 vmin1(const V3 &a) { return V3(fmin2(a.x, 1.0f), fmin2(a.y, 1.0f), fmin2(a.z, 1.0f)); }
-TG_DEV V3 transForm(const DScene &sc, const tgpu_medium &m, int form, const V3 &tau)
+// one model: type + parameters (the medium-level transForm / transSigmaBar / transSample below add InterpolatedTransmittance on top)
+TG_DEV V3 powV3(const V3 &a, float e) { return V3(tgpu_powf(a.x, e), tgpu_powf(a.y, e), tgpu_powf(a.z, e)); }
+TG_DEV V3 modelForm(const DScene &sc, int type, const float *param, int form, const V3 &tau)
 {
-    switch (m.transmittance) {
+    struct { const float *param; } m{param};
+    switch (type) {
+    case TGPU_TRANS_ERLANG: { // ErlangTransmittance.cpp:32-47
+        const float lambda = param[0];
+        if (form == 0) return 0.5f*expV3(-lambda*tau)*(V3(2.0f) + lambda*tau);
+        V3 ms = expV3(-lambda*tau)*(V3(1.0f) + lambda*tau);
+        if (form == 1) return ms*lambda*0.5f;
+        if (form == 2) return ms;
+        return (lambda*lambda)*tau*expV3(-lambda*tau);
+    }
+    case TGPU_TRANS_DAVIS: { // DavisTransmittance.cpp:31-46
+        const float alpha = param[0];
+        if (form == 0) return powV3(V3(1.0f) + tau/alpha, -alpha);
+        if (form == 1 || form == 2) return powV3(V3(1.0f) + tau/alpha, -(alpha + 1.0f));
+        return (1.0f + 1.0f/alpha)*powV3(V3(1.0f) + tau/alpha, -(alpha + 2.0f));
+    }
+    case TGPU_TRANS_DAVIS_WEINSTEIN: { // DavisWeinsteinTransmittance.cpp:28-80: the first channel only
+        const float h = param[0], c = param[1];
+        const float beta = 2.0f*h - 1.0f;
+        const float t = tau.x;
+        const float alpha = tgpu_powf(t, 1 - beta)/(tgpu_powf(c, 1 + beta)); // computeAlpha
+        const float base = 1.0f + t/alpha;
+        float Tr;
+        if (form == 0) {
+            Tr = tgpu_powf(base, -alpha);
+        } else if (form == 1 || form == 2) {
+            float trSurface = tgpu_powf(base, -alpha);
+            Tr = trSurface*(beta/base - (beta - 1.0f)*alpha/t*tgpu_logf(base));
+        } else {
+            float logBase = tgpu_logf(base);
+            float trSurface = tgpu_powf(base, -alpha);
+            float term1 = beta*(-1.0f + beta*(1.0f + t) + (-1.0f + 2.0f*beta)*t/alpha)/(t*base*base);
+            float term2 = ((-1.0f + beta)*beta*alpha/(t*t)*(2.0f*t + base)*logBase)/base;
+            float term3 = (beta - 1.0f)*alpha/t*logBase;
+            Tr = trSurface*(term1 - term2 + term3*term3);
+        }
+        return V3(isnanf_(Tr) ? 0.0f : Tr);
+    }
+    default: break;
+    }
+    switch (type) {
     case TGPU_TRANS_LINEAR: { // LinearTransmittance.cpp:30-59
         const float maxT = m.param[0];
         if (form == 0) return V3(1.0f) - vmin1(tau/maxT);
@@ -2029,15 +2071,53 @@ TG_DEV V3 transForm(const DScene &sc, const tgpu_medium &m, int form, const V3 &
     default: return fastExp(sc, -tau); // ExponentialTransmittance.cpp:26-41: all four forms
     }
 }
-TG_DEV float transSigmaBar(const tgpu_medium &m)
+TG_DEV float modelSigmaBar(int type, const float *param)
 {
-    switch (m.transmittance) {
+    struct { const float *param; } m{param};
+    switch (type) {
     case TGPU_TRANS_LINEAR: return 1.0f/m.param[0];
     case TGPU_TRANS_QUADRATIC: return 2.0f/m.param[0];
     case TGPU_TRANS_DOUBLE_EXPONENTIAL: return 0.5f*(m.param[0] + m.param[1]);
     case TGPU_TRANS_PULSE: return 2.0f/(m.param[1] - m.param[0]);
-    default: return 1.0f;
+    case TGPU_TRANS_ERLANG: return m.param[0]*0.5f; // ErlangTransmittance.cpp:49-52
+    default: return 1.0f;                            // exponential, Davis, Davis-Weinstein
     }
+}
+TG_DEV float transSigmaBar(const tgpu_medium &m)
+{
+    if (m.transmittance != TGPU_TRANS_INTERPOLATED) return modelSigmaBar(m.transmittance, m.param);
+    // InterpolatedTransmittance.cpp:73-76: 1/lerp(1/sigmaBarA, 1/sigmaBarB, u)
+    const float a = 1.0f/modelSigmaBar(m.tr_a_type, m.tr_a_param), b = 1.0f/modelSigmaBar(m.tr_b_type, m.tr_b_param);
+    return 1.0f/(a*(1.0f - m.tr_ratio) + b*m.tr_ratio);
+}
+TG_DEV V3 transForm(const DScene &sc, const tgpu_medium &m, int form, const V3 &tau)
+{
+    if (m.transmittance != TGPU_TRANS_INTERPOLATED) return modelForm(sc, m.transmittance, m.param, form, tau);
+    // InterpolatedTransmittance.cpp:43-71
+    const float u = m.tr_ratio;
+    const float sbA = modelSigmaBar(m.tr_a_type, m.tr_a_param), sbB = modelSigmaBar(m.tr_b_type, m.tr_b_param);
+    const float sigmaBar = transSigmaBar(m);
+    if (form == 0) {
+        const V3 a = modelForm(sc, m.tr_a_type, m.tr_a_param, 0, tau)/sbA, b = modelForm(sc, m.tr_b_type, m.tr_b_param, 0, tau)/sbB;
+        return sigmaBar*(a*(1.0f - u) + b*u);
+    }
+    if (form == 1 || form == 2) {
+        const V3 a = modelForm(sc, m.tr_a_type, m.tr_a_param, 2, tau), b = modelForm(sc, m.tr_b_type, m.tr_b_param, 2, tau);
+        const V3 ms = a*(1.0f - u) + b*u;
+        return form == 1 ? ms*sigmaBar : ms;
+    }
+    const V3 pdfA = modelForm(sc, m.tr_a_type, m.tr_a_param, 3, tau), pdfB = modelForm(sc, m.tr_b_type, m.tr_b_param, 3, tau);
+    const bool dA = m.tr_a_type == TGPU_TRANS_LINEAR || m.tr_a_type == TGPU_TRANS_PULSE; // Transmittance::isDirac
+    const bool dB = m.tr_b_type == TGPU_TRANS_LINEAR || m.tr_b_type == TGPU_TRANS_PULSE;
+    const float pa[3] = {pdfA.x, pdfA.y, pdfA.z}, pb[3] = {pdfB.x, pdfB.y, pdfB.z};
+    float r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bool diracA = dA && pa[i] > 0.0f, diracB = dB && pb[i] > 0.0f;
+        if (diracA != diracB) r[i] = diracA ? pa[i] : pb[i];
+        else r[i] = pa[i]*(1.0f - u) + pb[i]*u;
+    }
+    return V3(r[0], r[1], r[2]);
 }
 TG_DEV V3 transEval(const DScene &sc, const tgpu_medium &m, const V3 &tau, bool startOnSurface, bool endOnSurface)
 {   // Transmittance::eval (Transmittance.hpp:22-30)
@@ -2045,9 +2125,44 @@ TG_DEV V3 transEval(const DScene &sc, const tgpu_medium &m, const V3 &tau, bool 
     if (!startOnSurface && !endOnSurface) return transForm(sc, m, 3, tau)/transSigmaBar(m);
     return transForm(sc, m, 2, tau);
 }
-TG_DEV float transSample(const tgpu_medium &m, Sampler &smp, bool startOnSurface)
+TG_DEV float modelSample(const DScene &sc, int type, const float *param, Sampler &smp, bool startOnSurface)
 {   // sampleSurface / sampleMedium of the model
-    switch (m.transmittance) {
+    struct { const float *param; } m{param};
+    switch (type) {
+    case TGPU_TRANS_ERLANG: { // ErlangTransmittance.cpp:54-67
+        const float lambda = param[0];
+        if (!startOnSurface) {
+            const float xi0 = smp.next1D(), xi1 = smp.next1D();
+            return -1.0f/lambda*tgpu_logf(xi0*xi1);
+        }
+        const float xi = smp.next1D();
+        float x = 0.5f;
+        for (int i = 0; i < 10; ++i) { // Newton iterations on the CDF 1 - surfaceSurface
+            x += (xi - (1.0f - modelForm(sc, type, param, 0, V3(x)).x))/modelForm(sc, type, param, 1, V3(x)).x;
+            x = fmax2(x, 0.0f);
+        }
+        return x;
+    }
+    case TGPU_TRANS_DAVIS: { // DavisTransmittance.cpp:53-60
+        const float alpha = param[0];
+        return startOnSurface ? alpha*(tgpu_powf(1.0f - smp.next1D(), -1.0f/alpha) - 1.0f)
+                              : alpha*(tgpu_powf(1.0f - smp.next1D(), -1.0f/(1.0f + alpha)) - 1.0f);
+    }
+    case TGPU_TRANS_DAVIS_WEINSTEIN: { // DavisWeinsteinTransmittance.cpp:87-117: bisection on the CDF
+        const float xi = smp.next1D();
+        float step = 1e6;
+        float result = step*2;
+        while (double(step) > 1e-6) {
+            const float cdf = 1.0f - modelForm(sc, type, param, startOnSurface ? 0 : 2, V3(result)).x;
+            if (cdf > xi) result -= step;
+            else result += step;
+            step /= 2;
+        }
+        return result;
+    }
+    default: break;
+    }
+    switch (type) {
     case TGPU_TRANS_LINEAR: return startOnSurface ? m.param[0]*smp.next1D() : m.param[0];
     case TGPU_TRANS_QUADRATIC:
         return startOnSurface ? m.param[0]*(1.0f - __builtin_sqrtf(1.0f - smp.next1D())) : m.param[0]*smp.next1D();
@@ -2074,6 +2189,13 @@ TG_DEV float transSample(const tgpu_medium &m, Sampler &smp, bool startOnSurface
     }
     default: return -tgpu_logf(1.0f - smp.next1D());
     }
+}
+TG_DEV float transSample(const DScene &sc, const tgpu_medium &m, Sampler &smp, bool startOnSurface)
+{
+    if (m.transmittance != TGPU_TRANS_INTERPOLATED) return modelSample(sc, m.transmittance, m.param, smp, startOnSurface);
+    // InterpolatedTransmittance.cpp:78-85
+    return smp.nextBoolean(m.tr_ratio) ? modelSample(sc, m.tr_b_type, m.tr_b_param, smp, startOnSurface)
+                                       : modelSample(sc, m.tr_a_type, m.tr_a_param, smp, startOnSurface);
 }
 
 // HomogeneousMedium::transmittance (HomogeneousMedium.cpp:110-117) over a shadow segment that ends (on a surface) at
@@ -2190,7 +2312,7 @@ TG_DEV int volumePath(const DScene &sc, const DState &st, uint32_t path) // retu
     } else {
         int component = smp.nextDiscrete(3);
         float sigmaTc = component == 0 ? sigmaT.x : (component == 1 ? sigmaT.y : sigmaT.z);
-        float ts = transSample(m, smp, firstScatter)/sigmaTc;
+        float ts = transSample(sc, m, smp, firstScatter)/sigmaTc;
         t = fmin2(ts, maxT);
         exited = ts >= maxT;
         V3 tau = t*sigmaT;

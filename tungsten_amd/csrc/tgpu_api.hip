@@ -276,10 +276,18 @@ int validate(tgpu_ctx *ctx, const tgpu_scene_desc *s)
             if (!mediumOk(s->tri_media[size_t(i)*2]) || !mediumOk(s->tri_media[size_t(i)*2 + 1])) { fail(ctx, "triangle %u: bad medium", i); return TGPU_ERR_INVALID; }
     for (uint32_t i = 0; i < s->n_media; ++i) {
         const tgpu_medium &m = s->media[i];
-        bool ok = m.transmittance >= TGPU_TRANS_EXPONENTIAL && m.transmittance <= TGPU_TRANS_PULSE;
-        if ((m.transmittance == TGPU_TRANS_LINEAR || m.transmittance == TGPU_TRANS_QUADRATIC) && !(m.param[0] > 0.0f)) ok = false;
-        if (m.transmittance == TGPU_TRANS_DOUBLE_EXPONENTIAL && !(m.param[0] > 0.0f && m.param[1] > 0.0f)) ok = false;
-        if (m.transmittance == TGPU_TRANS_PULSE && !(m.param[1] > m.param[0] && m.param[2] >= 1.0f && m.param[2] <= 4096.0f)) ok = false;
+        auto modelOk = [](int type, const float *p) { // one transmittance model: TransmittanceFactory.cpp:14-24 minus "interpolated"
+            if (type < TGPU_TRANS_EXPONENTIAL || type >= TGPU_TRANS_INTERPOLATED) return false;
+            if ((type == TGPU_TRANS_LINEAR || type == TGPU_TRANS_QUADRATIC) && !(p[0] > 0.0f)) return false;
+            if (type == TGPU_TRANS_DOUBLE_EXPONENTIAL && !(p[0] > 0.0f && p[1] > 0.0f)) return false;
+            if (type == TGPU_TRANS_PULSE && !(p[1] > p[0] && p[2] >= 1.0f && p[2] <= 4096.0f)) return false;
+            if (type == TGPU_TRANS_ERLANG && !(p[0] > 0.0f)) return false;
+            if (type == TGPU_TRANS_DAVIS && !(p[0] > 1.0f)) return false;
+            if (type == TGPU_TRANS_DAVIS_WEINSTEIN && !(p[0] >= 0.5f && p[0] <= 1.0f && p[1] > 0.0f)) return false;
+            return true;
+        };
+        bool ok = m.transmittance == TGPU_TRANS_INTERPOLATED ? (modelOk(m.tr_a_type, m.tr_a_param) && modelOk(m.tr_b_type, m.tr_b_param) && m.tr_ratio >= 0.0f && m.tr_ratio <= 1.0f)
+                                                             : modelOk(m.transmittance, m.param);
         if (m.phase < 0 || m.phase > 1 || !(m.phase_g > -1.0f && m.phase_g < 1.0f)) ok = false;
         if (!ok) { fail(ctx, "medium %u: bad transmittance / phase model or parameters", i); return TGPU_ERR_INVALID; }
     }

@@ -730,32 +730,69 @@ int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp
             throw std::runtime_error("phase function '" + pt + "' is outside the hot-path scope");
         }
     }
-    int transType = TGPU_TRANS_EXPONENTIAL;
-    float transParam[3] = {0, 0, 0};
-    if (const Json &tr = v["transmittance"]) { // TransmittanceFactory.cpp:14-24
+    // TransmittanceFactory.cpp:14-24; one model: type + up to three parameters
+    struct Model { int type = TGPU_TRANS_EXPONENTIAL; float param[3] = {0, 0, 0}; };
+    auto parseModel = [](const Json &tr, bool allowInterpolated, auto &self, Model *childA, Model *childB, float *ratio) -> Model {
+        Model m;
         std::string tt = tr.isObject() ? tr["type"].asString() : tr.asString();
         if (tt == "exponential") {
-            transType = TGPU_TRANS_EXPONENTIAL;
+            m.type = TGPU_TRANS_EXPONENTIAL;
         } else if (tt == "linear" || tt == "quadratic") { // LinearTransmittance.cpp:10-20, QuadraticTransmittance.cpp:10-20
-            transType = tt == "linear" ? TGPU_TRANS_LINEAR : TGPU_TRANS_QUADRATIC;
-            transParam[0] = 1.0f;
-            if (tr.isObject()) tr.getField("max_t", transParam[0]);
+            m.type = tt == "linear" ? TGPU_TRANS_LINEAR : TGPU_TRANS_QUADRATIC;
+            m.param[0] = 1.0f;
+            if (tr.isObject()) tr.getField("max_t", m.param[0]);
         } else if (tt == "double_exponential") { // DoubleExponentialTransmittance.cpp:13-24
-            transType = TGPU_TRANS_DOUBLE_EXPONENTIAL;
-            transParam[0] = 0.5f;
-            transParam[1] = 10.0f;
-            if (tr.isObject()) { tr.getField("sigma_a", transParam[0]); tr.getField("sigma_b", transParam[1]); }
+            m.type = TGPU_TRANS_DOUBLE_EXPONENTIAL;
+            m.param[0] = 0.5f;
+            m.param[1] = 10.0f;
+            if (tr.isObject()) { tr.getField("sigma_a", m.param[0]); tr.getField("sigma_b", m.param[1]); }
         } else if (tt == "pulse") { // PulseTransmittance.cpp:13-27
-            transType = TGPU_TRANS_PULSE;
-            transParam[0] = 0.0f;
-            transParam[1] = 1.0f;
+            m.type = TGPU_TRANS_PULSE;
+            m.param[0] = 0.0f;
+            m.param[1] = 1.0f;
             int numPulses = 4;
-            if (tr.isObject()) { tr.getField("min", transParam[0]); tr.getField("max", transParam[1]); tr.getField("num_pulses", numPulses); }
-            transParam[2] = float(numPulses);
+            if (tr.isObject()) { tr.getField("min", m.param[0]); tr.getField("max", m.param[1]); tr.getField("num_pulses", numPulses); }
+            m.param[2] = float(numPulses);
+        } else if (tt == "erlang") { // ErlangTransmittance.cpp:13-22
+            m.type = TGPU_TRANS_ERLANG;
+            m.param[0] = 5.0f;
+            if (tr.isObject()) tr.getField("rate", m.param[0]);
+        } else if (tt == "davis") { // DavisTransmittance.cpp:10-21: alpha has to be > 1, clamped with a warning
+            m.type = TGPU_TRANS_DAVIS;
+            m.param[0] = 1.1f;
+            if (tr.isObject()) tr.getField("alpha", m.param[0]);
+            if (m.param[0] < 1 + 1e-6f) {
+                std::printf("Warning: alpha parameter of Davis transmittance has to be > 1. Clamping the current value (%g)\n", double(m.param[0]));
+                m.param[0] = 1 + 1e-6f;
+            }
+        } else if (tt == "davis_weinstein") { // DavisWeinsteinTransmittance.cpp:8-24
+            m.type = TGPU_TRANS_DAVIS_WEINSTEIN;
+            m.param[0] = 0.75f;
+            m.param[1] = 1.0f;
+            if (tr.isObject()) { tr.getField("h", m.param[0]); tr.getField("c", m.param[1]); }
+            if (m.param[0] < 0.5f || m.param[0] > 1.0f)
+                std::printf("Warning: Valid range of Davis Weinstein transmittance is [0.5, 1.0]. Clamping current value (%g) to within range\n", double(m.param[0]));
+            m.param[0] = std::min(std::max(m.param[0], 0.5f), 1.0f);
+        } else if (tt == "interpolated" && allowInterpolated) { // InterpolatedTransmittance.cpp:17-30: linear and erlang by default
+            m.type = TGPU_TRANS_INTERPOLATED;
+            childA->type = TGPU_TRANS_LINEAR; childA->param[0] = 1.0f;
+            childB->type = TGPU_TRANS_ERLANG; childB->param[0] = 5.0f;
+            *ratio = 0.5f;
+            if (tr.isObject()) {
+                if (const Json &a = tr["tr_a"]) *childA = self(a, false, self, nullptr, nullptr, nullptr);
+                if (const Json &b = tr["tr_b"]) *childB = self(b, false, self, nullptr, nullptr, nullptr);
+                tr.getField("ratio", *ratio);
+            }
+        } else if (tt == "interpolated") {
+            throw std::runtime_error("an interpolated transmittance inside an interpolated transmittance is outside the hot-path scope");
         } else {
             throw std::runtime_error("transmittance '" + tt + "' is outside the hot-path scope");
         }
-    }
+        return m;
+    };
+    Model model, childA, childB;
+    float trRatio = 0.0f;
+    if (const Json &tr = v["transmittance"]) model = parseModel(tr, true, parseModel, &childA, &childB, &trRatio);
     float sa[3] = {0, 0, 0}, ss[3] = {0, 0, 0}, density = 1.0f;
     v.getVec("sigma_a", sa, 3);
     v.getVec("sigma_s", ss, 3);
@@ -771,8 +808,11 @@ int Scene::parseMedium(const Json &v) // HomogeneousMedium.cpp:19-48, Medium.cpp
     m.absorption_only = m.sigma_s[0] == 0.0f && m.sigma_s[1] == 0.0f && m.sigma_s[2] == 0.0f;
     m.phase = phaseType;
     m.phase_g = phaseG;
-    m.transmittance = transType;
-    for (int i = 0; i < 3; ++i) m.param[i] = transParam[i];
+    m.transmittance = model.type;
+    m.tr_a_type = childA.type;
+    m.tr_b_type = childB.type;
+    m.tr_ratio = trRatio;
+    for (int i = 0; i < 3; ++i) { m.param[i] = model.param[i]; m.tr_a_param[i] = childA.param[i]; m.tr_b_param[i] = childB.param[i]; }
     _media.push_back(m);
     return int(_media.size()) - 1;
 }

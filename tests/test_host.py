@@ -129,3 +129,13 @@ def test_pfm_roundtrip(ta, tmp_path):
     p = tmp_path / "x.pfm"
     ta.save_pfm(p, img)
     assert np.array_equal(ta.load_pfm(p), img)
+
+
+def test_reference_side_integrator_compiles_against_the_reference_headers():
+    """integration/Mi355xPathTraceIntegrator.{hpp,cpp} -- the Integrator subclass of INTEGRATION.md section 2 -- type-checks against
+    the reference's own headers (only where /root/reference exists: the GPU box has no reference tree)."""
+    import subprocess
+    if not os.path.isdir("/root/reference/src/core"):
+        pytest.skip("no reference tree here")
+    r = subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "-f", "Makefile.ref", "integration-check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

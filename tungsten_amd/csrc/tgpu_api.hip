@@ -1114,7 +1114,8 @@ static int driveIteration(tgpu_ctx *ctx)
         }
         ctx->traceIter++;
     }
-    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] iter in=%u out=[%u %u %u %u %u] claims=%u free=%u base=%llu limit=%llu active=%zu\n", nCur,
+    if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] t=%.3f ms alive=%llu%s iter in=%u out=[%u %u %u %u %u] claims=%u free=%u base=%llu limit=%llu active=%zu\n",                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - 1e3*std::floor(1e-3*std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()/1e3)*1e3,
+                                      (unsigned long long)ctx->aliveCount, tail ? " (tail)" : "", nCur,
                                       hc[CNT(CNT_LIST0 + out*TG_LISTS)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 1)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 2)], hc[CNT(CNT_LIST0 + out*TG_LISTS + 3)],
                                       hc[CNT(CNT_LIST0 + out*TG_LISTS + 4)], hc[CNT(CNT_REGEN)], hc[CNT(CNT_FREE)], ctx->sampleBase, limit, ctx->active.size());
     uint64_t nNext = 0;

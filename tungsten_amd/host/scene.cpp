@@ -1071,9 +1071,14 @@ void Scene::parseCamera(const Json &v)
 
 Scene Scene::load(const std::string &jsonPath, const std::string &inputDirectory)
 {
+    return loadText(readFile(jsonPath), inputDirectory.empty() ? dirName(jsonPath) : inputDirectory);
+}
+
+Scene Scene::loadText(const std::string &jsonText, const std::string &resourceDirectory)
+{
     Scene s;
-    s.sceneDir = inputDirectory.empty() ? dirName(jsonPath) : inputDirectory;
-    s.sceneJsonText = readFile(jsonPath);
+    s.sceneDir = resourceDirectory;
+    s.sceneJsonText = jsonText;
     Json root = Json::parse(s.sceneJsonText);
 
     const Json &media = root["media"];

@@ -53,6 +53,8 @@ public:
     // Scene::load (Scene.cpp:378-391). Throws JsonLoadException / std::runtime_error.
     // inputDirectory: where relative resource paths are resolved (the CLI's -i; default: the scene file's directory, Shared.hpp:205)
     static Scene load(const std::string &jsonPath, const std::string &inputDirectory = std::string());
+    // The same from the scene text itself (what Scene::toJson of the reference writes); relative resource paths are resolved in resourceDirectory
+    static Scene loadText(const std::string &jsonText, const std::string &resourceDirectory);
 
     // CLI-style overrides applied before flatten() (Shared.hpp:221-248)
     void setResolution(uint32_t w, uint32_t h);

@@ -141,8 +141,14 @@ def main():
         done += spp_step
     for c in ctxs:
         c.wait()
-    if dist is not None:  # warm the communicator outside the timed region
-        gather_framebuffers(outs, shards, world, rank, K, dist)
+    # warm the end-of-render path outside the timed region as well: the device-side resolve, torch's scatter into image order (its kernels
+    # are loaded on first use: tens of ms on a cold box, measured as 690 vs 790 Msamples/s for the first process on a fresh machine) and,
+    # with several ranks, the communicator
+    for c, o in zip(ctxs, outs):
+        c.resolve_to_device(o.data_ptr())
+    for c in ctxs:
+        c.wait()
+    gather_framebuffers(outs, shards, world, rank, K, dist)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):

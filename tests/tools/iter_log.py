@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, "/root/repo")
 import tungsten_amd as ta
 scene = ta.HostScene("/root/repo/assets/materialtest/c2.json")
-shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, 0, 8)
+shard = ta.Shard(scene.res_x, scene.res_y, 0xBA5EBA11, 0, int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 ctx = ta.Context(0)
 ctx.upload(scene, shard)
 ctx.render(48, spp_step=16)

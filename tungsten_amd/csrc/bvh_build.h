@@ -101,8 +101,21 @@ private:
         return uint32_t(v < 1 ? 1 : (v > 8 ? 8 : v));
     }
 
+    // TGPU_BVH_ALIGN=1: a two-triangle leaf never straddles a 128-byte line (two 64-byte records): an unreferenced filler record goes in front of it
+    // when it would (A/B, profiles/r02_ab_notes.txt)
+    static bool alignLeaves()
+    {
+        const char *e = std::getenv("TGPU_BVH_ALIGN");
+        return e ? std::atoi(e) != 0 : false;
+    }
     int32_t makeLeaf(uint32_t first, uint32_t count, Box &box)
     {
+        if (count == 2 && (_out->triId.size() & 1u) && alignLeaves()) {
+            _out->tris.push_back({0.0f, 0.0f, 0.0f, 0.0f});
+            _out->tris.push_back({0.0f, 0.0f, 0.0f, 0.0f});
+            _out->tris.push_back({0.0f, 0.0f, 0.0f, 0.0f});
+            _out->triId.push_back(0);
+        }
         uint32_t start = uint32_t(_out->triId.size());
         box.reset();
         for (uint32_t i = first; i < first + count; ++i) {

@@ -43,31 +43,47 @@ def gather_framebuffer(local_rgb, shard, world, rank, dist=None, device=None):
     return image.reshape(res_y, res_x, 3)
 
 
+_INDEX_CACHE = {}
+
+
+def _shard_indices(res_x, res_y, total, device):
+    """Pixel indices (torch int64 on `device`) and sizes of all `total` shards of an image: computed once per (image, split, device) --
+    dicing the image into tiles is host work that does not belong between two renders."""
+    import torch
+
+    key = (res_x, res_y, total, str(device))
+    if key not in _INDEX_CACHE:
+        idx = [torch.from_numpy(Shard(res_x, res_y, 0xBA5EBA11, i, total).pixel_index.astype(np.int64)).to(device) for i in range(total)]
+        _INDEX_CACHE[key] = (idx, [int(t.numel()) for t in idx])
+    return _INDEX_CACHE[key]
+
+
 def gather_framebuffers(local_rgbs, shards, world, rank, sub, dist=None):
     """Like gather_framebuffer for `sub` image-plane shards per rank (one context each: two pools on separate streams
     fill each other's launch gaps and kernel tails).  Shard j of rank r is shard r*sub + j of world*sub.
-    Returns the (H, W, 3) image on rank 0, None elsewhere."""
+    The shards are put into image order where they live (on the GPU with RCCL: one indexed copy per shard), then the image
+    goes to the host once.  Returns the (H, W, 3) image on rank 0, None elsewhere."""
     import torch
 
     res_x, res_y = shards[0].res_x, shards[0].res_y
-    image = np.zeros((res_y*res_x, 3), np.float32) if rank == 0 else None
+    nccl = dist is not None and dist.get_backend() == "nccl"
+    where = local_rgbs[0].device if (world == 1 or nccl) else torch.device("cpu")
+    idx, sizes = _shard_indices(res_x, res_y, world*sub, where)
+    image = torch.zeros((res_y*res_x, 3), dtype=torch.float32, device=where) if rank == 0 else None
     for j in range(sub):
         local = local_rgbs[j]
         if world == 1:
-            image[shards[j].pixel_index] = local.detach().cpu().numpy()
+            image[idx[j]] = local.detach()
             continue
-        sizes = [Shard(res_x, res_y, 0xBA5EBA11, r*sub + j, world*sub).n_pixels for r in range(world)]
-        n_max = max(sizes)
-        where = local.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        n_max = max(sizes[r*sub + j] for r in range(world))
         padded = torch.zeros((n_max, 3), dtype=torch.float32, device=where)
         padded[: local.shape[0]] = local.to(where)
         gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
         dist.gather(padded, gather_list=gathered, dst=0)
         if rank == 0:
             for r in range(world):
-                sh = Shard(res_x, res_y, 0xBA5EBA11, r*sub + j, world*sub)
-                image[sh.pixel_index] = gathered[r][: sizes[r]].cpu().numpy()
-    return image.reshape(res_y, res_x, 3) if rank == 0 else None
+                image[idx[r*sub + j]] = gathered[r][: sizes[r*sub + j]]
+    return image.cpu().numpy().reshape(res_y, res_x, 3) if rank == 0 else None
 
 
 def exchange_records(table, dist, device=None):

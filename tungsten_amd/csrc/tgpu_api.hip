@@ -437,7 +437,12 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
         tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count, triPad);
         tgpu_bvh::Bvh bvh = builder.build();
         tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run(); // the quantised BVH4 the kernels traverse (bvh_build.h)
+        // TGPU_BVH_BFS=1: breadth-first node order -- the (up to four) children of a node are neighbours, so the second child a ray visits usually
+        // shares a 128-byte line with the first; the depth-first default keeps a node next to its FIRST child.  Measured: no difference
+        // (profiles/r02_ab_notes.txt), like TGPU_BVH_ALIGN (bvh_build.h)
+        if (getenv("TGPU_BVH_BFS") && atoi(getenv("TGPU_BVH_BFS"))) (void)tgpu_bvh::reorderTopLevels(bvh4, 1 << 20);
         if (first == 0 && nodeletLevels > 0) nodeletCount = tgpu_bvh::reorderTopLevels(bvh4, nodeletLevels); // the scene's own BVH only
+        if ((allTris.size()/4) & 1u) for (int k = 0; k < 4; ++k) allTris.push_back(tgpu_bvh::Float4{0.0f, 0.0f, 0.0f, 0.0f}); // every BVH's records start on a line
         const uint32_t nodeBase = uint32_t(allNodes.size()/4), triBase = uint32_t(allTris.size()/4);
         auto rebase = [&](uint32_t ref) -> uint32_t {
             if (ref == 0xFFFFFFFFu) return ref;                               // empty slot

@@ -278,9 +278,6 @@ TG_DEV V3 resolveNeeTerms(const DState &st, uint32_t slot, V3 em)
     if (__float_as_uint(e.w) & 1u) em += xyz(st.shF[slot]);
     return em;
 }
-// The general shade kernels call it out of line: inlined into k_shade<RoughConductor, general> it trips a register-allocation error of
-// this compiler ("Subtarget requires even aligned vector registers", ROCm 7.2 / gfx950); one call per vertex is not measurable.
-__device__ __noinline__ V3 resolveNeeTermsCall(const DState &st, uint32_t slot, V3 em) { return resolveNeeTerms(st, slot, em); }
 
 // =================================================================================================
 // K1 generate
@@ -1303,7 +1300,10 @@ TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
 // no classification.
 // =================================================================================================
 template <bool COUNT, bool RAW, bool INST>
-__global__ void __launch_bounds__(256, (INST ? 1 : TG_EXTEND_WAVES)) k_extend(DScene sc, DState st, int set, uint32_t rawCount)
+#ifndef TG_EXTEND_INST_WAVES
+#define TG_EXTEND_INST_WAVES 4 /* waves per SIMD the general-geometry closest-hit kernel is compiled for: 4 = 128 VGPRs, no extra spills; config 4 140 -> 153 Msamples/s against 141 VGPRs / 3 waves, 5 waves (96 VGPRs) 133 (profiles/r02_ab_notes.txt) */
+#endif
+__global__ void __launch_bounds__(256, (INST ? TG_EXTEND_INST_WAVES : TG_EXTEND_WAVES)) k_extend(DScene sc, DState st, int set, uint32_t rawCount)
 {
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
@@ -2499,7 +2499,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
     bool wasSpecular = flagsSpecular(flags);
     int end = END_ALIVE;
     if (stateNee(st.state[path])) // NEE terms of the previous vertex (k_shadow_q left the visibility bits)
-        em = MEDIA ? resolveNeeTermsCall(st, path, em) : resolveNeeTerms<false>(st, path, em);
+        em = resolveNeeTerms<MEDIA>(st, path, em); // (inline: an out-of-line call here cost the general kernels 600 B of scratch per lane, config 5 -9 %)
 
     // afterMedium: volumePath ran the check before the distance sampling and scaled tp by the medium weight since
     if (!afterMedium && bounce > 0 && isnanf_(tp.sum() + em.sum())) {
@@ -3157,7 +3157,7 @@ __global__ void __launch_bounds__(256, TG_SHADOWQ_WAVES) k_shadow_q(DScene sc, D
 // in scratch memory (400-1168 B per lane) at one wave per SIMD.
 // =================================================================================================
 #ifndef TG_INSTQ_WAVES
-#define TG_INSTQ_WAVES 3
+#define TG_INSTQ_WAVES 4 /* 128 VGPRs (3 waves: 135-138): config 4 shadow 28.3 -> 27.4 ms/step */
 #endif
 // Closest hit with persistent lanes: a wave claims CHUNK = 64*DEPTH entries of the input lists with one atomic and hands them to
 // its lanes one ray at a time (k_shadow_q's scheme); the hit goes to the slot's record, the sort by material is k_classify's job

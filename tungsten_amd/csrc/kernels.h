@@ -815,8 +815,9 @@ TG_DEV bool instanceIntersect(const DScene &sc, const DInstSet &is, uint32_t set
     const bool px = D.x >= 0.0f, py = D.y >= 0.0f, pz = D.z >= 0.0f;
     const float nearLane = tnear;
     float negFarLane = -rayFarT;
-    uint32_t tsNode[TG_TOP_STACK];
-    float tsT[TG_TOP_STACK];
+    // the (node, tMin) stack of this walk: in LDS behind the mesh levels (sc.topStackLds entries per thread, the tree's depth + 1), like the
+    // queue kernels' -- as local arrays it lived in scratch memory, a memory round trip per push and pop
+    uint2 *topStack = reinterpret_cast<uint2 *>((stack - threadIdx.x) + sc.stackLds*256) + threadIdx.x;
     int sp = 0;
     uint32_t node = 0;
     bool hit = false;
@@ -838,8 +839,8 @@ TG_DEV bool instanceIntersect(const DScene &sc, const DInstSet &is, uint32_t set
             const bool hitL = mn0 <= mx0, hitR = mn1 <= mx1;
             const uint32_t l = __float_as_uint(q3.x), r = __float_as_uint(q3.y);
             if (hitL && hitR) {
-                if (mn0 < mn1) { tsNode[sp] = r; tsT[sp] = mn1; ++sp; node = l; tMin = mn0; }
-                else { tsNode[sp] = l; tsT[sp] = mn0; ++sp; node = r; tMin = mn1; }
+                if (mn0 < mn1) { topStack[sp*256] = make_uint2(r, __float_as_uint(mn1)); ++sp; node = l; tMin = mn0; }
+                else { topStack[sp*256] = make_uint2(l, __float_as_uint(mn0)); ++sp; node = r; tMin = mn1; }
             } else if (hitL) { node = l; tMin = mn0; }
             else if (hitR) { node = r; tMin = mn1; }
             else { reachedLeaf = false; break; }
@@ -890,8 +891,9 @@ TG_DEV bool instanceIntersect(const DScene &sc, const DInstSet &is, uint32_t set
         while (true) {
             if (sp == 0) { done = true; break; }
             --sp;
-            node = tsNode[sp];
-            tMin = tsT[sp];
+            const uint2 e = topStack[sp*256];
+            node = e.x;
+            tMin = __uint_as_float(e.y);
             if (tMax < tMin) continue;
             break;
         }

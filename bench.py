@@ -14,7 +14,7 @@ here: total work is fixed -> "scaling": "strong"); each rank renders its shard w
 collective and one RCCL gather of the framebuffers to rank 0 closes the timed region.
 
 Extra objects on the JSON line:
-  roofline     the traversal kernel with the larger share of the step (k_extend_q: closest hit, four rays per lane; k_shadow_q:
+  roofline     the traversal kernel with the larger share of the step (k_extend_p: closest hit, persistent lanes; k_shadow_q:
                any hit, eight rays per lane), HBM bound.  achieved = algorithmic bytes per launch / average launch
                duration, both measured live after the timed region: bytes from the kernel's own visit counters (64 B per
                BVH node fetch, 48 B per triangle fetch, plus the queue traffic per ray / vertex), duration from HIP events
@@ -219,7 +219,7 @@ def main():
             for cx in ctxs:
                 cx.set_profiling(0)
             return tot
-        c = phase(1, done)                       # visit counters (k_extend_q<true>)
+        c = phase(1, done)                       # visit counters (the counting build of the kernel: k_extend_p<true>)
         t = phase(2, done + spp_step*rsteps)     # HIP-event timing of the production kernels, each on its own stream
         # committed PMC pass of the same command on configs[1] (profiles/collect.sh + summarize.py): HBM-side bytes per launch.
         # NOT measured in this run -- the source is named next to the number; null for other scenes / when the file is absent.
@@ -249,7 +249,10 @@ def main():
 
         launches = max(1, c["extend_launches"])
         ext_bytes = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES + c["extend_rays"]*RAY_QUEUE_BYTES)/launches
-        ext = roof("k_extend_q", ext_bytes, t["extend_ms"], t["extend_launches"],
+        # the closest-hit kernel of flat scenes: persistent lanes (k_extend_p) unless TGPU_EXTEND_P=0 selects the fixed four-rays-per-lane form;
+        # scenes with instances / spheres / disks run k_extend<general>
+        ext_kernel = "k_extend_q" if os.environ.get("TGPU_EXTEND_P", "1") == "0" else "k_extend_p"
+        ext = roof(ext_kernel, ext_bytes, t["extend_ms"], t["extend_launches"],
                    {"per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
                                 "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)}})
         # shadow kernel.  Queue form (k_shadow_q): per ray 36 B in (direction + far end, origin + near end, end cap), per vertex a

@@ -36,9 +36,9 @@ json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_
 latest = dict(out)
 latest["_source"] = f"profiles/{tag}_pmc.json"
 json.dump(latest, open(os.path.join(here, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
-ext = next((v for k, v in out.items() if k.startswith("k_extend_q<false")), None)
+ext = next((v for k, v in out.items() if k.startswith("k_extend_p<false") or k.startswith("k_extend_q<false")), None)
 if ext:
-    json.dump({"kernel": "k_extend_q<false, 4>", "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+    json.dump({"kernel": "k_extend_p<false> (k_extend_q<false, 4> in profiles taken before it existed)", "source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                "hbm_bytes_per_launch": round(ext["hbm_bytes_per_launch"]), "fetch_bytes_per_launch": round(ext["fetch_bytes_per_launch"]),
                "write_bytes_per_launch": round(ext["write_bytes_per_launch"]), "l2_hit_rate": round(ext["l2_hit_rate"], 4),
                "note": "FETCH_SIZE doubled per the gfx950 16-B/lane correction; includes Infinity-Cache hits"},

@@ -120,6 +120,7 @@ struct DScene {
     uint32_t ldsNodes;          // nodes [0, ldsNodes) of `nodes` (the top levels of the scene's BVH4, breadth first) are staged in LDS by the kernel
                                 // this copy of the scene is launched with (0: none); ldsNodeWord: their offset in the dynamic LDS block, in words
     uint32_t ldsNodeWord;
+    uint32_t ldsQueueWord;      // k_extend_p: offset (words) of the per-wave buffers of finished rays in the dynamic LDS block
     int32_t topStackLds;        // scenes with "instances": entries of the (node, tMin) stack of the top-level walk, in LDS behind the levels above
     uint32_t spillStride;       // threads of the largest grid
     uint32_t *stackSpill;

@@ -1551,6 +1551,208 @@ __global__ void __launch_bounds__(256, (DEPTH > 4 ? TG_EXTQ_WAVES_DEEP : TG_EXTQ
 }
 
 // =================================================================================================
+// K2p: the closest-hit kernel with PERSISTENT lanes (k_shadow_q's scheme).  In k_extend_q a lane owns four fixed list entries and the wave
+// moves on when its slowest lane has finished all four -- with ray lengths spread as they are, the lanes that finish early idle for a
+// good part of every 256-entry chunk.  Here a wave claims chunks of 256 entries with one atomic and hands the entries to its lanes one
+// at a time, whenever a group of lanes is waiting; a lane always has its next ray's record in registers (fetched while the current one is
+// traced) and its next list entry in flight.  Finished rays -- (slot, prim) pairs -- collect in a per-wave LDS buffer and are classified and
+// appended to the lists of the other set 256 at a time by k_extend_q's append code: one atomic per class and 256 rays, as before.
+// Per-ray arithmetic is closestHit's, unchanged.
+// =================================================================================================
+#ifdef TG_TU_MAIN
+#ifndef TG_EXTP_WAVES
+#define TG_EXTP_WAVES 5
+#endif
+#ifndef TG_EXTP_THRESH
+#define TG_EXTP_THRESH 24 /* waiting lanes that trigger a re-arm round: 8 / 16 / 24 / 32 -> extend 5.50 / 5.15 / 5.09 / 5.15 ms per step */
+#endif
+constexpr uint32_t TG_EXTP_BUF = 320; // pairs per wave: a flush leaves < 64 behind and a re-arm round adds <= 64
+template <bool COUNT>
+static __global__ void __launch_bounds__(256, TG_EXTP_WAVES) k_extend_p(DScene sc, DState st, int set)
+{
+    constexpr uint32_t CHUNK = 256u;
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    stageNodelets(sc);
+    uint2 *buf = reinterpret_cast<uint2 *>(ldsStack + sc.ldsQueueWord) + size_t(wave)*TG_EXTP_BUF;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t count = listTotal(lc, 0);
+    const int out = set ^ 1;
+    TraceCounters tc{0, 0};
+    uint32_t chunkPos = 0, chunkEnd = 0; // the wave's private chunk of list entries (wave-uniform)
+    bool exhausted = false;
+    auto claim = [&](bool want, uint32_t &slot) -> bool { // hands one list entry to every lane that wants one (all lanes call)
+        bool got = false;
+        unsigned long long m = __ballot(want);
+        while (m) {
+            if (chunkPos == chunkEnd) {
+                if (exhausted) break;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&st.counters[CNT(CNT_HEAD_EXT)], CHUNK);
+                b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
+                if (b >= count) {
+                    exhausted = true;
+                    break;
+                }
+                chunkPos = b;
+                chunkEnd = min(b + CHUNK, count);
+            }
+            const uint32_t rank = uint32_t(__builtin_popcountll(m & below)), avail = chunkEnd - chunkPos;
+            const bool mine = ((m >> lane) & 1ull) && rank < avail;
+            if (mine) got = listFetch(st, lc, set, 0, chunkPos + rank, slot);
+            chunkPos += min(uint32_t(__builtin_popcountll(m)), avail);
+            m &= ~__ballot(mine);
+        }
+        return got;
+    };
+    // classify the first nFlush (<= 256) buffered pairs and append their slots to the lists of the other set (k_extend_q's code)
+    auto flush = [&](uint32_t nFlush) {
+        uint32_t p[4], h[4];
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p[q] = 0;
+            h[q] = PRIM_IDLE;
+            if (uint32_t(lane) + 64u*q < nFlush) {
+                const uint2 e = buf[uint32_t(lane) + 64u*q];
+                p[q] = e.x;
+                h[q] = e.y;
+                n = q + 1;
+            }
+        }
+        uint32_t cls4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t cls = 0xFEu;
+            if (q < n) {
+                if (h[q] == PRIM_IDLE) {
+                    cls = 0xFDu;
+                } else {
+                    cls = hitClass(sc, h[q]);
+                    if (sc.nMedia && (st.med[p[q]] & 0xFFu)) cls = TG_CLASS_VOLUME;
+                }
+            }
+            cls4 |= cls << (8*q);
+        }
+#pragma unroll
+        for (int l = 0; l <= TG_LISTS; ++l) {
+            const uint32_t want = l == 0 ? 0xFFu : (l == TG_LISTS ? 0xFDu : uint32_t(l - 1));
+            unsigned long long m0 = __ballot((cls4 & 0xFFu) == want), m1 = __ballot(((cls4 >> 8) & 0xFFu) == want);
+            unsigned long long m2 = __ballot(((cls4 >> 16) & 0xFFu) == want), m3 = __ballot((cls4 >> 24) == want);
+            uint32_t n0 = uint32_t(__builtin_popcountll(m0)), n1 = uint32_t(__builtin_popcountll(m1));
+            uint32_t n2 = uint32_t(__builtin_popcountll(m2)), n3 = uint32_t(__builtin_popcountll(m3));
+            uint32_t nn = n0 + n1 + n2 + n3;
+            if (nn == 0) continue;
+            uint32_t *dst = l == TG_LISTS ? st.freeQ : st.lists[out][l];
+            uint32_t *ctr = l == TG_LISTS ? &st.counters[CNT(CNT_FREE)] : &st.counters[CNT(CNT_LIST0 + out*TG_LISTS + l)];
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(ctr, nn);
+            wbase = __shfl(wbase, 0);
+            if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p[0]);
+            if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p[1]);
+            if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p[2]);
+            if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p[3]);
+        }
+    };
+    // lane state: the ray being traced (slot cs), the ray whose record is in flight (pSlot -> nro, nrd, nflags), the next list entry (nvs)
+    uint32_t cs = 0, pSlot = 0, nvs = 0, nflags = 0;
+    bool pre = false, haveNext = false;
+    float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
+    auto fetchRay = [&]() {
+        nro = ldStream(&st.rayO[pSlot]);
+        nrd = ldStream(&st.rayD[pSlot]);
+        nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[pSlot]) + 3);
+    };
+    pre = claim(true, pSlot);
+    if (pre) fetchRay();
+    haveNext = claim(pre, nvs);
+    bool active = false, fin = false, idle = false; // idle: the entry's slot holds no live path (no hit record, class 0xFD)
+    uint32_t bufCount = 0; // wave-uniform
+    TravState r;
+    r.node = 0; r.sp = 0; r.bestT = 0.0f; r.bestU = 0.0f; r.bestV = 0.0f; r.bestPrim = PRIM_MISS;
+    while (true) {
+        if (active) {
+            if (travStep<false, COUNT>(sc, stack, r, tc) != TRAV_MORE) {
+                active = false;
+                fin = true;
+            }
+        }
+        const bool waiting = !active && (fin || pre);
+        const unsigned long long w = __ballot(waiting), act = __ballot(active);
+        if (w == 0 && act == 0) break;
+        if (act != 0 && __builtin_popcountll(w) < TG_EXTP_THRESH) continue;
+        // finished rays: hit record out, (slot, prim) into the wave's buffer
+        const bool retire = waiting && fin;
+        const unsigned long long rm = __ballot(retire);
+        if (retire) {
+            if (!idle) stStream(&st.hit[cs], make_float4(r.bestT, r.bestU, r.bestV, __uint_as_float(r.bestPrim)));
+            buf[bufCount + uint32_t(__builtin_popcountll(rm & below))] = make_uint2(cs, idle ? PRIM_IDLE : r.bestPrim);
+            fin = false;
+        }
+        bufCount += uint32_t(__builtin_popcountll(rm));
+        bool wantEntry = false;
+        if (waiting && pre) { // arm the ray whose record was fetched ahead
+            cs = pSlot;
+            idle = flagsEnd(nflags) == END_DEAD;
+            if (!idle) {
+                const V3 O = xyz(nro), D = xyz(nrd);
+                const float tnear = nro.w;
+                float tfar = nrd.w, u = 0.0f, v = 0.0f;
+                uint32_t prim = PRIM_MISS;
+                for (uint32_t i = 0; i < sc.nQuads; ++i) { // closestHit's order: quads, cubes, triangles
+                    QuadHit qh;
+                    if (quadIntersect(sc.quads[i], O, D, tnear, tfar, qh)) {
+                        tfar = qh.t; u = qh.u; v = qh.v;
+                        prim = mkPrim(KIND_QUAD, i);
+                    }
+                }
+                for (uint32_t i = 0; i < sc.nCubes; ++i) {
+                    float t;
+                    bool back;
+                    if (cubeIntersect(sc.cubes[i], O, D, tnear, tfar, t, back)) {
+                        tfar = t; u = 0.0f; v = 0.0f;
+                        prim = mkPrim(KIND_CUBE, i);
+                    }
+                }
+                travInit(r, sc.rootChild, O, D, tnear, tfar, prim);
+                r.bestU = u; r.bestV = v;
+                if (sc.nTris) active = true;
+                else fin = true;
+            } else {
+                fin = true;
+            }
+            if (haveNext) {
+                pSlot = nvs;
+                haveNext = false;
+                wantEntry = true;
+                fetchRay();
+            } else {
+                pre = false;
+            }
+        }
+        uint32_t slot = 0;
+        const bool got = claim(wantEntry, slot);
+        if (wantEntry) {
+            haveNext = got;
+            nvs = slot;
+        }
+        if (bufCount >= 256u) { // wave-uniform
+            flush(256u);
+            const uint32_t rem = bufCount - 256u; // < 64
+            uint2 e = make_uint2(0u, 0u);
+            if (uint32_t(lane) < rem) e = buf[256u + uint32_t(lane)];
+            if (uint32_t(lane) < rem) buf[lane] = e;
+            bufCount = rem;
+        }
+    }
+    if (bufCount) flush(bufCount);
+    if (COUNT) flushCounters(st.stats, 0, tc);
+}
+#endif
+
+// =================================================================================================
 // K5 miss (runs inside k_retire_regenerate): TraceBase::handleInfiniteLights (TraceBase.cpp:570-578) + end of traceSample
 // =================================================================================================
 // Returns the path's end state with its radiance and throughput.sum() (what the retire step needs), after writing them back.
@@ -2994,7 +3196,7 @@ __global__ void __launch_bounds__(256, ((INST || FWD) ? 1 : TG_SHADOW_WAVES)) k_
 // radiance (it visits every slot anyway and reads the second halves of both records).
 // =================================================================================================
 #ifndef TG_SHADOWQ_THRESH
-#define TG_SHADOWQ_THRESH 16
+#define TG_SHADOWQ_THRESH 24 /* 16 / 24 / 32: shadow 4.08 / 4.02 / 4.01 ms per step */
 #endif
 #ifndef TG_SHADOWQ_WAVES
 #define TG_SHADOWQ_WAVES 7
@@ -3781,8 +3983,6 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shadow<true, false, true>(DScene, DState, int); \
     PFX template __global__ void k_shadow<true, true, false>(DScene, DState, int); \
     PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
-#define TG_KERNELS_TAIL(PFX, C, I) \
-    PFX template __global__ void k_tail<C, I, false>(DScene, DState, int, uint32_t); \
-    PFX template __global__ void k_tail<C, I, true>(DScene, DState, int, uint32_t);
+#define TG_KERNELS_TAIL(PFX, C, I, F) PFX template __global__ void k_tail<C, I, F>(DScene, DState, int, uint32_t);
 
 } // namespace tg

@@ -29,10 +29,14 @@ TG_KERNELS_SHADE(extern, false)
 TG_KERNELS_SHADE(extern, true)
 TG_KERNELS_SHADOW(extern)
 TG_KERNELS_INSTQ(extern)
-TG_KERNELS_TAIL(extern, false, false)
-TG_KERNELS_TAIL(extern, false, true)
-TG_KERNELS_TAIL(extern, true, false)
-TG_KERNELS_TAIL(extern, true, true)
+TG_KERNELS_TAIL(extern, false, false, false)
+TG_KERNELS_TAIL(extern, false, false, true)
+TG_KERNELS_TAIL(extern, false, true, false)
+TG_KERNELS_TAIL(extern, false, true, true)
+TG_KERNELS_TAIL(extern, true, false, false)
+TG_KERNELS_TAIL(extern, true, false, true)
+TG_KERNELS_TAIL(extern, true, true, false)
+TG_KERNELS_TAIL(extern, true, true, true)
 }
 
 namespace {
@@ -96,6 +100,7 @@ struct tgpu_ctx {
     int numCUs = 256;
     int maxGrid = 2048;
     int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
+    bool extendPersistent = true;  // the persistent-lane form of the queue kernel (k_extend_p); TGPU_EXTEND_P=0: k_extend_q (A/B)
     uint32_t nodeletCount = 0;   // nodes of the top BVH4 levels staged in LDS by the queue kernels (TGPU_LDS_NODELETS)
     bool instExtendQueue = false; // TGPU_INST_EXTEND_Q=1: k_extend_iq + k_classify for scenes with instances / spheres / disks (A/B)
     int shadowQueue = 4;        // vertices (= 2 rays each) per lane of the shadow kernel's queue form: 4 or 8; TGPU_SHADOW_Q=0: k_shadow (A/B)
@@ -539,6 +544,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
 
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
     if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
+    if (const char *e = getenv("TGPU_EXTEND_P")) ctx->extendPersistent = atoi(e) != 0;
     ctx->instExtendQueue = getenv("TGPU_INST_EXTEND_Q") && atoi(getenv("TGPU_INST_EXTEND_Q")) != 0;
     if (const char *e = getenv("TGPU_SHADOW_Q")) ctx->shadowQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
@@ -1025,7 +1031,12 @@ static int driveIteration(tgpu_ctx *ctx)
                 DScene scq = sc; // the queue kernels' copy: with the LDS nodelets, if any
                 scq.ldsNodes = ctx->nodeletCount;
                 const size_t ldsQ = ctx->ldsBytes + size_t(ctx->nodeletCount)*64;
-                if (ctx->extendQueue == 8) { // queue form: eight (or four) rays per lane (kernels.h, k_extend_q)
+                if (ctx->extendQueue && ctx->extendPersistent) { // persistent lanes + per-wave buffers of finished rays behind the stacks (and nodelets)
+                    scq.ldsQueueWord = uint32_t(ldsQ/sizeof(uint32_t));
+                    const size_t ldsP = ldsQ + size_t(4)*TG_EXTP_BUF*sizeof(uint2);
+                    if (count) hipLaunchKernelGGL((k_extend_p<true>), dim3(grid), dim3(256), ldsP, stream, scq, st, cur);
+                    else hipLaunchKernelGGL((k_extend_p<false>), dim3(grid), dim3(256), ldsP, stream, scq, st, cur);
+                } else if (ctx->extendQueue == 8) { // queue form: eight (or four) rays per lane (kernels.h, k_extend_q)
                     if (count) hipLaunchKernelGGL((k_extend_q<true, 8>), dim3(grid), dim3(256), ldsQ, stream, scq, st, cur);
                     else hipLaunchKernelGGL((k_extend_q<false, 8>), dim3(grid), dim3(256), ldsQ, stream, scq, st, cur);
                 } else if (ctx->extendQueue) {

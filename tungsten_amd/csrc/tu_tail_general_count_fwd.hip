@@ -4,5 +4,5 @@
 #include "kernels.h"
 
 namespace tg {
-TG_KERNELS_TAIL(, false, false, false)
+TG_KERNELS_TAIL(, true, true, true)
 }

@@ -391,7 +391,10 @@ TG_DEV void aovFinish(const DScene &sc, const DState &st, uint32_t path, uint32_
 #ifndef TG_RETIRE_BLOCK
 #define TG_RETIRE_BLOCK 256
 #endif
-static __global__ void __launch_bounds__(TG_RETIRE_BLOCK) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
+#ifndef TG_RETIRE_WAVES
+#define TG_RETIRE_WAVES 5 /* waves per SIMD the retire kernel is compiled for (A/B: profiles/r02_ab_notes.txt) */
+#endif
+static __global__ void __launch_bounds__(TG_RETIRE_BLOCK, TG_RETIRE_WAVES) k_retire_regenerate(DScene sc, DState st, JobRing jobs, int set, unsigned long long sampleBase,
                                                             unsigned long long limit)
 {
     __shared__ uint32_t sWave[TG_RETIRE_BLOCK/64];
@@ -3005,7 +3008,10 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
 }
 
 template <int CLASS, bool MEDIA>
-__global__ void __launch_bounds__(256, 4) k_shade(DScene sc, DState st, int set)
+#ifndef TG_SHADE_WAVES
+#define TG_SHADE_WAVES 4 /* waves per SIMD the shade kernels are compiled for (A/B: profiles/r02_ab_notes.txt) */
+#endif
+__global__ void __launch_bounds__(256, TG_SHADE_WAVES) k_shade(DScene sc, DState st, int set)
 {
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + CLASS)];
     const uint32_t *list = st.lists[set][1 + CLASS];

@@ -269,15 +269,15 @@ def test_full_size_pass_properties(ta, oracle_py, gpu_ctx):
 
 
 def test_scheduling_choices_do_not_change_the_image(ta, gpu_ctx, monkeypatch):
-    """How rays are scheduled is a performance choice only: one ray per lane or a queue of 4 / 8 per lane (k_extend /
-    k_extend_q), NEE rays traced and resolved per vertex (k_shadow) or as a ray queue with the resolve in the retire kernel
+    """How rays are scheduled is a performance choice only: one ray per lane, a fixed queue of 4 / 8 per lane or persistent lanes (k_extend /
+    k_extend_q / k_extend_p), the BVH's memory layout, NEE rays traced and resolved per vertex (k_shadow) or as a ray queue with the resolve in the retire kernel
     (k_shadow_q), the top BVH levels staged in LDS or not, the BVH leaf limit, the pool size and the LDS share of the traversal stack must all give the bits of
     the default configuration (640x360, 8 spp of config 2)."""
     hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(640, 360))
     shard = ta.Shard(hs.res_x, hs.res_y)
 
     def render(env, max_paths=0):
-        for k in ("TGPU_EXTEND_Q", "TGPU_SHADOW_Q", "TGPU_BVH_LEAF", "TGPU_STACK_LDS", "TGPU_TAIL_MAX", "TGPU_LDS_NODELETS"):
+        for k in ("TGPU_EXTEND_P", "TGPU_EXTEND_Q", "TGPU_SHADOW_Q", "TGPU_BVH_LEAF", "TGPU_STACK_LDS", "TGPU_TAIL_MAX", "TGPU_LDS_NODELETS", "TGPU_BVH_BFS", "TGPU_BVH_ALIGN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -286,7 +286,8 @@ def test_scheduling_choices_do_not_change_the_image(ta, gpu_ctx, monkeypatch):
         return gpu_ctx.download()[0]
 
     base = render({})
-    for env, pool in [({"TGPU_EXTEND_Q": "0"}, 0), ({"TGPU_EXTEND_Q": "8"}, 0), ({"TGPU_BVH_LEAF": "4"}, 0),
+    for env, pool in [({"TGPU_EXTEND_Q": "0"}, 0), ({"TGPU_EXTEND_P": "0"}, 0), ({"TGPU_EXTEND_P": "0", "TGPU_EXTEND_Q": "8"}, 0), ({"TGPU_BVH_LEAF": "4"}, 0),
+                      ({"TGPU_BVH_BFS": "1", "TGPU_BVH_ALIGN": "1"}, 0), ({"TGPU_TAIL_MAX": "0"}, 3000),
                       ({"TGPU_SHADOW_Q": "0"}, 0), ({"TGPU_SHADOW_Q": "8", "TGPU_TAIL_MAX": "0"}, 30000),
                       ({"TGPU_LDS_NODELETS": "3"}, 0), ({"TGPU_LDS_NODELETS": "2", "TGPU_STACK_LDS": "12", "TGPU_TAIL_MAX": "0"}, 20000),
                       ({"TGPU_BVH_LEAF": "1", "TGPU_EXTEND_Q": "8"}, 50000), ({"TGPU_STACK_LDS": "3", "TGPU_TAIL_MAX": "0"}, 4096)]:

@@ -20,7 +20,9 @@ FIXTURES = [  # name, scene, resolution, spp, renderer overrides, integrator ove
     "transparency", "mixed", "dielectric_hg_medium", "sphere_disk")] + [
     # the remaining transmittance models of the fork (transmittances/TransmittanceFactory.cpp:14-24) in the Cornell box's camera medium
     (f"{n}_96x54_8spp", f"next/{n}.json", (96, 54), 8, {"adaptive_sampling": False}, {}) for n in (
-    "trans_erlang", "trans_davis", "trans_davis_weinstein", "trans_interpolated", "trans_interpolated2")]
+    "trans_erlang", "trans_davis", "trans_davis_weinstein", "trans_interpolated", "trans_interpolated2")] + [
+    # 8-bit PNG bitmaps (assets/next/textures/): gamma-corrected RGB albedo, palette albedo without interpolation (clamped, scaled), scalar roughness
+    ("ldr_texture_128x72_4spp", "next/ldr_texture.json", (128, 72), 4, {"adaptive_sampling": False}, {})]
 
 
 def main():

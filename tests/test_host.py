@@ -139,3 +139,95 @@ def test_reference_side_integrator_compiles_against_the_reference_headers():
         pytest.skip("no reference tree here")
     r = subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "-f", "Makefile.ref", "integration-check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _png_decode(path):
+    """Independent PNG decode (zlib + the five scanline filters) -> (h, w, 3) uint8 RGB and the colour type."""
+    import struct
+    import zlib
+    s = open(path, "rb").read()
+    o, idat, pal = 8, b"", None
+    while o < len(s):
+        n, = struct.unpack(">I", s[o:o + 4])
+        tag, data = s[o + 4:o + 8], s[o + 8:o + 8 + n]
+        o += 12 + n
+        if tag == b"IHDR":
+            w, h, depth, ct = struct.unpack(">IIBB", data[:10])
+        elif tag == b"PLTE":
+            pal = data
+        elif tag == b"IDAT":
+            idat += data
+    raw = zlib.decompress(idat)
+    bpp = {2: 3, 3: 1, 6: 4}[ct]
+    st = w*bpp
+    img = np.zeros((h, st), np.int32)
+    prev = [0]*st
+    for y in range(h):
+        f, row, cur = raw[y*(st + 1)], raw[y*(st + 1) + 1:(y + 1)*(st + 1)], [0]*st
+        for x in range(st):
+            a, b, c = (cur[x - bpp] if x >= bpp else 0), prev[x], (prev[x - bpp] if x >= bpp else 0)
+            q = a + b - c
+            pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+            pred = [0, a, b, (a + b) >> 1, a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)][f]
+            cur[x] = (row[x] + pred) & 255
+        img[y] = prev = cur
+    img = img.reshape(h, w, bpp)
+    if ct == 3:
+        img = np.frombuffer(pal, np.uint8).reshape(-1, 3)[img[:, :, 0]].astype(np.int32)
+    return img[:, :, :3]
+
+
+def test_png_bitmap_textures_expand_to_the_texels_the_reference_reads(ta):
+    """8-bit PNG bitmaps (io/ImageIO.cpp:386-407,496-526; textures/BitmapTexture.cpp:15-23,140-156,211-219): an RGB request goes through the
+    integer gamma table int(255*(i/255)^2.2) unless gamma_correct is off; a scalar (REQUEST_AVERAGE) request is the integer (r+g+b)/3 of the
+    uncorrected bytes; a texel is float(byte)*(1/255).  The files use colour types 2, 6 and 3, all five scanline filters, dynamic Huffman
+    blocks and split IDAT chunks; the decode is checked against zlib.  The rendered image is pinned by tests/test_oracle_golden.py."""
+    hs = ta.HostScene(scene_path("next/ldr_texture.json"), resolution=(32, 18))
+    d = hs.desc.contents
+    tex = os.path.join(REPO, "assets", "next", "textures")
+    gamma = np.array([int(255*(i/255)**2.2) for i in range(256)])
+    k = np.float32(1.0/255.0)
+    rough = _png_decode(os.path.join(tex, "rough.png"))
+    s = ((rough[:, :, 0] + rough[:, :, 1] + rough[:, :, 2])//3).astype(np.float32)*k
+    expect = {
+        (64, 48): (gamma[_png_decode(os.path.join(tex, "albedo.png"))].astype(np.float32)*k, 0, 1, 1.0),
+        (16, 16): (_png_decode(os.path.join(tex, "tiles.png")).astype(np.float32)*k, 1, 0, 0.8),
+        (32, 32): (np.stack([s, s, s], -1), 0, 1, 1.0),
+    }
+    seen = 0
+    for i in range(d.n_bitmaps):
+        b = d.bitmaps[i]
+        if (b.w, b.h) not in expect:
+            continue
+        texels, clamp, linear, scale = expect[(b.w, b.h)]
+        got = np.ctypeslib.as_array(b.texels, (b.h, b.w, 3))
+        assert (got == texels).all(), (b.w, b.h)
+        assert (b.clamp, b.linear) == (clamp, linear) and b.scale == np.float32(scale)
+        avg = np.zeros(3, np.float32)  # BitmapTexture::init: _avg += texel/float(w*h), row-major
+        for t in texels.reshape(-1, 3):
+            avg += t/np.float32(b.w*b.h)
+        assert (np.array(list(b.average), np.float32) == avg).all()
+        seen += 1
+    assert seen == 3
+
+
+def test_unsupported_bitmap_files_fail_loudly(ta, tmp_path):
+    d = json.load(open(scene_path("next/ldr_texture.json")))
+    bad = tmp_path/"broken.png"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0"*32)
+    d["bsdfs"][0]["albedo"] = str(bad)
+    for p in d["primitives"]:
+        if p.get("file"):
+            p["file"] = os.path.join(REPO, "assets", "next", p["file"])
+        if isinstance(p.get("emission"), str):
+            p["emission"] = os.path.join(REPO, "assets", "next", p["emission"])
+    for b in d["bsdfs"][1:]:
+        for key in ("albedo", "roughness"):
+            if isinstance(b.get(key), str):
+                b[key] = os.path.join(REPO, "assets", "next", b[key])
+            elif isinstance(b.get(key), dict) and "file" in b[key]:
+                b[key]["file"] = os.path.join(REPO, "assets", "next", b[key]["file"])
+    path = tmp_path/"scene.json"
+    path.write_text(json.dumps(d))
+    with pytest.raises(RuntimeError, match="Unable to load texture"):
+        ta.HostScene(str(path), resolution=(32, 18))

@@ -42,6 +42,8 @@ CASES = [
     ("trans_davis_weinstein_96x54_8spp", "next/trans_davis_weinstein.json", (96, 54), 8),
     ("trans_interpolated_96x54_8spp", "next/trans_interpolated.json", (96, 54), 8),    # linear (Dirac mediumMedium) + erlang
     ("trans_interpolated2_96x54_8spp", "next/trans_interpolated2.json", (96, 54), 8),  # exponential + davis
+    # 8-bit PNG bitmaps: gamma-table RGB albedo (interpolated, wrapped), palette albedo (nearest, clamped, scaled), scalar-average roughness
+    ("ldr_texture_128x72_4spp", "next/ldr_texture.json", (128, 72), 4),
 ]
 
 

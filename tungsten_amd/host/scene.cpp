@@ -306,6 +306,210 @@ bool loadPfm(const std::string &path, int &w, int &h, std::vector<float> &rgb)
     return ok;
 }
 
+// ---------------------------------------------------------------------------
+// PNG decoding (8-bit, non-interlaced: what texture files are; the reference goes through lodepng_decode_memory(..., LCT_RGBA, 8),
+// io/ImageIO.cpp:386-407): zlib inflate (stored, fixed and dynamic Huffman blocks) + the five scanline filters -> RGBA8
+// ---------------------------------------------------------------------------
+namespace {
+struct BitReader {
+    const uint8_t *p;
+    size_t n, pos = 0;
+    uint32_t bitBuf = 0;
+    int bitCnt = 0;
+    bool fail = false;
+    uint32_t bits(int k)
+    {
+        while (bitCnt < k) {
+            if (pos >= n) { fail = true; return 0; }
+            bitBuf |= uint32_t(p[pos++]) << bitCnt;
+            bitCnt += 8;
+        }
+        uint32_t v = bitBuf & ((k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u));
+        bitBuf >>= k;
+        bitCnt -= k;
+        return v;
+    }
+    void alignByte() { bitBuf = 0; bitCnt = 0; }
+};
+struct Huffman { // canonical code, decoded bit by bit (texture files are small)
+    uint16_t count[16] = {0}, symbol[320] = {0};
+    void build(const uint8_t *lengths, int n)
+    {
+        for (int i = 0; i < 16; ++i) count[i] = 0;
+        for (int i = 0; i < n; ++i) count[lengths[i]]++;
+        count[0] = 0;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int i = 1; i < 15; ++i) offs[i + 1] = uint16_t(offs[i] + count[i]);
+        for (int i = 0; i < n; ++i)
+            if (lengths[i]) symbol[offs[lengths[i]]++] = uint16_t(i);
+    }
+    int decode(BitReader &br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; ++len) {
+            code |= int(br.bits(1));
+            if (br.fail) return -1;
+            int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+bool inflateZlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
+{
+    if (in.size() < 6) return false;
+    BitReader br{in.data() + 2, in.size() - 2}; // skip the zlib header (CMF, FLG); the Adler checksum at the end is not verified
+    static const uint16_t lenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t distBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t distExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    bool last = false;
+    while (!last) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (br.fail) return false;
+        if (type == 0) {
+            br.alignByte();
+            if (br.pos + 4 > br.n) return false;
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8);
+            br.pos += 4;
+            if (br.pos + len > br.n) return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+            continue;
+        }
+        if (type == 3) return false;
+        Huffman lit, dist;
+        uint8_t lengths[320];
+        if (type == 1) {
+            for (int i = 0; i < 144; ++i) lengths[i] = 8;
+            for (int i = 144; i < 256; ++i) lengths[i] = 9;
+            for (int i = 256; i < 280; ++i) lengths[i] = 7;
+            for (int i = 280; i < 288; ++i) lengths[i] = 8;
+            lit.build(lengths, 288);
+            for (int i = 0; i < 30; ++i) lengths[i] = 5;
+            dist.build(lengths, 30);
+        } else {
+            const int nlen = int(br.bits(5)) + 257, ndist = int(br.bits(5)) + 1, ncode = int(br.bits(4)) + 4;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < ncode; ++i) cl[order[i]] = uint8_t(br.bits(3));
+            Huffman codeLen;
+            codeLen.build(cl, 19);
+            int i = 0;
+            while (i < nlen + ndist) {
+                int sym = codeLen.decode(br);
+                if (sym < 0 || br.fail) return false;
+                if (sym < 16) { lengths[i++] = uint8_t(sym); continue; }
+                int rep = 0;
+                uint8_t val = 0;
+                if (sym == 16) { if (i == 0) return false; val = lengths[i - 1]; rep = 3 + int(br.bits(2)); }
+                else if (sym == 17) rep = 3 + int(br.bits(3));
+                else rep = 11 + int(br.bits(7));
+                if (i + rep > nlen + ndist) return false;
+                while (rep--) lengths[i++] = val;
+            }
+            lit.build(lengths, nlen);
+            dist.build(lengths + nlen, ndist);
+        }
+        while (true) {
+            int sym = lit.decode(br);
+            if (sym < 0 || br.fail) return false;
+            if (sym < 256) { out.push_back(uint8_t(sym)); continue; }
+            if (sym == 256) break;
+            sym -= 257;
+            if (sym >= 29) return false;
+            const uint32_t len = lenBase[sym] + br.bits(lenExtra[sym]);
+            const int ds = dist.decode(br);
+            if (ds < 0 || ds >= 30) return false;
+            const uint32_t d = distBase[ds] + br.bits(distExtra[ds]);
+            if (br.fail || d > out.size()) return false;
+            const size_t from = out.size() - d;
+            for (uint32_t k = 0; k < len; ++k) out.push_back(out[from + k]);
+        }
+    }
+    return true;
+}
+} // namespace
+
+bool loadPng(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba)
+{
+    std::vector<uint8_t> file;
+    {
+        FILE *f = std::fopen(path.c_str(), "rb");
+        if (!f) return false;
+        uint8_t buf[65536];
+        size_t k;
+        while ((k = std::fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + k);
+        std::fclose(f);
+    }
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) return false;
+    auto be32 = [&](size_t o) { return (uint32_t(file[o]) << 24) | (uint32_t(file[o + 1]) << 16) | (uint32_t(file[o + 2]) << 8) | uint32_t(file[o + 3]); };
+    int depth = 0, colorType = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette, trns;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        const uint32_t len = be32(o);
+        const std::string tag(reinterpret_cast<const char *>(&file[o + 4]), 4);
+        if (o + 12 + len > file.size()) return false;
+        const uint8_t *d = &file[o + 8];
+        if (tag == "IHDR" && len >= 13) {
+            w = int(be32(o + 8)); h = int(be32(o + 12));
+            depth = d[8]; colorType = d[9]; interlace = d[12];
+        } else if (tag == "PLTE") palette.assign(d, d + len);
+        else if (tag == "tRNS") trns.assign(d, d + len);
+        else if (tag == "IDAT") idat.insert(idat.end(), d, d + len);
+        else if (tag == "IEND") break;
+        o += 12 + len;
+    }
+    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false; // 8-bit, non-interlaced files only
+    const int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
+    if (!channels) return false;
+    std::vector<uint8_t> raw;
+    if (!inflateZlib(idat, raw)) return false;
+    const size_t stride = size_t(w)*channels;
+    if (raw.size() < (stride + 1)*size_t(h)) return false;
+    std::vector<uint8_t> img(stride*h), zero(stride, 0);
+    for (int y = 0; y < h; ++y) { // PNG specification, section 9: filter types 0..4 on bytes, bpp = channels
+        const uint8_t *src = &raw[(stride + 1)*size_t(y)];
+        const int filter = src[0];
+        uint8_t *cur = &img[stride*y];
+        const uint8_t *up = y ? &img[stride*(y - 1)] : zero.data();
+        for (size_t x = 0; x < stride; ++x) {
+            const int a = x >= size_t(channels) ? cur[x - channels] : 0, b = up[x], c = x >= size_t(channels) ? up[x - channels] : 0;
+            int v = src[1 + x];
+            if (filter == 1) v += a;
+            else if (filter == 2) v += b;
+            else if (filter == 3) v += (a + b) >> 1;
+            else if (filter == 4) {
+                const int p0 = a + b - c, pa = std::abs(p0 - a), pb = std::abs(p0 - b), pc = std::abs(p0 - c);
+                v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            } else if (filter != 0) return false;
+            cur[x] = uint8_t(v);
+        }
+    }
+    rgba.resize(size_t(w)*h*4);
+    for (size_t i = 0; i < size_t(w)*h; ++i) {
+        uint8_t r, g, b, a = 255;
+        const uint8_t *p = &img[i*channels];
+        if (colorType == 0) { r = g = b = p[0]; }
+        else if (colorType == 2) { r = p[0]; g = p[1]; b = p[2]; }
+        else if (colorType == 3) {
+            if (size_t(p[0])*3 + 2 >= palette.size()) return false;
+            r = palette[p[0]*3]; g = palette[p[0]*3 + 1]; b = palette[p[0]*3 + 2];
+            if (p[0] < trns.size()) a = trns[p[0]];
+        } else if (colorType == 4) { r = g = b = p[0]; a = p[1]; }
+        else { r = p[0]; g = p[1]; b = p[2]; a = p[3]; }
+        rgba[i*4] = r; rgba[i*4 + 1] = g; rgba[i*4 + 2] = b; rgba[i*4 + 3] = a;
+    }
+    return true;
+}
+
 // PNG with stored (uncompressed) deflate blocks: enough for an output writer.
 bool savePng(const std::string &path, const uint8_t *rgb, int w, int h)
 {
@@ -396,40 +600,74 @@ void tonemapToLdr(const std::string &op, const float *rgb, int w, int h, std::ve
 // ---------------------------------------------------------------------------
 // JSON -> scene objects
 // ---------------------------------------------------------------------------
-int Scene::fetchTexture(const Json &v, bool /*scalarAverage*/) // Scene.cpp:127-151
+// One bitmap texture, expanded to float RGB texels exactly as BitmapTexture::getRgb/getScalar would return them
+// (textures/BitmapTexture.cpp:140-156), so the device lookup needs no texel types:
+//  * HDR files (.hdr, .pfm) stay float; a scalar request averages (r + g + b)/3 in float (io/ImageIO.cpp:173-187,298-365);
+//  * LDR files (.png) are RGBA8: an RGB request runs R, G, B through the integer gamma table when gamma_correct is set
+//    (ImageIO.cpp:26-43,507-519: entry i = int(255*(i/255)^2.2)), a scalar request takes the integer (r + g + b)/3 of the
+//    uncorrected bytes (:520-523); either way a texel is float(byte)*(1/255) (BitmapTexture.cpp:15-23,140-146).
+// A scalar texture is stored as (s, s, s): operator[] returns Vec3f(scalar) (BitmapTexture.cpp:323-351).
+int Scene::fetchBitmap(const std::string &path, bool scalarAverage, bool gammaCorrect, bool linear, bool clamp, float scale)
+{
+    std::string full = path.size() && path[0] == '/' ? path : sceneDir + "/" + path;
+    char keyTail[96];
+    std::snprintf(keyTail, sizeof(keyTail), "|%d%d%d%d|%a", int(scalarAverage), int(gammaCorrect), int(linear), int(clamp), double(scale));
+    const std::string key = full + keyTail;
+    for (size_t i = 0; i < _bitmapPaths.size(); ++i)
+        if (_bitmapPaths[i] == key) return int(i);
+
+    int w = 0, h = 0;
+    std::vector<float> texels;
+    const bool isHdr = endsWith(full, ".hdr") || endsWith(full, ".pfm");
+    if (isHdr) {
+        const bool ok = endsWith(full, ".hdr") ? loadRadianceHdr(full, w, h, texels) : loadPfm(full, w, h, texels);
+        if (!ok) throw std::runtime_error("Unable to load texture at '" + full + "'");
+        if (scalarAverage)
+            for (size_t i = 0; i < size_t(w)*h; ++i) {
+                const float s = (texels[i*3] + texels[i*3 + 1] + texels[i*3 + 2])/3;
+                texels[i*3] = texels[i*3 + 1] = texels[i*3 + 2] = s;
+            }
+    } else if (endsWith(full, ".png")) {
+        std::vector<uint8_t> rgba;
+        if (!loadPng(full, w, h, rgba))
+            throw std::runtime_error("Unable to load texture at '" + full + "' (8-bit non-interlaced PNG expected)");
+        uint8_t gamma[256];
+        for (int i = 0; i < 256; ++i) gamma[i] = gammaCorrect ? uint8_t(int(255.0*std::pow(i/255.0, 2.2))) : uint8_t(i);
+        texels.resize(size_t(w)*h*3);
+        for (size_t i = 0; i < size_t(w)*h; ++i) {
+            if (scalarAverage) {
+                const int s = (int(rgba[i*4]) + int(rgba[i*4 + 1]) + int(rgba[i*4 + 2]))/3;
+                texels[i*3] = texels[i*3 + 1] = texels[i*3 + 2] = float(uint8_t(s))*(1.0f/255.0f);
+            } else {
+                for (int k = 0; k < 3; ++k) texels[i*3 + k] = float(gamma[rgba[i*4 + k]])*(1.0f/255.0f);
+            }
+        }
+    } else {
+        throw std::runtime_error("Unable to load texture at '" + full + "' (.hdr, .pfm and .png bitmaps are in scope)");
+    }
+    tgpu_bitmap bm{};
+    bm.w = w; bm.h = h; bm.clamp = clamp ? 1 : 0; bm.linear = linear ? 1 : 0; bm.scale = scale; bm.texels = nullptr;
+    { // BitmapTexture::init (:183-207): _avg += getRgb(x, y)/float(_w*_h), rows top to bottom (average() = _scale*_avg is applied by the consumers)
+        float avg[3] = {0.0f, 0.0f, 0.0f};
+        const float n = float(w*h);
+        for (size_t i = 0; i < size_t(w)*h; ++i)
+            for (int k = 0; k < 3; ++k) avg[k] += texels[i*3 + k]/n;
+        for (int k = 0; k < 3; ++k) bm.average[k] = avg[k];
+    }
+    _bitmaps.push_back(bm);
+    _bitmapTexels.push_back(std::move(texels));
+    _bitmapPaths.push_back(key);
+    return int(_bitmaps.size()) - 1;
+}
+
+int Scene::fetchTexture(const Json &v, bool scalarAverage) // Scene.cpp:127-151
 {
     tgpu_texture t{};
     t.bitmap = -1;
     if (v.isString()) {
         // TextureCache.hpp:32-33: gammaCorrect = true, linear = true, clamp = false
-        std::string path = v.asString();
-        std::string full = path.size() && path[0] == '/' ? path : sceneDir + "/" + path;
-        for (size_t i = 0; i < _bitmapPaths.size(); ++i) {
-            if (_bitmapPaths[i] == full) {
-                t.type = TGPU_TEX_BITMAP;
-                t.bitmap = int(i);
-                _textures.push_back(t);
-                return int(_textures.size()) - 1;
-            }
-        }
-        int w = 0, h = 0;
-        std::vector<float> texels;
-        if (!(endsWith(full, ".hdr") && loadRadianceHdr(full, w, h, texels)))
-            throw std::runtime_error("Unable to load texture at '" + full + "' (only Radiance .hdr bitmaps are in scope)");
-        tgpu_bitmap bm{};
-        bm.w = w; bm.h = h; bm.clamp = 0; bm.linear = 1; bm.scale = 1.0f; bm.texels = nullptr;
-        { // BitmapTexture::init (:183-193): _avg += getRgb(x, y)/float(_w*_h), rows top to bottom
-            float avg[3] = {0.0f, 0.0f, 0.0f};
-            const float n = float(w*h);
-            for (size_t i = 0; i < size_t(w)*h; ++i)
-                for (int k = 0; k < 3; ++k) avg[k] += texels[i*3 + k]/n;
-            for (int k = 0; k < 3; ++k) bm.average[k] = avg[k];
-        }
-        _bitmaps.push_back(bm);
-        _bitmapTexels.push_back(std::move(texels));
-        _bitmapPaths.push_back(full);
         t.type = TGPU_TEX_BITMAP;
-        t.bitmap = int(_bitmaps.size()) - 1;
+        t.bitmap = fetchBitmap(v.asString(), scalarAverage, true, true, false, 1.0f);
     } else if (v.isNumber()) {
         t.type = TGPU_TEX_CONSTANT;
         t.value[0] = t.value[1] = t.value[2] = v.asFloat();
@@ -450,6 +688,16 @@ int Scene::fetchTexture(const Json &v, bool /*scalarAverage*/) // Scene.cpp:127-
         } else if (type == "constant") {
             t.type = TGPU_TEX_CONSTANT;
             v.getVec("value", t.value, 3);
+        } else if (type == "bitmap") { // BitmapTexture::fromJson (textures/BitmapTexture.cpp:211-219)
+            bool gammaCorrect = true, linear = true, clamp = false;
+            float scale = 1.0f;
+            v.getField("gamma_correct", gammaCorrect);
+            v.getField("interpolate", linear);
+            v.getField("clamp", clamp);
+            v.getField("scale", scale);
+            if (!v["file"]) throw std::runtime_error("bitmap texture without a \"file\"");
+            t.type = TGPU_TEX_BITMAP;
+            t.bitmap = fetchBitmap(v["file"].asString(), scalarAverage, gammaCorrect, linear, clamp, scale);
         } else {
             throw std::runtime_error("Texture type '" + type + "' is outside the hot-path scope");
         }
@@ -551,8 +799,11 @@ int Scene::parseBsdf(const Json &v)
                 b.roughness_tex = fetchTexture(r, true);
             }
             const tgpu_texture &at = _textures[size_t(b.albedo_tex)];
-            if (at.type != TGPU_TEX_CONSTANT) throw std::runtime_error("rough_plastic with a textured albedo is outside the hot-path scope");
-            float sum = at.value[0]; sum += at.value[1]; sum += at.value[2]; // ConstantTexture::average() = _value, Vec::avg()
+            float avg[3]; // Texture::average(): ConstantTexture = _value, BitmapTexture = _scale*_avg (BitmapTexture.cpp:281-284)
+            if (at.type == TGPU_TEX_CONSTANT) for (int k = 0; k < 3; ++k) avg[k] = at.value[k];
+            else if (at.type == TGPU_TEX_BITMAP) for (int k = 0; k < 3; ++k) avg[k] = _bitmaps[size_t(at.bitmap)].scale*_bitmaps[size_t(at.bitmap)].average[k];
+            else throw std::runtime_error("rough_plastic with a procedural albedo is outside the hot-path scope");
+            float sum = avg[0]; sum += avg[1]; sum += avg[2]; // Vec::avg()
             b.substrate_weight = sum*(1.0f/3.0f);
         }
     } else if (type == "oren_nayar") { // OrenNayarBsdf.cpp:14-31 (roughness default 1)

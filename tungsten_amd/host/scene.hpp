@@ -85,6 +85,7 @@ public:
 private:
     int fetchBsdf(const Json &v);
     int fetchTexture(const Json &v, bool scalarAverage);
+    int fetchBitmap(const std::string &path, bool scalarAverage, bool gammaCorrect, bool linear, bool clamp, float scale);
     int parseBsdf(const Json &v);
     void parsePrimitive(const Json &v);
     void parseCamera(const Json &v);
@@ -187,6 +188,8 @@ bool loadRadianceHdr(const std::string &path, int &w, int &h, std::vector<float>
 bool savePfm(const std::string &path, const float *img, int w, int h, int channels = 3);
 bool loadPfm(const std::string &path, int &w, int &h, std::vector<float> &rgb);
 bool savePng(const std::string &path, const uint8_t *rgb, int w, int h);
+// 8-bit, non-interlaced PNG -> RGBA8 (what lodepng_decode_memory(..., LCT_RGBA, 8) returns for such files, io/ImageIO.cpp:386-407)
+bool loadPng(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba);
 // Camera::tonemap + LDR quantisation (Tonemap.hpp:25-48, Integrator.cpp:56-80)
 void tonemapToLdr(const std::string &op, const float *rgb, int w, int h, std::vector<uint8_t> &ldr);
 

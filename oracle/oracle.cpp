@@ -159,9 +159,10 @@ struct Sampler { // sampling/SobolPathSampler.hpp:20-84 and sampling/UniformPath
         index = sample;
         dimension = 0;
     }
-    bool nextBoolean(float pTrue) { return supplemental->next1D() < pTrue; }
-    int nextDiscrete(int numChoices) { return int(supplemental->next1D()*float(numChoices)); }
-    float next1D()
+    bool nextBoolean(float pTrue) { bool r = supplemental->next1D() < pTrue; TRC("    rnd bool(%08x)=%d\n", hx(pTrue), int(r)); return r; }
+    int nextDiscrete(int numChoices) { int r = int(supplemental->next1D()*float(numChoices)); TRC("    rnd disc(%d)=%d\n", numChoices, r); return r; }
+    float next1D() { float r = next1Dq(); TRC("    rnd 1d=%08x\n", hx(r)); return r; }
+    float next1Dq()
     {
         if (!sobol || dimension >= 1024) return supplemental->next1D();
         // thirdparty/sobol/sobol.h:40-53 (only the first 32 columns are reachable with a 32-bit index)
@@ -349,6 +350,7 @@ struct oracle_ctx {
     uint32_t expTable[1024];
     float expA, expB;
     void buildExpTable();
+    bool coplanarTieGoesToCube(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const;
     bool handleSurface(Event &event, Temp &data, Info &info, int &medium, int bounce, bool enableLightSampling, Ray &ray,
                        V3 &throughput, V3 &emission, bool &wasSpecular, struct MediumStateO &state, Counters &c, V3 *transmittance = nullptr) const;
     V3 traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c, struct AovSample *aov = nullptr) const;
@@ -1265,6 +1267,41 @@ bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Coun
     return hit;
 }
 
+#if defined(__SSE__)
+// Reference mode only (rcp_mode = 1).  A ray that reaches a Quad and a Cube face at the SAME binary32 distance -- the Cornell boxes stand on the
+// floor quad, so every path that wanders below the floor in a camera medium can do this -- is not decided by the primitives' own tests
+// (Quad.cpp:78 keeps t <= farT, Cube.cpp:115 wants ttMin < farT: the quad wins whichever is tested first) but by Embree: the user geometries
+// sit in a BVH4 with one primitive per leaf, the cube's leaf is visited first, its hit shortens the ray, and the quad's leaf is then skipped when
+// the entry distance of ITS box, computed with Embree's reciprocal (rcp_ps + one Newton step), exceeds the new tfar
+// (thirdparty/embree/kernels/bvh/bvh_intersector_node.h:162-190, common/math/vec3fa.h:124-145, constants.h:30).  Found with a driver linked
+// against the compiled reference (tests/tools/ref_path_dump.cpp); with this rule the three transmittance fixtures that had a one-tile residual
+// are reproduced bit for bit in every pixel.  The GPU contract (rcp_mode = 0) is the primitive-level outcome: the quad wins a tie.
+bool oracle_ctx::coplanarTieGoesToCube(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const
+{
+    Ray r2 = ray;
+    r2.farT = nextafterf(ray.farT, INFINITY);
+    Temp d2 = data;
+    cubeIntersect(cb, idx, r2, d2);
+    if (!(d2.kind == PRIM_CUBE && r2.farT == ray.farT)) return false;
+    const tgpu_quad &q = sc.quads[data.index];
+    V3 c0(q.base), c1 = V3(q.base) + V3(q.edge0), c2 = V3(q.base) + V3(q.edge1), c3 = V3(q.base) + V3(q.edge0) + V3(q.edge1); // Quad::bounds (Quad.cpp:281-289)
+    float tNear = ray.nearT;
+    for (int k = 0; k < 3; ++k) {
+        float lo = std::min(std::min(c0[k], c1[k]), std::min(c2[k], c3[k])), hi = std::max(std::max(c0[k], c1[k]), std::max(c2[k], c3[k]));
+        float a = ray.dir[k];
+        if (std::abs(a) < 1e-18f) a = 1e-18f; // zero_fix
+        float r = _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(a)));
+        float rdir = r*(2.0f - r*a);
+        float tn = ((rdir >= 0.0f ? lo : hi) - ray.pos[k])*rdir;
+        if (tn > tNear) tNear = tn;
+    }
+    if (!(tNear > ray.farT)) return false;
+    data = d2;
+    data.inst = data.instSet = -1;
+    return true;
+}
+#endif
+
 bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const // renderer/TraceableScene.hpp:170-192
 {
     info.kind = PRIM_NONE;
@@ -1278,6 +1315,9 @@ bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const 
         if (quadIntersect(sc.quads[i], i, ray, data)) data.inst = data.instSet = -1;
     for (uint32_t i = 0; i < sc.n_cubes; ++i) {
         float before = ray.farT;
+#if defined(__SSE__)
+        if (rcpMode && data.kind == PRIM_QUAD && coplanarTieGoesToCube(sc.cubes[i], i, ray, data)) continue;
+#endif
         cubeIntersect(sc.cubes[i], i, ray, data);
         if (ray.farT != before) data.inst = data.instSet = -1;
     }

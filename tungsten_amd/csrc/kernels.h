@@ -400,6 +400,7 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK, TG_RETIRE_WAVES) k_ret
     __shared__ uint32_t sWave[TG_RETIRE_BLOCK/64];
     __shared__ uint32_t sHist[TG_RING];
     __shared__ uint32_t sBase;
+    __shared__ uint2 sQueue[TG_RETIRE_BLOCK/64][128]; // per wave: (list entry, rank of its claim) of the entries that need work
     const ListCounts lc = loadListCounts(st, set);
     const uint32_t total = listTotal(lc, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -424,38 +425,46 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK, TG_RETIRE_WAVES) k_ret
         sBase = sum ? atomicAdd(&st.counters[CNT(CNT_REGEN)], sum) : 0u;
     }
     __syncthreads();
-    unsigned long long next = sampleBase + sBase + sWave[wave]; // the wave's claims, in the order pass 2 meets them
-    // pass 2
-    for (uint32_t q0 = first; q0 < total; q0 += stride) {
-        const uint32_t q = q0 + uint32_t(lane);
+    const unsigned long long waveBase = sampleBase + sBase + sWave[wave]; // the wave's claims, in the order pass 2 meets them
+    // pass 2.  Only the entries that need work (escaped or ended paths: about a third of the lists) cost more than their end-state byte, so the
+    // wave first packs them -- (entry, rank of its claim) -- into a small LDS queue and then works on 64 of them at a time with every lane busy:
+    // twice the loads in flight per wave of a kernel that waits on memory for two thirds of its cycles (profiles/r02_sq_summary.txt).
+    uint2 *queue = sQueue[wave];
+    uint32_t queued = 0, claimed = 0; // wave-uniform
+    auto work = [&](uint32_t count) { // the first `count` (<= 64) queue entries, one per lane
         uint32_t slot = 0, ring = 0xFFFFFFFFu;
-        const bool have = q < total && listFetch(st, lc, set, 0, q, slot);
         bool needs = false;
-        if (have) {
-            int end;
-            V3 c(0.0f);
-            float tpSum = 0.0f;
-            if (q < lc.n[0]) {
-                // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so
-                // that their record is read and written once, not by a miss kernel first and by this one again
-                end = missPathEx(sc, st, slot, c, tpSum);
-            } else {
-                end = int(endFlag[q]); // END_* of the entry, written by its shade / volume step
-                if (end != END_ALIVE && end != END_DEAD) { // a path that goes on is left alone: its NEE terms ride with its next vertex
-                    c = xyz(st.em[slot]);
-                    if (stateNee(st.state[slot])) c = resolveNeeTerms(st, slot, c);
-                    if (end == END_CHECKED) tpSum = st.tpSum[slot];
+        unsigned long long g = 0;
+        if (uint32_t(lane) < count) {
+            const uint2 e = queue[lane];
+            const uint32_t q = e.x;
+            g = waveBase + e.y;
+            if (listFetch(st, lc, set, 0, q, slot)) {
+                int end;
+                V3 c(0.0f);
+                float tpSum = 0.0f;
+                if (q < lc.n[0]) {
+                    // entries of list 0 are the paths that left the scene: their environment lookup (K5 miss) happens here, so
+                    // that their record is read and written once, not by a miss kernel first and by this one again
+                    end = missPathEx(sc, st, slot, c, tpSum);
+                } else {
+                    end = int(endFlag[q]); // END_* of the entry, written by its shade / volume step
+                    if (end != END_DEAD) { // (END_ALIVE entries are not queued: their NEE terms ride with their next vertex)
+                        c = xyz(st.em[slot]);
+                        if (stateNee(st.state[slot])) c = resolveNeeTerms(st, slot, c);
+                        if (end == END_CHECKED) tpSum = st.tpSum[slot];
+                    }
                 }
-            }
-            if (end != END_ALIVE) {
-                needs = true;
-                if (end != END_DEAD) {
-                    const bool nanEnd = end == END_CHECKED && isnanf_(tpSum + c.sum()); // PathTracer.cpp:130-131
-                    if (end == END_ZERO || nanEnd) c = V3(0.0f);
-                    uint32_t ref = st.sampleRef[slot];
-                    if (st.aov0) aovFinish(sc, st, slot, ref, end == END_CHECKED && !nanEnd);
-                    st.results[ref] = mk4(c, 0.0f);
-                    ring = ref/st.resultSlice;
+                if (end != END_ALIVE) {
+                    needs = true;
+                    if (end != END_DEAD) {
+                        const bool nanEnd = end == END_CHECKED && isnanf_(tpSum + c.sum()); // PathTracer.cpp:130-131
+                        if (end == END_ZERO || nanEnd) c = V3(0.0f);
+                        uint32_t ref = st.sampleRef[slot];
+                        if (st.aov0) aovFinish(sc, st, slot, ref, end == END_CHECKED && !nanEnd);
+                        st.results[ref] = mk4(c, 0.0f);
+                        ring = ref/st.resultSlice;
+                    }
                 }
             }
         }
@@ -467,9 +476,7 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK, TG_RETIRE_WAVES) k_ret
             if (lane == leader) atomicAdd(&sHist[r], uint32_t(__builtin_popcountll(m)));
             todo &= ~m;
         }
-        const unsigned long long asking = __ballot(needs);
         if (needs) {
-            const unsigned long long g = next + uint32_t(__builtin_popcountll(asking & below));
             if (g < limit) {
                 startSample(sc, st, jobs, g, slot);
             } else { // idle: the next extend drops the slot onto the free list (it reads tp.w)
@@ -477,8 +484,25 @@ static __global__ void __launch_bounds__(TG_RETIRE_BLOCK, TG_RETIRE_WAVES) k_ret
                 st.state[slot] = packState(false, END_DEAD);
             }
         }
-        next += uint32_t(__builtin_popcountll(asking));
+        // close the gap: what is left moves to the front of the queue
+        uint2 rest = make_uint2(0u, 0u);
+        const bool moves = count + uint32_t(lane) < queued;
+        if (moves) rest = queue[count + uint32_t(lane)];
+        if (moves) queue[lane] = rest;
+        queued -= count;
+    };
+    for (uint32_t q0 = first; q0 < total; q0 += stride) {
+        const uint32_t q = q0 + uint32_t(lane);
+        const bool need = q < total && (q < lc.n[0] || endFlag[q] != END_ALIVE);
+        const unsigned long long m = __ballot(need);
+        const uint32_t rank = uint32_t(__builtin_popcountll(m & below));
+        if (need) queue[queued + rank] = make_uint2(q, claimed + rank); // the claim order of pass 1: by entry
+        const uint32_t n = uint32_t(__builtin_popcountll(m));
+        queued += n;
+        claimed += n;
+        if (queued >= 64u) work(64u);
     }
+    if (queued) work(queued);
     __syncthreads();
     if (threadIdx.x < TG_RING && sHist[threadIdx.x]) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + threadIdx.x)], sHist[threadIdx.x]);
 }

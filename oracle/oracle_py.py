@@ -54,7 +54,7 @@ def lib():
 
 
 REF = dict(rng=0, math=0, rcp=0)        # the reference's behaviour (tile-sequential PCG, glibc libm)
-REF_RCP = dict(rng=0, math=0, rcp=1)    # + Embree's RCPPS-based rcp() (x86 only)
+REF_RCP = dict(rng=0, math=0, rcp=1)    # + Embree's RCPPS-based rcp() (x86 only): triangle t,u,v and the node test that decides coplanar quad/cube ties
 GPU = dict(rng=1, math=1, rcp=0)        # what the HIP core computes (path-local PCG, tgpu_math.h)
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGPU_ABI_VERSION 3
+#define TGPU_ABI_VERSION 4
 
 typedef enum tgpu_status {
     TGPU_OK = 0,
@@ -298,6 +298,14 @@ typedef struct tgpu_scene_desc {
     const int32_t *tri_bsdf;    /* n_tris   : index into bsdfs                */
     const uint8_t *tri_smooth;  /* n_tris   : mesh "smooth" flag              */
     const int16_t *tri_media;   /* n_tris*2 : int_medium, ext_medium of the mesh, -1 = none; NULL = no media */
+    /* the meshes the soup was baked from, as Primitives: mesh m owns triangles
+     * [mesh_first_tri[m], mesh_first_tri[m+1]); mesh_bounds = TriangleMesh::bounds()
+     * over EVERY vertex, referenced or not (TriangleMesh.cpp:233-239,519-522).
+     * Descriptive: the traversal kernels work on the soup; the oracle's reference
+     * mode and a per-mesh BVH build need the grouping.                          */
+    uint32_t        n_meshes;
+    const uint32_t *mesh_first_tri; /* n_meshes + 1                            */
+    const float    *mesh_bounds;    /* n_meshes*6 : min xyz, max xyz           */
 
     uint32_t         n_quads;   const tgpu_quad    *quads;
     uint32_t         n_cubes;   const tgpu_cube    *cubes;

@@ -6,6 +6,7 @@
 // reference's operation order; build with -ffp-contract=off (the reference
 // build has no FMA contraction).
 #include "oracle.h"
+#include "embree_bvh4.h"
 #include "../include/tgpu_math.h"
 #include "../include/tgpu_bounds.h"
 
@@ -34,7 +35,11 @@ constexpr float INV_FOUR_PI = 0.25f*INV_PI;
 const float INF = std::numeric_limits<float>::infinity();
 // Path tracing of ONE sample to stderr (ORACLE_TRACE=1): every vertex with the bits of ray, hit, throughput, radiance and
 // sampler state, to be diffed against the GPU's slot dump (TGPU_TRACE_SLOTS=1); tests/tools/trace_path.py drives both.
-static const bool g_trace = std::getenv("ORACLE_TRACE") != nullptr;
+static bool g_trace = std::getenv("ORACLE_TRACE") != nullptr;
+// ORACLE_TRACE_AT="pixelIndex:sample": oracle_render_image traces only that sample (run with one thread); ORACLE_DUMP_TILE=t: prints the
+// radiance bits of every sample of tile t in rendering order ("S pixelIndex sample r g b"), to be diffed against tests/tools/ref_path_dump.cpp
+static const char *g_traceAt = std::getenv("ORACLE_TRACE_AT");
+static const char *g_dumpTile = std::getenv("ORACLE_DUMP_TILE");
 // ORACLE_BRUTE=1: triangle queries test EVERY triangle (no BVH pruning) -- the definition the BVH walk must reproduce:
 // lexicographic minimum of (t, triangle id) over all triangles whose test passes.  Minutes per image; for single-path diagnosis.
 static const bool g_brute = std::getenv("ORACLE_BRUTE") != nullptr;
@@ -350,7 +355,15 @@ struct oracle_ctx {
     uint32_t expTable[1024];
     float expA, expB;
     void buildExpTable();
-    bool coplanarTieGoesToCube(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const;
+    // reference mode (rcp_mode = 1): the reference's two levels of Embree BVH4, restated (oracle/embree_bvh4.h)
+    struct RefFinite { int kind; uint32_t index; };
+    std::vector<RefFinite> refFinites;                 // the primitives of TraceableScene's user geometry
+    embree_restated::Bvh4 refTop;                      // BVH4 over their Primitive::bounds()
+    std::vector<embree_restated::Bvh4> refMesh;        // per mesh: BVH4 with Triangle4 leaves, primitive ids local to the mesh
+    bool refAccel = false;
+    void buildReferenceAccel();
+    bool refMeshIntersect(uint32_t mesh, Ray &ray, Temp &data, Counters &c) const;
+    void refIntersect(Ray &ray, Temp &data, Counters &c) const;
     bool handleSurface(Event &event, Temp &data, Info &info, int &medium, int bounce, bool enableLightSampling, Ray &ray,
                        V3 &throughput, V3 &emission, bool &wasSpecular, struct MediumStateO &state, Counters &c, V3 *transmittance = nullptr) const;
     V3 traceSample(uint32_t px, uint32_t py, Sampler &sampler, Counters &c, struct AovSample *aov = nullptr) const;
@@ -1267,40 +1280,150 @@ bool oracle_ctx::instanceIntersect(uint32_t setIndex, Ray &ray, Temp &data, Coun
     return hit;
 }
 
-#if defined(__SSE__)
-// Reference mode only (rcp_mode = 1).  A ray that reaches a Quad and a Cube face at the SAME binary32 distance -- the Cornell boxes stand on the
-// floor quad, so every path that wanders below the floor in a camera medium can do this -- is not decided by the primitives' own tests
-// (Quad.cpp:78 keeps t <= farT, Cube.cpp:115 wants ttMin < farT: the quad wins whichever is tested first) but by Embree: the user geometries
-// sit in a BVH4 with one primitive per leaf, the cube's leaf is visited first, its hit shortens the ray, and the quad's leaf is then skipped when
-// the entry distance of ITS box, computed with Embree's reciprocal (rcp_ps + one Newton step), exceeds the new tfar
-// (thirdparty/embree/kernels/bvh/bvh_intersector_node.h:162-190, common/math/vec3fa.h:124-145, constants.h:30).  Found with a driver linked
-// against the compiled reference (tests/tools/ref_path_dump.cpp); with this rule the three transmittance fixtures that had a one-tile residual
-// are reproduced bit for bit in every pixel.  The GPU contract (rcp_mode = 0) is the primitive-level outcome: the quad wins a tie.
-bool oracle_ctx::coplanarTieGoesToCube(const tgpu_cube &cb, uint32_t idx, Ray &ray, Temp &data) const
+// Reference mode only (rcp_mode = 1): which primitive TraceableScene::intersect reports is decided by Embree wherever binary32 leaves room, and the
+// oracle restates Embree for it (oracle/embree_bvh4.h; pinned by tests/golden/ref_kat5.npz against the compiled library).  The scene's finites are the
+// primitives of ONE user geometry in a BVH4 with one primitive per leaf (renderer/TraceableScene.hpp:107-129); Primitive::intersect is only called for
+// leaves the traversal reaches, with the ray interval the traversal has at that moment:
+//   * a ray leaving the Cornell box through the edge between the ceiling quad and a wall can pass the ceiling's own test (Quad.cpp:71-98, u = 3e-8)
+//     and miss the ceiling's flat box by one ulp of Embree's slab arithmetic -> the reference returns the wall, 3 ulp farther
+//     (cornell-box/scene_sobol.json at 96x54, pixel (67,7) sample 41);
+//   * two quads reached at the SAME binary32 distance (floor / wall edge): Quad.cpp:78 keeps t <= farT, so the leaf visited LAST wins unless its
+//     box is culled against the shortened ray (64x36, pixel (47,33) sample 15);
+//   * a quad and a cube face at the same distance (boxes standing on the floor): Cube.cpp:115 wants ttMin < farT, so the cube only wins when its
+//     leaf comes first and the quad's box is then culled.
+// Each TriangleMesh is one such primitive and owns a second BVH4 over its triangles (TriangleMesh.cpp:531-566) with Triangle4 leaves: four triangles
+// are tested at once, the smallest t of a block wins (lowest lane on a tie), and a later block must pass T < |den|*tfar -- first found keeps a tie.
+// The GPU contract (rcp_mode = 0) is tree-free: the primitive's own test, nearest hit = min (t, id).
+void oracle_ctx::buildReferenceAccel()
 {
-    Ray r2 = ray;
-    r2.farT = nextafterf(ray.farT, INFINITY);
-    Temp d2 = data;
-    cubeIntersect(cb, idx, r2, d2);
-    if (!(d2.kind == PRIM_CUBE && r2.farT == ray.farT)) return false;
-    const tgpu_quad &q = sc.quads[data.index];
-    V3 c0(q.base), c1 = V3(q.base) + V3(q.edge0), c2 = V3(q.base) + V3(q.edge1), c3 = V3(q.base) + V3(q.edge0) + V3(q.edge1); // Quad::bounds (Quad.cpp:281-289)
-    float tNear = ray.nearT;
-    for (int k = 0; k < 3; ++k) {
-        float lo = std::min(std::min(c0[k], c1[k]), std::min(c2[k], c3[k])), hi = std::max(std::max(c0[k], c1[k]), std::max(c2[k], c3[k]));
-        float a = ray.dir[k];
-        if (std::abs(a) < 1e-18f) a = 1e-18f; // zero_fix
-        float r = _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(a)));
-        float rdir = r*(2.0f - r*a);
-        float tn = ((rdir >= 0.0f ? lo : hi) - ray.pos[k])*rdir;
-        if (tn > tNear) tNear = tn;
+    refAccel = false;
+#if defined(__SSE__)
+    if (!rcpMode) return;
+    using embree_restated::Box;
+    std::vector<Box> boxes;
+    auto grow = [](Box &b, const V3 &p) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], p[k]); b.hi[k] = std::max(b.hi[k], p[k]); } };
+    for (uint32_t i = 0; i < sc.n_instance_sets; ++i) { // Instance::bounds (Instance.cpp:380-383)
+        Box b;
+        for (int k = 0; k < 3; ++k) { b.lo[k] = inst->sets[i].bounds.lo[k]; b.hi[k] = inst->sets[i].bounds.hi[k]; }
+        boxes.push_back(b);
+        refFinites.push_back(RefFinite{PRIM_INSTANCE, i});
     }
-    if (!(tNear > ray.farT)) return false;
-    data = d2;
+    for (uint32_t i = 0; i < sc.n_quads; ++i) { // Quad::bounds (Quad.cpp:281-289)
+        const tgpu_quad &q = sc.quads[i];
+        Box b = embree_restated::emptyBox();
+        grow(b, V3(q.base)); grow(b, V3(q.base) + V3(q.edge0)); grow(b, V3(q.base) + V3(q.edge1)); grow(b, V3(q.base) + V3(q.edge0) + V3(q.edge1));
+        boxes.push_back(b);
+        refFinites.push_back(RefFinite{PRIM_QUAD, i});
+    }
+    for (uint32_t i = 0; i < sc.n_cubes; ++i) { // Cube::bounds (Cube.cpp:333-344)
+        const tgpu_cube &cb = sc.cubes[i];
+        Box b = embree_restated::emptyBox();
+        for (int c = 0; c < 8; ++c)
+            grow(b, V3(cb.pos) + mulPoint0(cb.rot, V3(c & 1 ? cb.scale[0] : -cb.scale[0], c & 2 ? cb.scale[1] : -cb.scale[1], c & 4 ? cb.scale[2] : -cb.scale[2])));
+        boxes.push_back(b);
+        refFinites.push_back(RefFinite{PRIM_CUBE, i});
+    }
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) { // Sphere::bounds (Sphere.cpp:273-276)
+        const tgpu_sphere &sp = sc.spheres[i];
+        Box b;
+        for (int k = 0; k < 3; ++k) { b.lo[k] = sp.pos[k] - sp.radius; b.hi[k] = sp.pos[k] + sp.radius; }
+        boxes.push_back(b);
+        refFinites.push_back(RefFinite{PRIM_SPHERE, i});
+    }
+    for (uint32_t i = 0; i < sc.n_disks; ++i) { // Disk::bounds (Disk.cpp:298-306)
+        const tgpu_disk &dk = sc.disks[i];
+        Box b = embree_restated::emptyBox();
+        V3 c(dk.center), t = V3(dk.tangent)*dk.r, bt = V3(dk.bitangent)*dk.r;
+        grow(b, c - t - bt); grow(b, c + t - bt); grow(b, c + t + bt); grow(b, c - t + bt);
+        boxes.push_back(b);
+        refFinites.push_back(RefFinite{PRIM_DISK, i});
+    }
+    refMesh.resize(sc.n_meshes);
+    for (uint32_t m = 0; m < sc.n_meshes; ++m) { // TriangleMesh::bounds (TriangleMesh.cpp:519-522)
+        Box b;
+        for (int k = 0; k < 3; ++k) { b.lo[k] = sc.mesh_bounds[size_t(m)*6 + k]; b.hi[k] = sc.mesh_bounds[size_t(m)*6 + 3 + k]; }
+        boxes.push_back(b);
+        refFinites.push_back(RefFinite{PRIM_TRI, m});
+        uint32_t first = sc.mesh_first_tri[m], n = sc.mesh_first_tri[m + 1] - first;
+        std::vector<Box> tb(n);
+        for (uint32_t i = 0; i < n; ++i) { // TriangleMesh::bounds(i) (kernels/common/scene_triangle_mesh.h:154-161)
+            tb[i] = embree_restated::emptyBox();
+            for (int v = 0; v < 3; ++v) grow(tb[i], V3(sc.tri_pos + size_t(first + i)*9 + size_t(v)*3));
+        }
+        refMesh[m].build(tb, 4, 4, 28); // BVH4Triangle4SceneBuilderSAH (bvh_builder_sah.cpp:773: sahBlockSize 4, minLeafSize 4, maxLeafSize inf -> 4*7 blocks)
+    }
+    // The order of the primitives inside the user geometry (the scene file's) is not part of the flattened scene.  It only matters where Embree falls
+    // back to a median split by position in the array (every centroid of a subtree coincides), which no scene on the path does.
+    refTop.build(boxes, 4, 1, 1); // BVH4VirtualSceneBuilderSAH (bvh_builder_sah.cpp:811-815, common/state.cpp:83-84)
+    refAccel = true;
+#endif
+}
+
+bool oracle_ctx::refMeshIntersect(uint32_t mesh, Ray &ray, Temp &data, Counters &c) const // TriangleMesh::intersect (TriangleMesh.cpp:317-335)
+{
+    using embree_restated::Bvh4;
+    const Bvh4 &bvh = refMesh[mesh];
+    const uint32_t firstTri = sc.mesh_first_tri[mesh];
+    Bvh4::Ray er;
+    for (int k = 0; k < 3; ++k) { er.org[k] = ray.pos[k]; er.dir[k] = ray.dir[k]; }
+    er.tnear = ray.nearT;
+    er.tfar = ray.farT;
+    uint32_t prim = 0xFFFFFFFFu;
+    float u = 0, v = 0;
+    bvh.intersect(er, false, [&](uint32_t first, uint32_t count, Bvh4::Ray &r) {
+        for (uint32_t block = 0; block < count; block += 4) { // ArrayIntersector1 over Triangle4 blocks; Intersect1EpilogM: select_min(valid, vt)
+            int best = -1;
+            TriHit bestHit{false, 0, 0, 0};
+            for (uint32_t lane = 0; lane < 4 && block + lane < count; ++lane) {
+                uint32_t id = firstTri + bvh.prims()[first + block + lane];
+                c.tris++;
+                TriHit h = triTest(tris[id], ray, r.tfar, 1);
+                if (h.valid && (best < 0 || h.t < bestHit.t)) { best = int(lane); bestHit = h; }
+            }
+            if (best >= 0) {
+                r.tfar = bestHit.t;
+                prim = firstTri + bvh.prims()[first + block + uint32_t(best)];
+                u = bestHit.u;
+                v = bestHit.v;
+            }
+        }
+    }, &c.nodes);
+    if (prim == 0xFFFFFFFFu) return false;
+    ray.farT = er.tfar;
     data.inst = data.instSet = -1;
+    data.kind = PRIM_TRI;
+    data.index = prim;
+    data.u = u;
+    data.v = v;
+    const float *p = sc.tri_pos + size_t(prim)*9;
+    V3 p0(p), p1(p + 3), p2(p + 6);
+    data.Ng = (p1 - p0).cross(p2 - p0); // unnormalizedGeometricNormalAt :81-88
+    data.backSide = data.Ng.dot(ray.dir) > 0.0f;
     return true;
 }
-#endif
+
+void oracle_ctx::refIntersect(Ray &ray, Temp &data, Counters &c) const // rtcIntersect(_scene, eRay) of TraceableScene::intersect (:175-177)
+{
+    using embree_restated::Bvh4;
+    Bvh4::Ray er;
+    for (int k = 0; k < 3; ++k) { er.org[k] = ray.pos[k]; er.dir[k] = ray.dir[k]; }
+    er.tnear = ray.nearT;
+    er.tfar = ray.farT;
+    refTop.intersect(er, true, [&](uint32_t first, uint32_t /*count = 1*/, Bvh4::Ray &r) {
+        const RefFinite &f = refFinites[refTop.prims()[first]];
+        bool hit = false; // the intersect callback (TraceableScene.hpp:114-121): embreeRay.tfar = ray.farT() when the primitive says yes
+        switch (f.kind) {
+        case PRIM_INSTANCE: hit = instanceIntersect(f.index, ray, data, c); break;
+        case PRIM_QUAD: hit = quadIntersect(sc.quads[f.index], f.index, ray, data); if (hit) data.inst = data.instSet = -1; break;
+        case PRIM_CUBE: { float before = ray.farT; hit = cubeIntersect(sc.cubes[f.index], f.index, ray, data); if (ray.farT != before) data.inst = data.instSet = -1; break; }
+        case PRIM_SPHERE: hit = sphereIntersect(sc.spheres[f.index], f.index, ray, data); if (hit) data.inst = data.instSet = -1; break;
+        case PRIM_DISK: hit = diskIntersect(sc.disks[f.index], f.index, ray, data); if (hit) data.inst = data.instSet = -1; break;
+        case PRIM_TRI: hit = refMeshIntersect(f.index, ray, data, c); break;
+        default: break;
+        }
+        if (hit) r.tfar = ray.farT;
+    }, &c.nodes);
+}
 
 bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const // renderer/TraceableScene.hpp:170-192
 {
@@ -1310,14 +1433,14 @@ bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const 
     // Order of the finites: "instances" primitives first, then everything else.  Embree visits its user geometries
     // front to back by box entry; an Instance is the only primitive whose result depends on what was found before
     // it (it ignores the incoming farT for its local rays), and its box is normally entered first.
+    if (refAccel) {
+        refIntersect(ray, data, c);
+    } else {
     for (uint32_t i = 0; i < sc.n_instance_sets; ++i) instanceIntersect(i, ray, data, c);
     for (uint32_t i = 0; i < sc.n_quads; ++i)
         if (quadIntersect(sc.quads[i], i, ray, data)) data.inst = data.instSet = -1;
     for (uint32_t i = 0; i < sc.n_cubes; ++i) {
         float before = ray.farT;
-#if defined(__SSE__)
-        if (rcpMode && data.kind == PRIM_QUAD && coplanarTieGoesToCube(sc.cubes[i], i, ray, data)) continue;
-#endif
         cubeIntersect(sc.cubes[i], i, ray, data);
         if (ray.farT != before) data.inst = data.instSet = -1;
     }
@@ -1340,6 +1463,7 @@ bool oracle_ctx::intersect(Ray &ray, Temp &data, Info &info, Counters &c) const 
         data.Ng = (p1 - p0).cross(p2 - p0); // unnormalizedGeometricNormalAt :81-88
         data.backSide = data.Ng.dot(ray.dir) > 0.0f;
     }
+    } // !refAccel
     if (data.kind != PRIM_NONE) {
         info.p = ray.pos + ray.dir*ray.farT;
         info.w = ray.dir;
@@ -3530,6 +3654,7 @@ oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_m
     ctx->buildBvh(0, ctx->sc.n_tris, ctx->sceneBvh);
     ctx->buildInstances();
     ctx->buildExpTable();
+    ctx->buildReferenceAccel();
     return ctx;
 }
 
@@ -3667,6 +3792,9 @@ int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint
             s.matrices = ctx->sc.sobol_matrices;
             s.sobol = ctx->sc.settings.use_sobol != 0;
             s.seed = seeds[t];
+            const bool dumpTile = g_dumpTile && uint32_t(std::atoi(g_dumpTile)) == t;
+            uint32_t traceP = ~0u, traceS = ~0u;
+            if (g_traceAt) std::sscanf(g_traceAt, "%u:%u", &traceP, &traceS);
             for (uint32_t y = 0; y < th; ++y) { // PathTraceIntegrator::renderTile :136-156
                 for (uint32_t x = 0; x < tw; ++x) {
                     uint32_t px = tx + x, py = ty + y, pixelIndex = px + py*W;
@@ -3679,7 +3807,9 @@ int oracle_render_image(oracle_ctx *ctx, uint32_t seed, uint32_t spp_begin, uint
                             s.supplemental = &s.local;
                         }
                         AovSample aov;
+                        if (g_traceAt) g_trace = pixelIndex == traceP && spp_begin + i == traceS;
                         V3 col = ctx->traceSample(px, py, s, c, ctx->trackOutputs ? &aov : nullptr);
+                        if (dumpTile) std::fprintf(stderr, "S %u %u %08x %08x %08x\n", pixelIndex, spp_begin + i, hx(col.x), hx(col.y), hx(col.z));
                         addSample(rgb_mean + size_t(pixelIndex)*3, sample_count + pixelIndex, col);
                         if (ctx->trackOutputs) addOutputSamples(ctx, pixelIndex, col, aov);
                     }
@@ -3733,6 +3863,77 @@ int oracle_render_shard(oracle_ctx *ctx, const tgpu_shard_desc *shard, uint32_t 
     worker();
     for (auto &t : th) t.join();
     return 0;
+}
+
+void oracle_kat_embree_user(const float *boxes6, uint32_t n_boxes, const float *rays, uint32_t n_rays, uint32_t *visits, uint32_t max_visits,
+                            uint32_t *n_visits, uint32_t *prim, float *tfar)
+{
+    using namespace embree_restated;
+    std::vector<Box> boxes(n_boxes);
+    for (uint32_t i = 0; i < n_boxes; ++i) for (int k = 0; k < 3; ++k) { boxes[i].lo[k] = boxes6[i*6 + k]; boxes[i].hi[k] = boxes6[i*6 + 3 + k]; }
+    Bvh4 bvh;
+    bvh.build(boxes, 4, 1, 1);
+    const size_t stride = 8 + size_t(n_boxes);
+    for (uint32_t r = 0; r < n_rays; ++r) {
+        const float *rr = rays + r*stride;
+        Bvh4::Ray er;
+        for (int k = 0; k < 3; ++k) { er.org[k] = rr[k]; er.dir[k] = rr[3 + k]; }
+        er.tnear = rr[6];
+        er.tfar = rr[7];
+        uint32_t nv = 0, hitPrim = 0xFFFFFFFFu;
+        bvh.intersect(er, true, [&](uint32_t first, uint32_t, Bvh4::Ray &ray) {
+            uint32_t id = bvh.prims()[first];
+            if (nv < max_visits) visits[size_t(r)*max_visits + nv] = id;
+            nv++;
+            float t = rr[8 + id];
+            if (t < 0.0f || t < ray.tnear || t > ray.tfar) return;
+            ray.tfar = t;
+            hitPrim = id;
+        });
+        n_visits[r] = nv;
+        prim[r] = hitPrim;
+        tfar[r] = er.tfar;
+    }
+}
+
+void oracle_kat_embree_tris(const float *verts3, uint32_t n_verts, const uint32_t *tris3, uint32_t n_tris, const float *rays8, uint32_t n_rays,
+                            uint32_t *prim, float *tuv3)
+{
+    using namespace embree_restated;
+    (void)n_verts;
+    std::vector<Box> boxes(n_tris);
+    std::vector<TriIsect> tri(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        V3 p0(verts3 + size_t(tris3[i*3])*3), p1(verts3 + size_t(tris3[i*3 + 1])*3), p2(verts3 + size_t(tris3[i*3 + 2])*3);
+        boxes[i] = emptyBox();
+        for (int k = 0; k < 3; ++k) { boxes[i].lo[k] = std::min(p0[k], std::min(p1[k], p2[k])); boxes[i].hi[k] = std::max(p0[k], std::max(p1[k], p2[k])); }
+        tri[i].v0 = p0; tri[i].e1 = p0 - p1; tri[i].e2 = p2 - p0; tri[i].Ng = tri[i].e1.cross(tri[i].e2);
+    }
+    Bvh4 bvh;
+    bvh.build(boxes, 4, 4, 28);
+    for (uint32_t r = 0; r < n_rays; ++r) {
+        const float *rr = rays8 + size_t(r)*8;
+        Ray ray{V3(rr), V3(rr + 3), rr[6], rr[7]};
+        Bvh4::Ray er;
+        for (int k = 0; k < 3; ++k) { er.org[k] = rr[k]; er.dir[k] = rr[3 + k]; }
+        er.tnear = rr[6];
+        er.tfar = rr[7];
+        uint32_t hitPrim = 0xFFFFFFFFu;
+        float u = 0, v = 0;
+        bvh.intersect(er, false, [&](uint32_t first, uint32_t count, Bvh4::Ray &q) {
+            for (uint32_t block = 0; block < count; block += 4) {
+                int best = -1;
+                TriHit bh{false, 0, 0, 0};
+                for (uint32_t lane = 0; lane < 4 && block + lane < count; ++lane) {
+                    TriHit h = triTest(tri[bvh.prims()[first + block + lane]], ray, q.tfar, 1);
+                    if (h.valid && (best < 0 || h.t < bh.t)) { best = int(lane); bh = h; }
+                }
+                if (best >= 0) { q.tfar = bh.t; hitPrim = bvh.prims()[first + block + uint32_t(best)]; u = bh.u; v = bh.v; }
+            }
+        });
+        prim[r] = hitPrim;
+        tuv3[size_t(r)*3] = er.tfar; tuv3[size_t(r)*3 + 1] = u; tuv3[size_t(r)*3 + 2] = v;
+    }
 }
 
 int oracle_trace_closest(oracle_ctx *ctx, const float *rays, uint32_t n, float *hits)

@@ -87,6 +87,16 @@ void oracle_camera_ray(const oracle_ctx *ctx, uint32_t px, uint32_t py, float xi
 void oracle_tile_seeds(uint32_t res_x, uint32_t res_y, uint32_t seed, uint32_t *out);
 uint32_t oracle_kat_binary_bvh(const float *boxes6, uint32_t n, const float *origin3, const float *dir3, uint32_t *out, uint32_t max_visits);
 
+/* The Embree restatement of the reference mode (oracle/embree_bvh4.h) on its own, for tests/test_ref_kat5.py:
+ * user form  -- n_boxes boxes as ONE user geometry; per ray {org3, dir3, tnear, tfar, scripted[n_boxes]}: a visited primitive reports a hit at
+ *               its scripted distance unless that is negative or outside [tnear, tfar].  visits (capacity max_visits per ray) receives the
+ *               primitives in the order the traversal asks them, n_visits their number, prim / tfar the result (prim 0xFFFFFFFF = none).
+ * tri form   -- a triangle mesh (TriangleMesh.cpp:531-566); per ray {org3, dir3, tnear, tfar} -> prim, {t, u, v}.                              */
+void oracle_kat_embree_user(const float *boxes6, uint32_t n_boxes, const float *rays, uint32_t n_rays, uint32_t *visits, uint32_t max_visits,
+                            uint32_t *n_visits, uint32_t *prim, float *tfar);
+void oracle_kat_embree_tris(const float *verts3, uint32_t n_verts, const uint32_t *tris3, uint32_t n_tris, const float *rays8, uint32_t n_rays,
+                            uint32_t *prim, float *tuv3);
+
 /* Triangle queries test EVERY triangle instead of walking the BVH: the definition (include/tgpu_bounds.h) both BVH walks
  * are checked against.  O(rays x triangles): ray batches and single paths only. */
 void oracle_set_brute_force(oracle_ctx *ctx, int on);

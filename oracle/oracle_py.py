@@ -47,6 +47,8 @@ def lib():
         L.oracle_set_brute_force.argtypes = [C.c_void_p, C.c_int]
         L.oracle_bind_output_buffers.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_kat_output_buffer.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_kat_embree_user.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_kat_embree_tris.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.oracle_get_stats.argtypes = [C.c_void_p, C.POINTER(OracleStats)]
         L.oracle_reset_stats.argtypes = [C.c_void_p]
         _lib = L

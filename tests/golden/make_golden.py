@@ -44,6 +44,17 @@ FIXTURES = [
     ("nonexp_stock_deep_96_8spp", "non-exponential/scene.json", (96, 96), 8, False, {"stratified_sampler": True, "max_bounces": 16}),
     ("nonexp_stock_adaptive_128_48spp", "non-exponential/scene.json", (128, 128), 48, True, {}),
     ("c1_adaptive_128x72_64spp", "materialtest/materialtest.json", (128, 72), 64, True),
+    # round 3: fixtures LONG enough to see rare events (one flipped decision desynchronises a tile's sequential PCG stream for good).
+    # The first two contain the events that showed the oracle's reference mode needed Embree's traversal restated (oracle/embree_bvh4.h):
+    # a ceiling quad culled by its own flat box (pixel (67,7) sample 41) and a floor / wall tie decided by visit order (pixel (47,33) sample 15)
+    ("cornell_sobol_96x54_64spp", "cornell-box/scene_sobol.json", (96, 54), 64),
+    ("cornell_sobol_64x36_128spp", "cornell-box/scene_sobol.json", (64, 36), 128),
+    ("cornell_stock_96x54_48spp", "cornell-box/scene.json", (96, 54), 48),           # BASELINE config 3's scene as shipped (uniform sampler)
+    ("c2_320x180_32spp", "materialtest/c2.json", (320, 180), 32),                    # two pixels of this one need Embree's first-found triangle
+    ("c2_32x18_320spp", "materialtest/c2.json", (32, 18), 320),                      # sample indices >= 256: the second Sobol' block (SobolPathSampler.hpp:47-52)
+    ("c5_128x72_64spp", "materialtest/c5.json", (128, 72), 64),
+    ("inst_many_96x54_48spp", "instances/inst_many.json", (96, 54), 48),
+    ("cornell_fog_96x54_64spp", "cornell-box/scene_fog.json", (96, 54), 64),
 ]
 
 

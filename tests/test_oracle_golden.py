@@ -44,14 +44,24 @@ CASES = [
     ("trans_interpolated2_96x54_8spp", "next/trans_interpolated2.json", (96, 54), 8),  # exponential + davis
     # 8-bit PNG bitmaps: gamma-table RGB albedo (interpolated, wrapped), palette albedo (nearest, clamped, scaled), scalar-average roughness
     ("ldr_texture_128x72_4spp", "next/ldr_texture.json", (128, 72), 4),
+    # round 3: long enough to contain rare events -- box culls and exact ties that only Embree's own traversal order decides (oracle/embree_bvh4.h)
+    ("cornell_sobol_96x54_64spp", "cornell-box/scene_sobol.json", (96, 54), 64),     # pixel (67,7) sample 41: ceiling quad culled by its flat box
+    ("cornell_sobol_64x36_128spp", "cornell-box/scene_sobol.json", (64, 36), 128),   # pixel (47,33) sample 15: floor / wall tie, last visited wins
+    ("cornell_stock_96x54_48spp", "cornell-box/scene.json", (96, 54), 48),           # BASELINE config 3's scene as shipped (uniform sampler)
+    ("c2_320x180_32spp", "materialtest/c2.json", (320, 180), 32),                    # first-found triangle on an exact tie (2 pixels)
+    ("c2_32x18_320spp", "materialtest/c2.json", (32, 18), 320),                      # sample indices >= 256
+    ("c5_128x72_64spp", "materialtest/c5.json", (128, 72), 64),
+    ("inst_many_96x54_48spp", "instances/inst_many.json", (96, 54), 48),
+    ("cornell_fog_96x54_64spp", "cornell-box/scene_fog.json", (96, 54), 64),
 ]
 
 
-# Fixtures whose paths wander below the Cornell box's floor (camera medium) and reach the floor quad and a box's bottom face at the same binary32
-# distance: which of the two the reference hits is decided by Embree's node test with its RCPPS-based reciprocal (DESIGN.md section 7f,
-# oracle_ctx::coplanarTieGoesToCube).  Where RCPPS matches the fixture host they must be exact in EVERY pixel; elsewhere one flipped decision
-# desynchronises a tile's sequential PCG stream, so only the image mean is asserted there.
-COPLANAR_TIES = {"trans_erlang_96x54_8spp", "trans_davis_weinstein_96x54_8spp", "trans_interpolated_96x54_8spp"}
+# Fixtures that contain an event only Embree's own traversal decides (a primitive culled by its leaf box, two primitives at one binary32 distance:
+# DESIGN.md section 2a, oracle/embree_bvh4.h, oracle_ctx::refIntersect), all through its RCPPS-based reciprocal.  Where RCPPS matches the fixture
+# host they must be exact in EVERY pixel; elsewhere one flipped decision desynchronises a tile's sequential PCG stream, so only the image mean is
+# asserted there (and the test says so by its id).
+EMBREE_DECIDED = {"trans_erlang_96x54_8spp", "trans_davis_weinstein_96x54_8spp", "trans_interpolated_96x54_8spp",
+                  "cornell_sobol_96x54_64spp", "cornell_sobol_64x36_128spp", "cornell_stock_96x54_48spp", "c2_320x180_32spp", "cornell_fog_96x54_64spp"}
 
 
 def intel_rcp(oracle_py):
@@ -75,7 +85,7 @@ def test_oracle_matches_reference(ta, oracle_py, name, scene, res, spp):
     assert (cnt == spp).all()
     rmse = float(np.sqrt(((img - ref)**2).mean()))
     exact = float((img == ref).all(axis=2).mean())
-    if name in COPLANAR_TIES:
+    if name in EMBREE_DECIDED:
         if intel_rcp(oracle_py):
             assert exact == 1.0, f"{name}: {int(round((1.0 - exact)*img.shape[0]*img.shape[1]))} pixels differ from the reference"
         else:
@@ -160,7 +170,7 @@ def test_golden_fixtures_match_their_manifest():
     on_disk = set()
     for root, _, files in os.walk(GOLDEN):
         for f in files:
-            if f.endswith((".pfm", ".dat")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json", "ref_kat4.json"):
+            if f.endswith((".pfm", ".dat")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json", "ref_kat4.json", "ref_kat5.npz"):
                 on_disk.add(os.path.relpath(os.path.join(root, f), GOLDEN))
     assert on_disk == set(manifest), f"fixtures without manifest entry or vice versa: {sorted(on_disk ^ set(manifest))}"
     for name, digest in manifest.items():
@@ -249,3 +259,26 @@ def test_coplanar_tie_follows_the_reference(ta, oracle_py):
         ref = oracle_py.Oracle(hs, **oracle_py.REF_RCP).trace_closest(np.stack([ray, ray2]))
         assert ref[:, 0].view(np.uint32).tolist() == [0x3eec7e10, 0x3f09f435]
         assert (ref[:, 3].view(np.uint32) >> 29).tolist() == [2, 1]      # cube, quad
+
+
+def test_embree_decided_events_of_the_cornell_box(ta, oracle_py):
+    """Two recorded events of the compiled reference on BASELINE config 3's scene (cornell-box/scene_sobol.json, camera rays, found with
+    tests/tools/ref_path_dump.cpp beside ORACLE_TRACE_AT):
+      1. 96x54, pixel (67,7), sample 41: the ray leaves through the edge between the ceiling and the right wall.  The ceiling quad's own test passes
+         (t = 0x40fcbc5a, u = 3e-8) but the ray misses the ceiling's flat Embree leaf box by an ulp, so the reference reports the WALL at 0x40fcbc5d.
+      2. 64x36, pixel (47,33), sample 15: floor and right wall at the SAME distance 0x40d5e339; Quad::intersect keeps t <= farT, so the leaf Embree
+         visits last wins -- the floor.
+    The oracle's reference mode (Embree's BVH4 and traversal restated) must agree; the GPU contract is the primitives' own tests in index order:
+    the ceiling, and the wall (the later quad keeps the tie)."""
+    hs = ta.HostScene(scene_path("cornell-box/scene_sobol.json"), resolution=(96, 54))
+    bits = lambda *w: np.array(w, np.uint32).view(np.float32)
+    org = bits(0x00000000, 0x3f800000, 0x40d9999a)
+    r1 = np.concatenate([org, [1e-4], bits(0x3e01a738, 0x3e01a737, 0xbf7bdcd1), [np.inf]]).astype(np.float32)
+    r2 = np.concatenate([org, [1e-4], bits(0x3e1933b4, 0xbe1933b4, 0xbf7a3447), [np.inf]]).astype(np.float32)
+    gpu = oracle_py.Oracle(hs, **oracle_py.GPU).trace_closest(np.stack([r1, r2]))
+    assert gpu[:, 0].view(np.uint32).tolist() == [0x40fcbc5a, 0x40d5e339]
+    assert gpu[:, 3].view(np.uint32).tolist() == [(1 << 29) | 1, (1 << 29) | 3]      # ceiling, right wall
+    if intel_rcp(oracle_py):
+        ref = oracle_py.Oracle(hs, **oracle_py.REF_RCP).trace_closest(np.stack([r1, r2]))
+        assert ref[:, 0].view(np.uint32).tolist() == [0x40fcbc5d, 0x40d5e339]
+        assert ref[:, 3].view(np.uint32).tolist() == [(1 << 29) | 3, (1 << 29) | 0]  # right wall, floor

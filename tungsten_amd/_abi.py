@@ -1,7 +1,7 @@
 """ctypes mirror of include/tungsten_amd.h (keep in sync; tests/test_abi.py checks sizes)."""
 import ctypes as C
 
-TGPU_ABI_VERSION = 3
+TGPU_ABI_VERSION = 4
 
 f32 = C.c_float
 i32 = C.c_int32
@@ -101,6 +101,7 @@ class SceneDesc(C.Structure):
     _fields_ = [("abi_version", u32), ("camera", Camera), ("settings", Settings), ("output_buffers", OutputBuffer*5),
                 ("n_tris", u32), ("tri_pos", pf32), ("tri_normal", pf32), ("tri_uv", pf32), ("tri_bsdf", pi32),
                 ("tri_smooth", pu8), ("tri_media", C.POINTER(C.c_int16)),
+                ("n_meshes", u32), ("mesh_first_tri", pu32), ("mesh_bounds", pf32),
                 ("n_quads", u32), ("quads", C.POINTER(Quad)),
                 ("n_cubes", u32), ("cubes", C.POINTER(Cube)),
                 ("n_spheres", u32), ("spheres", C.POINTER(Sphere)),

@@ -1575,8 +1575,17 @@ void Scene::flatten()
 
     // ---- meshes: world-space bake (TriangleMesh.cpp:524-552) ----
     _triPos.clear(); _triNormal.clear(); _triUv.clear(); _triBsdf.clear(); _triSmooth.clear(); _triMedia.clear();
-    for (const MeshData &m : meshes) bakeMesh(m, nullptr, nullptr);
+    _meshFirstTri.assign(1, 0u);
+    _meshBounds.clear();
+    for (const MeshData &m : meshes) {
+        float lo[3], hi[3];
+        bakeMesh(m, lo, hi);
+        _meshFirstTri.push_back(uint32_t(_triBsdf.size()));
+        _meshBounds.insert(_meshBounds.end(), lo, lo + 3);
+        _meshBounds.insert(_meshBounds.end(), hi, hi + 3);
+    }
     _desc.n_tris = uint32_t(_triBsdf.size());
+    _desc.n_meshes = uint32_t(meshes.size());
 
     // ---- quads (Quad.cpp:298-316), cubes (Cube.cpp:353-370) ----
     _quads.clear();
@@ -1697,6 +1706,8 @@ void Scene::flatten()
     _desc.n_master_quads = uint32_t(_quads.size()) - _desc.n_quads;
     _desc.n_master_cubes = uint32_t(_cubes.size()) - _desc.n_cubes;
     _desc.tri_pos = _triPos.data();
+    _desc.mesh_first_tri = _meshFirstTri.data();
+    _desc.mesh_bounds = _meshBounds.data();
     _desc.tri_normal = _triNormal.data();
     _desc.tri_uv = _triUv.data();
     _desc.tri_bsdf = _triBsdf.data();

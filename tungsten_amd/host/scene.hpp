@@ -97,6 +97,8 @@ private:
     std::vector<std::pair<std::string, int>> _namedMedia;
     std::vector<tgpu_medium> _media;
     std::vector<int16_t> _triMedia;
+    std::vector<uint32_t> _meshFirstTri; // n_meshes + 1 offsets into the soup
+    std::vector<float> _meshBounds;      // n_meshes*6
     int _cameraMedium = -1;
     // "instances" primitive (primitives/Instance.cpp:60-93): masters are private primitives of the set
     struct MasterSrc { int kind; MeshData mesh; QuadSrc quad; CubeSrc cube; };

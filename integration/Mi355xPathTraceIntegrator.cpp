@@ -15,17 +15,23 @@
 #include <host/scene.hpp> // tungsten_amd/host: this repository's scene loader / flattener
 
 #include <rapidjson/document.h>
+#include <functional>
 #include <set>
 #include <sstream>
 
 namespace Tungsten {
 
 Mi355xPathTraceIntegrator::Mi355xPathTraceIntegrator() {}
-Mi355xPathTraceIntegrator::~Mi355xPathTraceIntegrator()
+Mi355xPathTraceIntegrator::~Mi355xPathTraceIntegrator() { teardownAfterRender(); }
+
+void Mi355xPathTraceIntegrator::check(int status) const
 {
-    if (_waiter.joinable()) _waiter.join();
-    if (_ctx) tgpu_destroy(_ctx);
+    if (status != TGPU_OK)
+        FAIL("%s", _ctx ? tgpu_last_error(_ctx) : "no device context");
 }
+
+bool Mi355xPathTraceIntegrator::adaptive() const { return _scene->rendererSettings().useAdaptiveSampling(); }
+bool Mi355xPathTraceIntegrator::supportsResumeRender() const { return true; } // PathTraceIntegrator.cpp:215-218
 
 void Mi355xPathTraceIntegrator::fromJson(JsonPtr value, const Scene &/*scene*/) { _settings.fromJson(value); }
 rapidjson::Value Mi355xPathTraceIntegrator::toJson(Allocator &allocator) const { return _settings.toJson(allocator); }
@@ -69,6 +75,7 @@ void Mi355xPathTraceIntegrator::flatten(const TraceableScene &scene)
 
 void Mi355xPathTraceIntegrator::prepareForRender(TraceableScene &scene, uint32 seed)
 {
+    teardownAfterRender(); // a second prepareForRender without a teardown in between must not leak the first context
     _currentSpp = 0;
     _scene = &scene;
     advanceSpp();
@@ -83,9 +90,11 @@ void Mi355xPathTraceIntegrator::prepareForRender(TraceableScene &scene, uint32 s
     UniformSampler sampler(MathUtil::hash32(seed));
     _pixelIndex.clear();
     _tileSeed.clear();
+    _seedOfTile.clear();
     for (uint32 y = 0; y < h; y += 16) {
         for (uint32 x = 0; x < w; x += 16) {
             const uint32 tileSeed = MathUtil::hash32(sampler.nextI());
+            _seedOfTile.push_back(tileSeed);
             for (uint32 ty = y; ty < min(y + 16u, h); ++ty) {
                 for (uint32 tx = x; tx < min(x + 16u, w); ++tx) {
                     _pixelIndex.push_back(tx + ty*w);
@@ -94,9 +103,9 @@ void Mi355xPathTraceIntegrator::prepareForRender(TraceableScene &scene, uint32 s
             }
         }
     }
+    _work.init(w, h, seed); // the same generator, advanced past the tile seeds: the draws generateWork's stochastic rounding takes
     tgpu_shard_desc shard{uint32(_pixelIndex.size()), _pixelIndex.data(), _tileSeed.data()};
-    if (tgpu_upload_scene(_ctx, &_flat->desc(), &shard, 0) != TGPU_OK)
-        FAIL("%s", tgpu_last_error(_ctx));
+    check(tgpu_upload_scene(_ctx, &_flat->desc(), &shard, 0));
 }
 
 void Mi355xPathTraceIntegrator::teardownAfterRender()
@@ -105,42 +114,106 @@ void Mi355xPathTraceIntegrator::teardownAfterRender()
     if (_ctx) tgpu_destroy(_ctx);
     _ctx = nullptr;
     _flat.reset();
+    _error = nullptr;
+    _aborted = false;
 }
 
-// OutputBuffer has no bulk setter: the only writer besides addSample is deserialize(), which reads _bufferA and then _sampleCount -- the
-// arrays tgpu_download returns -- from a stream (cameras/OutputBuffer.hpp:191-200)
+// One buffer of the camera, device -> OutputBuffer.  OutputBuffer has no bulk setter: the only writer besides addSample is deserialize(), which
+// reads _bufferA, then _bufferB and _variance if the buffer has them, then _sampleCount from a stream (cameras/OutputBuffer.hpp:191-200).  Which
+// parts exist is what the renderer settings asked for; the flattened scene carries the same flags, so the device holds exactly these parts.
+void Mi355xPathTraceIntegrator::publishBuffer(int type, int channels, const std::function<void(InputStreamHandle &)> &deserialize)
+{
+    const tgpu_output_buffer &want = _flat->desc().output_buffers[type];
+    const size_t n = _pixelIndex.size();
+    std::string bytes;
+    std::vector<uint32> shardWords, imageWords;
+    for (int part : {TGPU_PART_A, TGPU_PART_B, TGPU_PART_VARIANCE, TGPU_PART_COUNT}) {
+        if ((part == TGPU_PART_B && !want.two_buffer_variance) || (part == TGPU_PART_VARIANCE && !want.sample_variance))
+            continue;
+        const size_t width = part == TGPU_PART_COUNT ? 1 : size_t(channels);
+        shardWords.resize(n*width);
+        imageWords.resize(n*width);
+        check(tgpu_download_output_buffer(_ctx, type, part, shardWords.data()));
+        for (size_t i = 0; i < n; ++i) // shard order (tile by tile) -> image order
+            for (size_t c = 0; c < width; ++c)
+                imageWords[size_t(_pixelIndex[i])*width + c] = shardWords[i*width + c];
+        bytes.append(reinterpret_cast<const char *>(imageWords.data()), imageWords.size()*sizeof(uint32));
+    }
+    InputStreamHandle in(new std::istringstream(bytes, std::ios_base::in | std::ios_base::binary));
+    deserialize(in);
+}
+
+// The way back (resume): OutputBuffer::serialize writes the same parts in the same order (:202-211)
+void Mi355xPathTraceIntegrator::uploadBuffer(int type, int channels, const std::function<void(OutputStreamHandle &)> &serialize)
+{
+    const tgpu_output_buffer &want = _flat->desc().output_buffers[type];
+    const size_t n = _pixelIndex.size();
+    std::shared_ptr<std::ostringstream> text(new std::ostringstream(std::ios_base::out | std::ios_base::binary));
+    OutputStreamHandle out(text);
+    serialize(out);
+    const std::string bytes = text->str();
+    size_t offset = 0;
+    std::vector<uint32> shardWords;
+    for (int part : {TGPU_PART_A, TGPU_PART_B, TGPU_PART_VARIANCE, TGPU_PART_COUNT}) {
+        if ((part == TGPU_PART_B && !want.two_buffer_variance) || (part == TGPU_PART_VARIANCE && !want.sample_variance))
+            continue;
+        const size_t width = part == TGPU_PART_COUNT ? 1 : size_t(channels);
+        if (offset + n*width*sizeof(uint32) > bytes.size())
+            FAIL("Output buffer %d serialises to fewer parts than the renderer settings announce", type);
+        const uint32 *imageWords = reinterpret_cast<const uint32 *>(bytes.data() + offset);
+        shardWords.resize(n*width);
+        for (size_t i = 0; i < n; ++i)
+            for (size_t c = 0; c < width; ++c)
+                shardWords[i*width + c] = imageWords[size_t(_pixelIndex[i])*width + c];
+        check(tgpu_upload_output_buffer(_ctx, type, part, shardWords.data()));
+        offset += n*width*sizeof(uint32);
+    }
+}
+
 void Mi355xPathTraceIntegrator::publish()
 {
-    const size_t n = _pixelIndex.size();
-    std::vector<float> shardRgb(n*3), rgb(n*3);
-    std::vector<uint32> shardCount(n), count(n);
-    if (tgpu_download(_ctx, shardRgb.data(), shardCount.data()) != TGPU_OK)
-        FAIL("%s", tgpu_last_error(_ctx));
-    for (size_t i = 0; i < n; ++i) { // shard order (tile by tile) -> image order
-        for (int c = 0; c < 3; ++c)
-            rgb[size_t(_pixelIndex[i])*3 + c] = shardRgb[i*3 + c];
-        count[_pixelIndex[i]] = shardCount[i];
+    Camera &cam = _scene->cam();
+    publishBuffer(TGPU_OUTPUT_COLOR, 3, [&](InputStreamHandle &in) { cam.colorBuffer()->deserialize(in); });
+    if (cam.depthBuffer())      publishBuffer(TGPU_OUTPUT_DEPTH,      1, [&](InputStreamHandle &in) { cam.depthBuffer()->deserialize(in); });
+    if (cam.normalBuffer())     publishBuffer(TGPU_OUTPUT_NORMAL,     3, [&](InputStreamHandle &in) { cam.normalBuffer()->deserialize(in); });
+    if (cam.albedoBuffer())     publishBuffer(TGPU_OUTPUT_ALBEDO,     3, [&](InputStreamHandle &in) { cam.albedoBuffer()->deserialize(in); });
+    if (cam.visibilityBuffer()) publishBuffer(TGPU_OUTPUT_VISIBILITY, 1, [&](InputStreamHandle &in) { cam.visibilityBuffer()->deserialize(in); });
+}
+
+// generateWork (PathTraceIntegrator.cpp:110-134): from 16 spp on the per-tile statistics the device accumulated steer the next pass
+bool Mi355xPathTraceIntegrator::generateWork(std::vector<uint32> &sampleIndex, std::vector<uint32> &sampleCount)
+{
+    if (tungsten_amd::AdaptiveScheduler::needsStatistics(adaptive(), _currentSpp)) {
+        std::vector<tgpu_sample_record> table(_work.tileCount());
+        check(tgpu_download_records(_ctx, table.data()));
+        _work.setStatistics(table.data());
     }
-    std::string bytes(reinterpret_cast<const char *>(rgb.data()), rgb.size()*sizeof(float));
-    bytes.append(reinterpret_cast<const char *>(count.data()), count.size()*sizeof(uint32));
-    InputStreamHandle in(new std::istringstream(bytes, std::ios_base::in | std::ios_base::binary));
-    _scene->cam().colorBuffer()->deserialize(in);
+    if (!_work.generateWork(_currentSpp, _nextSpp, adaptive()))
+        return false;
+    _work.passArrays(sampleIndex, sampleCount);
+    return true;
 }
 
 void Mi355xPathTraceIntegrator::startRender(std::function<void()> completionCallback)
 {
-    if (done()) {
+    std::vector<uint32> sampleIndex, sampleCount;
+    if (done() || !generateWork(sampleIndex, sampleCount)) { // :222-227
         _currentSpp = _nextSpp;
         advanceSpp();
         completionCallback();
         return;
     }
-    if (tgpu_render_pass(_ctx, _currentSpp, _nextSpp - _currentSpp, nullptr) != TGPU_OK)
-        FAIL("%s", tgpu_last_error(_ctx));
+    _aborted = false;
+    if (adaptive())
+        check(tgpu_render_pass_adaptive(_ctx, sampleIndex.data(), sampleCount.data(), nullptr));
+    else
+        check(tgpu_render_pass(_ctx, _currentSpp, _nextSpp - _currentSpp, nullptr));
     if (_waiter.joinable()) _waiter.join();
     _waiter = std::thread([this, completionCallback]() {
         try {
-            if (tgpu_wait(_ctx) != TGPU_OK)
+            const int status = tgpu_wait(_ctx);
+            if (_aborted) return; // abortRender: the pass is dropped, nothing is published, nobody is called back (TaskGroup::abort)
+            if (status != TGPU_OK)
                 throw std::runtime_error(tgpu_last_error(_ctx));
             publish();
             _currentSpp = _nextSpp;
@@ -162,13 +235,75 @@ void Mi355xPathTraceIntegrator::waitForCompletion()
     }
 }
 
+// PathTraceIntegrator::abortRender (:249-256) stops the task group and returns; it never throws, and neither does the next waitForCompletion
 void Mi355xPathTraceIntegrator::abortRender()
 {
+    _aborted = true;
     if (_ctx) tgpu_abort(_ctx);
     if (_waiter.joinable()) _waiter.join();
+    _error = nullptr;
 }
 
-void Mi355xPathTraceIntegrator::saveState(OutputStreamHandle &/*out*/) {}
-void Mi355xPathTraceIntegrator::loadState(InputStreamHandle &/*in*/) {}
+// The resume file's integrator block in the reference's layout (:158-164): one 24-byte SampleRecord per variance tile
+// (SampleRecord.hpp:57-66: sampleCount, nextSampleCount, sampleIndex, adaptiveWeight, mean, runningVariance), then every tile's sampler
+// (SobolPathSampler: uint32 seed + the supplemental generator's 64-bit state; UniformPathSampler: the state alone).  The device keeps no
+// tile-sequential generator, so the state written is the one a fresh sampler has -- what loadState expects back.
+void Mi355xPathTraceIntegrator::saveState(OutputStreamHandle &out)
+{
+    if (adaptive()) {
+        std::vector<tgpu_sample_record> table(_work.tileCount());
+        check(tgpu_download_records(_ctx, table.data()));
+        _work.setStatistics(table.data());
+    }
+    for (size_t i = 0; i < _work.tileCount(); ++i) {
+        tungsten_amd::TileState t = _work.tile(i);
+        if (!adaptive()) t.sampleCount = 0;
+        FileUtils::streamWrite(out, t.sampleCount);
+        FileUtils::streamWrite(out, t.nextSampleCount);
+        FileUtils::streamWrite(out, t.sampleIndex);
+        FileUtils::streamWrite(out, t.adaptiveWeight);
+        FileUtils::streamWrite(out, t.mean);
+        FileUtils::streamWrite(out, t.runningVariance);
+    }
+    const bool sobol = _scene->rendererSettings().useSobol();
+    for (uint32 seed : _seedOfTile) {
+        if (sobol) FileUtils::streamWrite(out, seed);
+        FileUtils::streamWrite(out, uint64(seed));
+    }
+}
+
+// Integrator::resumeRender (Integrator.cpp:131-162) has filled the camera's buffers from the file just before this call: they go to the device
+// together with the SampleRecords, so that the next pass continues the running means.
+void Mi355xPathTraceIntegrator::loadState(InputStreamHandle &in)
+{
+    std::vector<tgpu_sample_record> table(_work.tileCount());
+    for (size_t i = 0; i < _work.tileCount(); ++i) {
+        tungsten_amd::TileState t = tungsten_amd::TileState();
+        FileUtils::streamRead(in, t.sampleCount);
+        FileUtils::streamRead(in, t.nextSampleCount);
+        FileUtils::streamRead(in, t.sampleIndex);
+        FileUtils::streamRead(in, t.adaptiveWeight);
+        FileUtils::streamRead(in, t.mean);
+        FileUtils::streamRead(in, t.runningVariance);
+        _work.setTile(i, t);
+        table[i] = tgpu_sample_record{t.sampleCount, t.mean, t.runningVariance};
+    }
+    const bool sobol = _scene->rendererSettings().useSobol();
+    for (uint32 expected : _seedOfTile) {
+        uint32 seed = expected;
+        uint64 state;
+        if (sobol) FileUtils::streamRead(in, seed);
+        FileUtils::streamRead(in, state);
+        if (seed != expected)
+            FAIL("The resume file was rendered with another seed");
+    }
+    if (adaptive()) check(tgpu_upload_records(_ctx, table.data()));
+    Camera &cam = _scene->cam();
+    uploadBuffer(TGPU_OUTPUT_COLOR, 3, [&](OutputStreamHandle &out) { cam.colorBuffer()->serialize(out); });
+    if (cam.depthBuffer())      uploadBuffer(TGPU_OUTPUT_DEPTH,      1, [&](OutputStreamHandle &out) { cam.depthBuffer()->serialize(out); });
+    if (cam.normalBuffer())     uploadBuffer(TGPU_OUTPUT_NORMAL,     3, [&](OutputStreamHandle &out) { cam.normalBuffer()->serialize(out); });
+    if (cam.albedoBuffer())     uploadBuffer(TGPU_OUTPUT_ALBEDO,     3, [&](OutputStreamHandle &out) { cam.albedoBuffer()->serialize(out); });
+    if (cam.visibilityBuffer()) uploadBuffer(TGPU_OUTPUT_VISIBILITY, 1, [&](OutputStreamHandle &out) { cam.visibilityBuffer()->serialize(out); });
+}
 
 }

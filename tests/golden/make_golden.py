@@ -55,6 +55,13 @@ FIXTURES = [
     ("c5_128x72_64spp", "materialtest/c5.json", (128, 72), 64),
     ("inst_many_96x54_48spp", "instances/inst_many.json", (96, 54), 48),
     ("cornell_fog_96x54_64spp", "cornell-box/scene_fog.json", (96, 54), 64),
+    # the LDR output path (Integrator::writeBuffers: Camera::tonemap, *255, clamp, PNG; Integrator.cpp:56-80, cameras/Tonemap.hpp:26-62): the PNG the
+    # reference writes NEXT TO the PFM is kept for these, one per tonemap operator, so that PFM -> PNG can be checked byte for byte on the CPU
+    ("tonemap_linear_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "linear", "keep_png": True}),
+    ("tonemap_gamma_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "gamma", "keep_png": True}),
+    ("tonemap_reinhard_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "reinhard", "keep_png": True}),
+    ("tonemap_filmic_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "filmic", "keep_png": True}),
+    ("tonemap_pbrt_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "pbrt", "keep_png": True}),
 ]
 
 
@@ -79,6 +86,8 @@ def main():
             d["integrator"]["max_bounces"] = overrides["max_bounces"]
         if "stratified_sampler" in overrides:
             d["renderer"]["stratified_sampler"] = overrides["stratified_sampler"]
+        if "tonemap" in overrides:
+            d["camera"]["tonemap"] = overrides["tonemap"]
         tmp = os.path.join(os.path.dirname(src), f"_tmp_{name}.json")
         json.dump(d, open(tmp, "w"))
         try:
@@ -88,7 +97,7 @@ def main():
         if r.returncode != 0:
             sys.exit(r.stdout + r.stderr)
         png = os.path.join(HERE, name + ".png")
-        if os.path.exists(png):
+        if os.path.exists(png) and not overrides.get("keep_png"):
             os.remove(png)
         print("wrote", name + ".pfm")
 

@@ -327,6 +327,76 @@ def test_full_size_other_configs_bit_exact(ta, oracle_py, gpu_ctx, tmp_path, con
     assert_bit_exact(got, ref, f"{config} at full size")
 
 
+def test_full_size_config_3_bit_exact(ta, oracle_py, gpu_ctx):
+    """BASELINE config 3 (the Cornell box with the Sobol' sampler, NEE towards its quad light) at its full 1000x563, every pixel, 32 spp."""
+    hs = ta.HostScene(scene_path("cornell-box/scene_sobol.json"))
+    assert (hs.res_x, hs.res_y) == (1000, 563)
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render(32, spp_step=16)
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 32, spp_step=16)
+    assert_bit_exact(got, ref, "config 3, 1000x563x32spp")
+
+
+@pytest.mark.parametrize("scene,res,begin,spp,step", [
+    ("materialtest/c2.json", (128, 72), 256, 32, 16),            # configs are quoted at 256..1024 spp: the second Sobol' block and beyond
+    ("materialtest/c2.json", (64, 36), 240, 48, 16),             # a render that crosses index 256 between two passes
+    ("materialtest/c2.json", (64, 36), 250, 12, 12),             # ... and inside one pass
+    ("cornell-box/scene_sobol.json", (96, 54), 1008, 16, 16),    # config 3's last pass
+    ("materialtest/c5.json", (64, 36), 1000, 24, 8),             # config 5's last passes (media, supplemental PCG per sample index)
+    ("instances/inst_mesh.json", (64, 36), 496, 16, 16),         # config 4's last pass
+    ("non-exponential/scene.json", (64, 64), 65536, 8, 8),       # far beyond any block
+])
+def test_sample_indices_past_256(ta, oracle_py, gpu_ctx, scene, res, begin, spp, step):
+    """SobolPathSampler::startPath (SobolPathSampler.hpp:47-52) splits the sample index: idx = (index & ~0xFF) | ((index + scramble) & 0xFF).
+    Every other GPU test stays inside the first block of 256; these start a render at a later index (what a resumed render does) and compare with
+    the oracle started at the same index -- itself pinned past 256 by c2_32x18_320spp.pfm."""
+    hs = ta.HostScene(scene_path(scene), resolution=res)
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render(spp, spp_step=step, spp_begin=begin)
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, spp, spp_step=step, spp_begin=begin)
+    assert_bit_exact(got, ref, f"{scene} samples [{begin}, {begin + spp})")
+
+
+def test_a_320_spp_render_matches_the_oracle(ta, oracle_py, gpu_ctx):
+    """One whole render across the block boundary, pool kept full by regeneration the way the benchmark runs: 64x36, 320 spp in 20 passes."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(64, 36))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render(320, spp_step=16)
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 320, spp_step=16)
+    assert_bit_exact(got, ref, "c2 64x36x320spp")
+
+
+def test_output_buffers_and_adaptive_passes_past_256(ta, oracle_py, gpu_ctx):
+    """The auxiliary buffers and an adaptive pass at sample indices >= 256 (per-tile sample offsets past the first Sobol' block)."""
+    hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(64, 36), output_buffers=["depth", ("normal", True, False), "albedo", ("visibility", False, True)])
+    assert hs.adaptive
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    var_w, var_h = (hs.res_x + 3)//4, (hs.res_y + 3)//4
+    idx = np.full(var_w*var_h, 250, np.uint32) + (np.arange(var_w*var_h) % 3).astype(np.uint32)*7   # tiles at 250, 257, 264
+    counts = (2 + (np.arange(var_w*var_h) % 9)).astype(np.uint32)                                  # 2..10 samples: some tiles cross 256
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render_pass_adaptive(idx, counts)
+    gpu_ctx.render_pass_adaptive(idx + counts, counts[::-1].copy())
+    gpu_ctx.wait()
+    got = gpu_ctx.download()
+    o = oracle_py.Oracle(hs, **oracle_py.GPU)
+    ref_bufs = o.bind_output_buffers(shard.n_pixels)
+    o_rgb = np.zeros((shard.n_pixels, 3), np.float32)
+    o_cnt = np.zeros(shard.n_pixels, np.uint32)
+    o_rec = np.zeros(var_w*var_h, ta.RECORD_DTYPE)
+    o.render_shard_adaptive(shard, idx, counts, o_rgb, o_cnt, o_rec)
+    o.render_shard_adaptive(shard, idx + counts, counts[::-1].copy(), o_rgb, o_cnt, o_rec)
+    assert_bit_exact(got, (o_rgb, o_cnt), "adaptive colour past 256")
+    _assert_outputs_bit_exact(gpu_ctx, ref_bufs, "adaptive past 256")
+    assert np.array_equal(gpu_ctx.download_records().view(np.uint32), o_rec.view(np.uint32))
+
+
 def test_image_matches_reference_golden_within_tolerance(ta, gpu_ctx):
     """GPU image vs the compiled reference's golden PFM: identical Sobol sequences, but the supplemental
     stream is path-local and t,u,v use IEEE division -> agreement is statistical, not bitwise."""
@@ -383,7 +453,8 @@ def test_cpp_host_integrator_cli(ta, oracle_py, tmp_path):
 def test_cli_resume_file_continues_a_render_bit_for_bit(ta, oracle_py, tmp_path):
     """Integrator::saveRenderResumeData / resumeRender on the reference's file layout (Integrator.cpp:108-162): 16 spp, then a second
     run that resumes to 32 spp, equals a straight 32-spp render in every bit; -r (restart) ignores the file; --timeout stops after a
-    pass; -i resolves resources; the reference's own resume file (tests/golden/next/RenderState_*.dat) loads with a hash warning."""
+    pass; -i resolves resources; a state file with another scene hash is refused (another scene's file in the same directory; the reference's own
+    file tests/golden/next/RenderState_*.dat) unless --accept-foreign-resume-file asks for it."""
     import json
     import shutil
     import struct
@@ -430,12 +501,26 @@ def test_cli_resume_file_continues_a_render_bit_for_bit(ta, oracle_py, tmp_path)
     c = tmp_path / "c"
     out, _ = run(64, "-r", "--timeout", "1ms", outdir=c)
     assert "Completed 16/64 spp" in out and "Completed 32/64 spp" not in out
-    # the reference's own file (c2 at 64x36, 32 spp): same layout; its scene hash is the reference's re-serialisation -> warning only
+    # scene B must not continue from scene A's state file (same directory, same default file name, same resolution and sampler flags):
+    # Integrator.cpp:146-148 refuses the hash, and so does this host -- B renders from 0 spp and its image is B's
+    d["bsdfs"][0]["albedo"] = 0.25 if d["bsdfs"][0].get("albedo") != 0.25 else 0.5
+    out, _ = run(32, outdir=a)
+    assert "Resume unsuccessful" in out and "Completed 16/32 spp" in out and "Completed 32/32 spp" in out
+    assert not np.array_equal(ta.load_pfm(a / "r.pfm"), straight)
+    d = json.load(open(scene_path("materialtest/c2.json")))
+    d["camera"]["resolution"] = [64, 36]
+    d["renderer"].update({"spp": 16, "spp_step": 16, "output_file": "r.png", "hdr_output_file": "r.pfm", "enable_resume_render": True,
+                          "resume_render_file": "RenderState.dat"})
+    # the reference's own file (c2 at 64x36, 32 spp): same layout, but its scene hash is the reference's re-serialisation of the scene
     e = tmp_path / "e"
     os.makedirs(e)
     shutil.copy(os.path.join(GOLDEN, "next", "RenderState_c2_64x36_32spp_step16.dat"), e / "RenderState.dat")
-    out, _ = run(32, outdir=e)
-    assert "Resume successful" in out and "Warning: the resume file was written for another scene text" in out
+    os.makedirs(tmp_path / "e_refused")
+    shutil.copy(os.path.join(GOLDEN, "next", "RenderState_c2_64x36_32spp_step16.dat"), tmp_path / "e_refused" / "RenderState.dat")
+    out, _ = run(32, outdir=tmp_path / "e_refused")
+    assert "Resume unsuccessful" in out                          # refused by default
+    out, _ = run(32, "--accept-foreign-resume-file", outdir=e)
+    assert "Resume successful" in out and "Warning: the resume file carries another scene hash" in out
     assert "Completed" not in out                                # 32 of 32 spp are in the file: nothing left to render
     got = ta.load_pfm(e / "r.pfm")
     want = ta.load_pfm(os.path.join(GOLDEN, "next", "RenderState_c2_64x36_32spp_step16.pfm"))

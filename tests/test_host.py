@@ -231,3 +231,23 @@ def test_unsupported_bitmap_files_fail_loudly(ta, tmp_path):
     path.write_text(json.dumps(d))
     with pytest.raises(RuntimeError, match="Unable to load texture"):
         ta.HostScene(str(path), resolution=(32, 18))
+
+
+@pytest.mark.parametrize("tonemap", ["linear", "gamma", "reinhard", "filmic", "pbrt"])
+def test_ldr_output_matches_the_reference_png(ta, tonemap, tmp_path):
+    """The LDR half of Integrator::writeBuffers (Integrator.cpp:56-80): Camera::tonemap (cameras/Tonemap.hpp:26-62: clamp at 0, the operator),
+    *255, truncate, clamp, PNG.  The compiled reference wrote tests/golden/tonemap_<op>_48x27_4spp.png NEXT TO the .pfm of the same render, so
+    this host's PFM -> PNG path, fed the reference's float image, has to reproduce the reference's PNG pixels byte for byte."""
+    from PIL import Image
+    from conftest import GOLDEN
+    name = f"tonemap_{tonemap}_48x27_4spp"
+    hdr = ta.load_pfm(os.path.join(GOLDEN, name + ".pfm"))
+    want = np.asarray(Image.open(os.path.join(GOLDEN, name + ".png")).convert("RGB"))
+    assert want.shape == hdr.shape == (27, 48, 3)
+    out = str(tmp_path / "out.png")
+    rgb = np.ascontiguousarray(hdr, np.float32)
+    rc = ta.host_lib().tgh_save_png_tonemapped(out.encode(), tonemap.encode(), rgb.ctypes.data_as(C.POINTER(C.c_float)), 48, 27)
+    assert rc == 0
+    got = np.asarray(Image.open(out).convert("RGB"))
+    assert np.array_equal(got, want), f"{int((got != want).any(axis=2).sum())} of {48*27} pixels differ from the reference's PNG"
+    assert len(np.unique(want)) > 50   # a real image, not a constant

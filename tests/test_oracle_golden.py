@@ -84,17 +84,17 @@ def test_oracle_matches_reference(ta, oracle_py, name, scene, res, spp):
     assert img.shape == ref.shape
     assert (cnt == spp).all()
     rmse = float(np.sqrt(((img - ref)**2).mean()))
-    exact = float((img == ref).all(axis=2).mean())
-    if name in EMBREE_DECIDED:
-        if intel_rcp(oracle_py):
-            assert exact == 1.0, f"{name}: {int(round((1.0 - exact)*img.shape[0]*img.shape[1]))} pixels differ from the reference"
-        else:
-            assert abs(float(img.mean())/float(ref.mean()) - 1.0) < 5e-3
-        return
-    # stated tolerance: image RMSE < 1e-4 on any host; bit-exact where RCPPS matches the fixture host
-    assert rmse < 1e-4, f"{name}: rmse {rmse}"
+    differing = int((img != ref).any(axis=2).sum())
     if intel_rcp(oracle_py):
-        assert exact == 1.0, f"{name}: only {exact:.5f} of the pixels are bit-identical to the reference"
+        # RCPPS as on the fixture host: the reference's image, every pixel, every bit
+        assert differing == 0, f"{name}: {differing} pixels differ from the reference (rmse {rmse:.3e})"
+        return
+    # Another reciprocal approximation: isolated decisions may flip (and, in EMBREE_DECIDED fixtures, desynchronise a tile's sequential PCG
+    # stream), so only statistical agreement can be asserted -- and the report shows that this weaker mode ran.
+    if name not in EMBREE_DECIDED:
+        assert rmse < 1e-4, f"{name}: rmse {rmse}"
+    assert abs(float(img.mean())/float(ref.mean()) - 1.0) < 5e-3
+    pytest.skip(f"RCPPS differs from the fixture host: {name} checked statistically only ({differing} pixels differ, rmse {rmse:.2e})")
 
 
 def test_oracle_adaptive_sampling_matches_reference(ta, oracle_py):
@@ -170,7 +170,7 @@ def test_golden_fixtures_match_their_manifest():
     on_disk = set()
     for root, _, files in os.walk(GOLDEN):
         for f in files:
-            if f.endswith((".pfm", ".dat")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json", "ref_kat4.json", "ref_kat5.npz"):
+            if f.endswith((".pfm", ".dat", ".png")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json", "ref_kat4.json", "ref_kat5.npz"):
                 on_disk.add(os.path.relpath(os.path.join(root, f), GOLDEN))
     assert on_disk == set(manifest), f"fixtures without manifest entry or vice versa: {sorted(on_disk ^ set(manifest))}"
     for name, digest in manifest.items():
@@ -211,10 +211,12 @@ def test_oracle_output_buffers_match_reference(ta, oracle_py, name, scene, res, 
         both_nan = np.isnan(ref) & np.isnan(got)
         same = (ref == got) | both_nan
         finite = np.isfinite(ref) & np.isfinite(got)
-        assert (np.isfinite(ref) == np.isfinite(got)).mean() > 0.999, file
-        assert float(np.sqrt(((ref - got)[finite]**2).mean())) < 1e-3*max(1.0, float(np.abs(ref[finite]).max())), file
-        if exact_host:
-            assert same.all(axis=2).mean() > 0.999, f"{file}: only {same.all(axis=2).mean():.5f} of the pixels are bit-identical"
+        if exact_host: # RCPPS as on the fixture host: every value of every file, NaN ("no sample") positions included
+            assert np.array_equal(np.isfinite(ref), np.isfinite(got)), file
+            assert same.all(), f"{file}: {int((~same.all(axis=2)).sum())} pixels differ from the reference"
+        else:          # another reciprocal approximation flips isolated decisions: statistical agreement only
+            assert (np.isfinite(ref) == np.isfinite(got)).mean() > 0.999, file
+            assert float(np.sqrt(((ref - got)[finite]**2).mean())) < 1e-3*max(1.0, float(np.abs(ref[finite]).max())), file
         checked += 1
 
     def mean_of(b, channels):

@@ -1435,8 +1435,13 @@ TG_DEV bool mixedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 // inline them; the tail kernels' translation units leave them out (TG_NO_NESTED_BSDFS: inlined into the whole-path kernel they
 // multiply its compile time, and out-of-line calls of functions this size fault on gfx950 with ROCm 7.2 -- measured, profiles/r02_ab_notes.txt),
 // and the launcher keeps scenes that use them out of the tail kernel (ctx->hasNested)
+#ifdef TG_NESTED_OUT_OF_LINE
+#define TG_NESTED_FN __device__ __noinline__
+#else
+#define TG_NESTED_FN TG_DEV
+#endif
 template <class SC>
-TG_DEV V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+TG_NESTED_FN V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
 {
     if (d.type == TGPU_BSDF_MIXED) { // MixedBsdf.cpp:104-108
         float ratio = texEval(sc, d.aux_tex, uvx, uvy).x;
@@ -1455,7 +1460,7 @@ TG_DEV V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &w
     return V3(0.0f);
 }
 template <class SC>
-TG_DEV float nestedPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+TG_NESTED_FN float nestedPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
 {
     if (d.type == TGPU_BSDF_MIXED) { // MixedBsdf.cpp:125-131
         float ratio;
@@ -1469,7 +1474,7 @@ TG_DEV float nestedPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 
     return 0.0f;
 }
 template <class SC>
-TG_DEV bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+TG_NESTED_FN bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
     if (d.type == TGPU_BSDF_MIXED) return mixedSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatSample(sc, d, e, s);

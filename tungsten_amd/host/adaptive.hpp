@@ -1,8 +1,14 @@
-// The work generator of PathTraceIntegrator (src/core/integrators/path_tracer/PathTraceIntegrator.cpp:44-134):
-// per 4x4-pixel variance tile a SampleRecord (path_tracer/SampleRecord.hpp:11-66) whose running statistics the
-// devices accumulate (k_accumulate_records); between passes the host turns them into the next pass' per-tile
-// sample counts.  Float operations keep the reference's order and width (the library is built with
-// -ffp-contract=off), the stochastic rounding consumes the integrator's own PCG stream after the tile seeds.
+// Pass scheduler of the path tracer: how many samples every 4x4-pixel variance tile gets in the next pass.
+//
+// Behaviour = the reference's generateWork and its helpers (src/core/integrators/path_tracer/PathTraceIntegrator.cpp:44-134 with
+// SampleRecord.hpp:11-66): below 16 spp every tile gets the pass's spp; from then on one sample per pixel is guaranteed and the rest of the
+// budget follows the tiles' relative error (variance of the tile mean over its squared mean), clipped at the 95th percentile, spread to the
+// four neighbours, and rounded stochastically with the integrator's own PCG stream (the draws after the tile seeds).  The devices own the
+// running statistics (k_accumulate_records); the host only sees them through setStatistics() between passes.
+//
+// Results must equal the reference's bit for bit (the sample counts decide which Sobol' indices exist), so every float operation keeps the
+// reference's order and width (-ffp-contract=off).  The data layout is this host's: one array per field (the device tables are exactly the
+// three statistics columns, the pass arguments exactly the index / next columns) instead of an array of records.
 #pragma once
 #include "../../include/tungsten_amd.h"
 #include "scene.hpp"
@@ -13,15 +19,10 @@
 
 namespace tungsten_amd {
 
-struct SampleRecord {
-    uint32_t sampleCount = 0, nextSampleCount = 0, sampleIndex = 0;
-    float adaptiveWeight = 0.0f, mean = 0.0f, runningVariance = 0.0f;
-    float variance() const { return runningVariance/float(sampleCount - 1u); }
-    float errorEstimate() const
-    {
-        float m = mean*mean;
-        return variance()/(float(sampleCount)*(m > 1e-3f ? m : 1e-3f)); // max(mean*mean, 1e-3f)
-    }
+// One tile's entry of the resume file (Integrator.cpp:108-129 writes the reference's 24-byte SampleRecord: these six words in this order).
+struct TileState { // an aggregate (this header is also compiled as C++11 inside the reference tree): value-initialise with TileState()
+    uint32_t sampleCount, nextSampleCount, sampleIndex;
+    float adaptiveWeight, mean, runningVariance;
 };
 
 class AdaptiveScheduler {
@@ -30,116 +31,109 @@ public:
 
     void init(uint32_t resX, uint32_t resY, uint32_t seed)
     {
-        _w = resX;
-        _h = resY;
-        // the integrator's sampler: seeded at :187, then one draw per 16x16 tile for the tile seeds (diceTiles :29-38)
-        _sampler = Pcg32(hash32(seed));
-        const uint32_t nTiles = ((resX + TileSize - 1)/TileSize)*((resY + TileSize - 1)/TileSize);
-        for (uint32_t i = 0; i < nTiles; ++i) (void)_sampler.nextI();
-        _varW = (resX + VarianceTileSize - 1)/VarianceTileSize; // :190-193
-        _varH = (resY + VarianceTileSize - 1)/VarianceTileSize;
-        _samples.assign(size_t(_varW)*_varH, SampleRecord{});
+        _pixels = int(resX)*int(resY);
+        _cols = (resX + VarianceTileSize - 1)/VarianceTileSize;
+        _rows = (resY + VarianceTileSize - 1)/VarianceTileSize;
+        const size_t n = size_t(_cols)*_rows;
+        _count.assign(n, 0u); _next.assign(n, 0u); _index.assign(n, 0u);
+        _weight.assign(n, 0.0f); _mean.assign(n, 0.0f); _m2.assign(n, 0.0f);
+        // the integrator's generator: seeded with hash32(seed), one draw per 16x16 image tile already spent on the tile seeds (:29-38,187)
+        _rng = Pcg32(hash32(seed));
+        const uint32_t imageTiles = ((resX + TileSize - 1)/TileSize)*((resY + TileSize - 1)/TileSize);
+        for (uint32_t i = 0; i < imageTiles; ++i) (void)_rng.nextI();
     }
 
-    uint32_t varW() const { return _varW; }
-    uint32_t varH() const { return _varH; }
-    std::vector<SampleRecord> &samples() { return _samples; }
-    const std::vector<SampleRecord> &samples() const { return _samples; }
+    uint32_t varW() const { return _cols; }
+    uint32_t varH() const { return _rows; }
+    size_t tileCount() const { return _count.size(); }
 
-    // True when the coming pass [currentSpp, nextSpp) consults the statistics, i.e. the caller has to
-    // bring the devices' records in with setStatistics() before generateWork().
+    // the pass [currentSpp, ...) is steered by the statistics: the caller brings the devices' tables in first
     static bool needsStatistics(bool adaptive, uint32_t currentSpp) { return adaptive && currentSpp >= AdaptiveThreshold; }
 
     void setStatistics(const tgpu_sample_record *table)
     {
-        for (size_t i = 0; i < _samples.size(); ++i) {
-            _samples[i].sampleCount = table[i].sample_count;
-            _samples[i].mean = table[i].mean;
-            _samples[i].runningVariance = table[i].running_variance;
-        }
+        for (size_t i = 0; i < _count.size(); ++i) { _count[i] = table[i].sample_count; _mean[i] = table[i].mean; _m2[i] = table[i].running_variance; }
     }
 
-    // generateWork (:110-134); false = converged, the pass renders nothing
+    // Decides the pass [currentSpp, nextSpp).  false: nothing left to refine (every tile's error is zero), the pass renders nothing.
     bool generateWork(uint32_t currentSpp, uint32_t nextSpp, bool adaptive)
     {
-        for (SampleRecord &r : _samples) r.sampleIndex += r.nextSampleCount;
-        int sppCount = int(nextSpp - currentSpp);
-        if (needsStatistics(adaptive, currentSpp)) {
-            float maxError = errorPercentile95();
-            if (maxError == 0.0f) return false;
-            for (SampleRecord &r : _samples) r.adaptiveWeight = r.adaptiveWeight < maxError ? r.adaptiveWeight : maxError; // min()
-            dilateAdaptiveWeights();
-            distributeAdaptiveSamples(sppCount);
-        } else {
-            for (SampleRecord &r : _samples) r.nextSampleCount = uint32_t(sppCount);
+        const size_t n = _count.size();
+        for (size_t i = 0; i < n; ++i) _index[i] += _next[i];
+        const int spp = int(nextSpp - currentSpp);
+        if (!needsStatistics(adaptive, currentSpp)) {
+            std::fill(_next.begin(), _next.end(), uint32_t(spp));
+            return true;
+        }
+        // relative error of every tile; its 95th percentile over the tiles that have one caps the weights
+        std::vector<float> ranked;
+        ranked.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float variance = _m2[i]/float(_count[i] - 1u);
+            const float meanSq = _mean[i]*_mean[i];
+            _weight[i] = variance/(float(_count[i])*(meanSq > 1e-3f ? meanSq : 1e-3f));
+            if (_weight[i] > 0.0f) ranked.push_back(_weight[i]);
+        }
+        if (ranked.empty()) return false;
+        std::sort(ranked.begin(), ranked.end());
+        const float cap = ranked[(ranked.size()*95)/100];
+        if (cap == 0.0f) return false;
+        for (float &w : _weight) w = w < cap ? w : cap;
+        // a tile takes the larger weight of its neighbours: one sweep pulling from below and right, one from above and left (in place, so weights travel)
+        pullFromNeighbours(+1);
+        pullFromNeighbours(-1);
+        // one sample per pixel is fixed; the others are shared out in proportion to the weights, fractions carried from tile to tile
+        double weightSum = 0.0;
+        for (float w : _weight) weightSum += w;
+        const int perTile = ((spp - 1)*_pixels)/int(VarianceTileSize*VarianceTileSize);
+        const float samplesPerWeight = float(double(perTile)/weightSum);
+        float carry = 0.0f;
+        for (size_t i = 0; i < n; ++i) {
+            const float share = _weight[i]*samplesPerWeight;
+            int whole = int(share);
+            carry += share - float(whole);
+            if (_rng.next1D() < carry) {
+                whole++;
+                carry -= 1.0f;
+            }
+            _next[i] = uint32_t(whole + 1);
         }
         return true;
     }
 
-    void passArrays(std::vector<uint32_t> &sampleIndex, std::vector<uint32_t> &sampleCount) const
+    // arguments of tgpu_render_pass_adaptive
+    void passArrays(std::vector<uint32_t> &sampleIndex, std::vector<uint32_t> &sampleCount) const { sampleIndex = _index; sampleCount = _next; }
+
+    TileState tile(size_t i) const { return TileState{_count[i], _next[i], _index[i], _weight[i], _mean[i], _m2[i]}; }
+    void setTile(size_t i, const TileState &t)
     {
-        sampleIndex.resize(_samples.size());
-        sampleCount.resize(_samples.size());
-        for (size_t i = 0; i < _samples.size(); ++i) {
-            sampleIndex[i] = _samples[i].sampleIndex;
-            sampleCount[i] = _samples[i].nextSampleCount;
-        }
+        _count[i] = t.sampleCount; _next[i] = t.nextSampleCount; _index[i] = t.sampleIndex;
+        _weight[i] = t.adaptiveWeight; _mean[i] = t.mean; _m2[i] = t.runningVariance;
     }
 
 private:
-    float errorPercentile95() // :44-59
+    // dir = +1: rows top to bottom, tiles left to right, each taking max(self, tile below, tile to the right); dir = -1: the mirror image
+    void pullFromNeighbours(int dir)
     {
-        std::vector<float> errors;
-        errors.reserve(_samples.size());
-        for (SampleRecord &r : _samples) {
-            r.adaptiveWeight = r.errorEstimate();
-            if (r.adaptiveWeight > 0.0f) errors.push_back(r.adaptiveWeight);
-        }
-        if (errors.empty()) return 0.0f;
-        std::sort(errors.begin(), errors.end());
-        return errors[(errors.size()*95)/100];
-    }
-
-    void dilateAdaptiveWeights() // :61-85
-    {
-        auto grow = [](float &a, float b) { a = a > b ? a : b; }; // Tungsten::max (MathUtil.hpp:22-26)
-        for (uint32_t y = 0; y < _varH; ++y)
-            for (uint32_t x = 0; x < _varW; ++x) {
-                size_t idx = x + size_t(y)*_varW;
-                if (y < _varH - 1) grow(_samples[idx].adaptiveWeight, _samples[idx + _varW].adaptiveWeight);
-                if (x < _varW - 1) grow(_samples[idx].adaptiveWeight, _samples[idx + 1].adaptiveWeight);
+        const int cols = int(_cols), rows = int(_rows);
+        for (int r = 0; r < rows; ++r) {
+            const int y = dir > 0 ? r : rows - 1 - r;
+            const bool hasRow = dir > 0 ? y < rows - 1 : y > 0;
+            for (int c = 0; c < cols; ++c) {
+                const int x = dir > 0 ? c : cols - 1 - c;
+                const bool hasCol = dir > 0 ? x < cols - 1 : x > 0;
+                float &w = _weight[size_t(x) + size_t(y)*_cols];
+                if (hasRow) { const float o = _weight[size_t(x) + size_t(y + dir)*_cols]; w = w > o ? w : o; }
+                if (hasCol) { const float o = _weight[size_t(x + dir) + size_t(y)*_cols]; w = w > o ? w : o; }
             }
-        for (int y = int(_varH) - 1; y >= 0; --y)
-            for (int x = int(_varW) - 1; x >= 0; --x) {
-                size_t idx = size_t(x) + size_t(y)*_varW;
-                if (y > 0) grow(_samples[idx].adaptiveWeight, _samples[idx - _varW].adaptiveWeight);
-                if (x > 0) grow(_samples[idx].adaptiveWeight, _samples[idx - 1].adaptiveWeight);
-            }
-    }
-
-    void distributeAdaptiveSamples(int spp) // :87-108
-    {
-        double totalWeight = 0.0;
-        for (SampleRecord &r : _samples) totalWeight += r.adaptiveWeight;
-        int adaptiveBudget = (spp - 1)*int(_w)*int(_h);
-        int budgetPerTile = adaptiveBudget/int(VarianceTileSize*VarianceTileSize);
-        float weightToSampleFactor = float(double(budgetPerTile)/totalWeight);
-        float pixelPdf = 0.0f;
-        for (SampleRecord &r : _samples) {
-            float fractionalSamples = r.adaptiveWeight*weightToSampleFactor;
-            int adaptiveSamples = int(fractionalSamples);
-            pixelPdf += fractionalSamples - float(adaptiveSamples);
-            if (_sampler.next1D() < pixelPdf) {
-                adaptiveSamples++;
-                pixelPdf -= 1.0f;
-            }
-            r.nextSampleCount = uint32_t(adaptiveSamples + 1);
         }
     }
 
-    uint32_t _w = 0, _h = 0, _varW = 0, _varH = 0;
-    std::vector<SampleRecord> _samples;
-    Pcg32 _sampler;
+    int _pixels = 0;
+    uint32_t _cols = 0, _rows = 0;
+    std::vector<uint32_t> _count, _next, _index;   // samples a tile has, gets in the coming pass, and the first sample index of that pass
+    std::vector<float> _weight, _mean, _m2;        // adaptive weight; running mean and sum of squared deviations of the tile's samples
+    Pcg32 _rng;
 };
 
 } // namespace tungsten_amd

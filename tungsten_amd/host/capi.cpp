@@ -103,7 +103,7 @@ tgh_adaptive *tgh_adaptive_create(uint32_t resX, uint32_t resY, uint32_t seed)
     return a;
 }
 void tgh_adaptive_free(tgh_adaptive *a) { delete a; }
-uint32_t tgh_adaptive_tiles(const tgh_adaptive *a) { return uint32_t(a->work.samples().size()); }
+uint32_t tgh_adaptive_tiles(const tgh_adaptive *a) { return uint32_t(a->work.tileCount()); }
 int tgh_adaptive_needs_statistics(int adaptive, uint32_t currentSpp) { return AdaptiveScheduler::needsStatistics(adaptive != 0, currentSpp); }
 void tgh_adaptive_set_statistics(tgh_adaptive *a, const tgpu_sample_record *table) { a->work.setStatistics(table); }
 // returns 1 and fills sampleIndex/sampleCount (one entry per variance tile) when the pass has work, else 0

@@ -132,15 +132,29 @@ void Integrator::saveOutputBuffers()
     }
 }
 
-void Integrator::writeBuffers(const std::string &suffix, bool /*overwrite*/)
+void Integrator::writeBuffers(const std::string &suffix, bool overwrite)
 {
     std::vector<float> hdr;
     frameBuffer(hdr);
     const RendererSettings &r = _scene->renderer;
-    auto withSuffix = [&](const std::string &file) {
+    // Where an image goes: the configured name with the suffix in front of its extension; with overwrite_output_files off, the first of
+    // name, name001, name002, ... that does not exist yet (the stock scenes ship that way: a re-render keeps the earlier images).  Same names
+    // as the reference's incrementalFilename (Integrator.cpp:24-38).
+    auto target = [&](const std::string &file) {
+        size_t slash = file.find_last_of("/\\");
         size_t dot = file.find_last_of('.');
-        return dot == std::string::npos ? file + suffix : file.substr(0, dot) + suffix + file.substr(dot);
+        if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) dot = file.size();
+        const std::string stem = file.substr(0, dot) + suffix, extension = file.substr(dot);
+        std::string path = stem + extension;
+        if (overwrite) return path;
+        char number[16];
+        for (int index = 1; std::ifstream(path).good(); ++index) {
+            std::snprintf(number, sizeof(number), "%03d", index);
+            path = stem + number + extension;
+        }
+        return path;
     };
+    auto withSuffix = target;
     int w = int(_scene->resX), h = int(_scene->resY);
     if (!r.outputFile.empty()) {
         std::vector<uint8_t> ldr;
@@ -219,7 +233,7 @@ void Integrator::saveRenderResumeData()
     saveState(out);
 }
 
-bool Integrator::resumeRender(bool *hashMismatch)
+bool Integrator::resumeRender(bool acceptForeignHash, bool *hashMismatch)
 {
     if (hashMismatch) *hashMismatch = false;
     std::ifstream in(_scene->renderer.resumeRenderFile, std::ios::binary);
@@ -240,7 +254,10 @@ bool Integrator::resumeRender(bool *hashMismatch)
     uint64_t jsonHash = 0;
     in.read(reinterpret_cast<char *>(&jsonHash), sizeof(jsonHash));
     if (!in) return false;
-    if (jsonHash != sceneHash(*_scene) && hashMismatch) *hashMismatch = true; // see the header comment: a warning, not a refusal
+    if (jsonHash != sceneHash(*_scene)) { // Integrator.cpp:146-148: a state file of another scene is not this render's past
+        if (!acceptForeignHash) return false;
+        if (hashMismatch) *hashMismatch = true;
+    }
     const size_t nPixels = size_t(_scene->resX)*_scene->resY;
     struct Part { int type, part; std::vector<uint32_t> words; };
     std::vector<Part> parts;
@@ -344,7 +361,7 @@ void PathTraceIntegrator::startRender(std::function<void()> completionCallback)
 // Bring the SampleRecords the devices accumulated (k_accumulate_records) back to the host table.
 void PathTraceIntegrator::collectRecords()
 {
-    std::vector<tgpu_sample_record> table(_work.samples().size(), tgpu_sample_record{0, 0.0f, 0.0f});
+    std::vector<tgpu_sample_record> table(_work.tileCount(), tgpu_sample_record{0, 0.0f, 0.0f});
     for (Device &d : _devices) check(d.ctx, tgpu_download_records(d.ctx, table.data()), "tgpu_download_records");
     if (_world > 1) recordExchange(table);
     _work.setStatistics(table.data());
@@ -443,10 +460,10 @@ void PathTraceIntegrator::uploadOutputPart(int type, int part, const std::vector
 void PathTraceIntegrator::saveState(std::ostream &out)
 {
     if (_scene->renderer.useAdaptiveSampling) collectRecords(); // mean / variance live on the devices between passes
-    for (const SampleRecord &r : _work.samples()) {
+    for (size_t i = 0; i < _work.tileCount(); ++i) {
         // without adaptive_sampling the devices keep no SampleRecords (the reference updates them regardless but never reads
         // them then): the counters are filled in, mean and variance stay 0
-        SampleRecord w = r;
+        TileState w = _work.tile(i);
         if (!_scene->renderer.useAdaptiveSampling) w.sampleCount = 0;
         out.write(reinterpret_cast<const char *>(&w.sampleCount), 4);
         out.write(reinterpret_cast<const char *>(&w.nextSampleCount), 4);
@@ -465,8 +482,8 @@ void PathTraceIntegrator::saveState(std::ostream &out)
 
 bool PathTraceIntegrator::loadState(std::istream &in)
 {
-    std::vector<SampleRecord> records(_work.samples().size());
-    for (SampleRecord &r : records) {
+    std::vector<TileState> records(_work.tileCount(), TileState());
+    for (TileState &r : records) {
         in.read(reinterpret_cast<char *>(&r.sampleCount), 4);
         in.read(reinterpret_cast<char *>(&r.nextSampleCount), 4);
         in.read(reinterpret_cast<char *>(&r.sampleIndex), 4);
@@ -483,7 +500,7 @@ bool PathTraceIntegrator::loadState(std::istream &in)
         if (!in) return false;
         if (seed != expect) return false; // rendered with another seed: its samples do not continue this render's sequences
     }
-    _work.samples() = records;
+    for (size_t i = 0; i < records.size(); ++i) _work.setTile(i, records[i]);
     if (_scene->renderer.useAdaptiveSampling) {
         std::vector<tgpu_sample_record> table(records.size());
         for (size_t i = 0; i < records.size(); ++i) table[i] = tgpu_sample_record{records[i].sampleCount, records[i].mean, records[i].runningVariance};

@@ -36,9 +36,12 @@ public:
     // {current_spp, adaptive_sampling, stratified_sampler} + NUL, a 64-bit scene hash, the colour buffer (RGB float32 per pixel,
     // then uint32 sample counts), then the integrator's saveState()/loadState() block.  The hash is BitManip::hash (65599
     // polynomial) of THIS loader's scene text without its "renderer" member -- the reference hashes its own re-serialisation of
-    // the scene, which only it can produce -- so a file written by the reference loads with a warning (`hashMismatch`), not an error.
+    // the scene, which only it can produce.  A file whose hash differs is REFUSED, as the reference refuses it (Integrator.cpp:146-148): the
+    // default file name is shared by every scene of a directory, and another scene's buffers of the same size would otherwise load -- and, if
+    // complete, be saved as this scene's image.  `acceptForeignHash` (CLI: --accept-foreign-resume-file) is the explicit opt-in for a file
+    // written by the reference renderer for the same scene; `hashMismatch` reports that the opt-in was needed.
     void saveRenderResumeData();
-    bool resumeRender(bool *hashMismatch = nullptr);
+    bool resumeRender(bool acceptForeignHash = false, bool *hashMismatch = nullptr);
 
     bool done() const { return _currentSpp >= _spp; }       // Integrator.hpp:52-55
     uint32_t currentSpp() const { return _currentSpp; }
@@ -90,7 +93,7 @@ public:
     bool supportsResumeRender() const override { return true; }
 
     // SampleRecords (adaptive.hpp), one per 4x4 variance tile of the whole image
-    const std::vector<SampleRecord> &sampleRecords() const { return _work.samples(); }
+    const AdaptiveScheduler &scheduler() const { return _work; }   // the SampleRecord columns (tile(i)) and what the next pass will get
     // Multi-process renders with adaptive sampling: called once per pass with the whole-image
     // {sampleCount, mean, runningVariance} table holding this process' variance tiles; must fill in the
     // other ranks' tiles (an all-reduce/all-gather; tungsten_amd/dist.py does it over torch.distributed).

@@ -59,44 +59,61 @@ std::string Scene::assetDir()
 }
 
 // ---------------------------------------------------------------------------
-// transform parsing (JsonPtr.cpp:91-186)
+// transform parsing.  Behaviour = the reference's fromJson(Mat4f) (JsonPtr.cpp:91-186): a 16-number array, or an object
+// {position, look_at | x_axis / y_axis / z_axis / up, scale, rotation}.  The arithmetic order is the reference's (the camera and every
+// primitive frame come out of here, bit for bit); the structure is this loader's: a frame of three axes, a bit mask of the axes the file
+// gives, and one table saying in which order the axes are made orthonormal.
 // ---------------------------------------------------------------------------
-static Vec3 randomOrtho(const Vec3 &a)
-{
-    Vec3 res;
-    if (std::abs(a.x) > std::abs(a.y))
-        res = Vec3(0.0f, 1.0f, 0.0f);
-    else
-        res = Vec3(1.0f, 0.0f, 0.0f);
-    return a.cross(res).normalized();
-}
+namespace {
 
-static void gramSchmidt(Vec3 &a, Vec3 &b, Vec3 &c)
-{
-    a.normalize();
-    b -= a*a.dot(b);
-    if (b.lengthSq() < 1e-5)
-        b = randomOrtho(a);
-    else
-        b.normalize();
+struct AxisFrame {
+    Vec3 axis[3] = {Vec3(1.0f, 0.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), Vec3(0.0f, 0.0f, 1.0f)};
+    unsigned given = 0; // bit k: axis k comes from the file
 
-    c -= a*a.dot(c);
-    c -= b*b.dot(c);
-    if (c.lengthSq() < 1e-5)
-        c = a.cross(b);
-    else
-        c.normalize();
-}
+    bool read(const Json &v, const char *key, int k)
+    {
+        float t[3];
+        if (!v.getVec(key, t, 3)) return false;
+        axis[k] = Vec3(t[0], t[1], t[2]);
+        given |= 1u << k;
+        return true;
+    }
 
-static bool getVec3(const Json &v, const char *key, Vec3 &dst)
-{
-    float tmp[3];
-    if (!v.getVec(key, tmp, 3)) return false;
-    dst = Vec3(tmp[0], tmp[1], tmp[2]);
-    return true;
-}
+    // Orthonormal frame from (first, second, third): `first` keeps its direction, `second` loses its component along it, `third` along both.
+    // An axis that degenerates (squared length under 1e-5) is replaced: the second by a perpendicular of the first built from the
+    // coordinate axis the first is less aligned with, the third by first x second.
+    void orthonormalise(int first, int second, int third)
+    {
+        Vec3 &a = axis[first], &b = axis[second], &c = axis[third];
+        a.normalize();
+        b -= a*a.dot(b);
+        if (b.lengthSq() < 1e-5) {
+            Vec3 helper = std::abs(a.x) > std::abs(a.y) ? Vec3(0.0f, 1.0f, 0.0f) : Vec3(1.0f, 0.0f, 0.0f);
+            b = a.cross(helper).normalized();
+        } else {
+            b.normalize();
+        }
+        c -= a*a.dot(c);
+        c -= b*b.dot(c);
+        if (c.lengthSq() < 1e-5) c = a.cross(b);
+        else c.normalize();
+    }
+};
 
-static Mat4 parseTransform(const Json &v)
+// index = mask of given axes (x = 1, y = 2, z = 4) -> the order (first, second, third) in which they are orthonormalised: given axes lead,
+// z before y before x among equals, except that a lone x is followed by z (JsonPtr.cpp:134-144)
+constexpr int kAxisOrder[8][3] = {
+    {2, 1, 0}, // nothing given
+    {0, 2, 1}, // x
+    {1, 2, 0}, // y
+    {1, 0, 2}, // x y
+    {2, 1, 0}, // z
+    {2, 0, 1}, // x z
+    {2, 1, 0}, // y z
+    {2, 1, 0}, // x y z
+};
+
+Mat4 parseTransform(const Json &v)
 {
     if (v.isArray()) {
         if (v.size() != 16) throw JsonLoadException("Trying to parse a matrix, but this array has the wrong size");
@@ -106,55 +123,37 @@ static Mat4 parseTransform(const Json &v)
     }
     if (!v.isObject()) throw JsonLoadException("Parameter has wrong type: Expecting a matrix value here");
 
-    Vec3 x(1.0f, 0.0f, 0.0f), y(0.0f, 1.0f, 0.0f), z(0.0f, 0.0f, 1.0f);
-    Vec3 pos(0.0f);
-    getVec3(v, "position", pos);
+    float p[3] = {0.0f, 0.0f, 0.0f};
+    v.getVec("position", p, 3);
+    const Vec3 origin(p[0], p[1], p[2]);
 
-    bool explicitX = false, explicitY = false, explicitZ = false;
-    Vec3 lookAt;
-    if (getVec3(v, "look_at", lookAt)) {
-        z = lookAt - pos;
-        explicitZ = true;
-    }
-    explicitY = getVec3(v, "up", y);
-    explicitX = getVec3(v, "x_axis", x) || explicitX;
-    explicitY = getVec3(v, "y_axis", y) || explicitY;
-    explicitZ = getVec3(v, "z_axis", z) || explicitZ;
+    AxisFrame f;
+    if (f.read(v, "look_at", 2)) f.axis[2] = f.axis[2] - origin; // the view direction; an explicit z_axis below overrides it
+    f.read(v, "up", 1);
+    f.read(v, "x_axis", 0);
+    f.read(v, "y_axis", 1);
+    f.read(v, "z_axis", 2);
 
-    int id = (explicitZ ? 4 : 0) + (explicitY ? 2 : 0) + (explicitX ? 1 : 0);
-    switch (id) {
-    case 0: gramSchmidt(z, y, x); break;
-    case 1: gramSchmidt(x, z, y); break;
-    case 2: gramSchmidt(y, z, x); break;
-    case 3: gramSchmidt(y, x, z); break;
-    case 4: gramSchmidt(z, y, x); break;
-    case 5: gramSchmidt(z, x, y); break;
-    case 6: gramSchmidt(z, y, x); break;
-    case 7: gramSchmidt(z, y, x); break;
+    const int *order = kAxisOrder[f.given];
+    f.orthonormalise(order[0], order[1], order[2]);
+    if (f.axis[0].cross(f.axis[1]).dot(f.axis[2]) < 0.0f) { // left-handed: flip the first axis the file did not give (z if it gave all three)
+        int flip = 2;
+        for (int k = 0; k < 2; ++k)
+            if (!(f.given & (1u << k))) { flip = k; break; }
+        f.axis[flip] = -f.axis[flip];
     }
-    if (x.cross(y).dot(z) < 0.0f) {
-        if (!explicitX)
-            x = -x;
-        else if (!explicitY)
-            y = -y;
-        else
-            z = -z;
+    float t[3];
+    if (v.getVec("scale", t, 3))
+        for (int k = 0; k < 3; ++k) f.axis[k] *= t[k];
+    if (v.getVec("rotation", t, 3)) {
+        const Mat4 turn = Mat4::rotYXZ(Vec3(t[0], t[1], t[2]));
+        for (int k = 0; k < 3; ++k) f.axis[k] = turn*f.axis[k];
     }
-    Vec3 scale;
-    if (getVec3(v, "scale", scale)) {
-        x *= scale.x;
-        y *= scale.y;
-        z *= scale.z;
-    }
-    Vec3 rot;
-    if (getVec3(v, "rotation", rot)) {
-        Mat4 tform = Mat4::rotYXZ(rot);
-        x = tform*x;
-        y = tform*y;
-        z = tform*z;
-    }
-    return Mat4(x[0], y[0], z[0], pos[0], x[1], y[1], z[1], pos[1], x[2], y[2], z[2], pos[2], 0.0f, 0.0f, 0.0f, 1.0f);
+    const Vec3 &x = f.axis[0], &y = f.axis[1], &z = f.axis[2];
+    return Mat4(x[0], y[0], z[0], origin[0], x[1], y[1], z[1], origin[1], x[2], y[2], z[2], origin[2], 0.0f, 0.0f, 0.0f, 1.0f);
 }
+
+} // namespace
 
 // ---------------------------------------------------------------------------
 // resources

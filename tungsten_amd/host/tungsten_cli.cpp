@@ -1,6 +1,7 @@
 // `tungsten_amd` -- the StandaloneRenderer loop of the reference CLI (src/tungsten/Shared.hpp:191-337)
 // on top of the MI355X integrator:  load scene -> flatten -> pass loop -> outputs.
-//   tungsten_amd [--spp N] [-s seed] [-o out.png] [-e out.pfm] [-d outdir] [-i indir] [-c interval] [--timeout t] [-r] [--gpus a,b,..] [--pools K] scene.json...
+//   tungsten_amd [--spp N] [-s seed] [-o out.png] [-e out.pfm] [-d outdir] [-i indir] [-c interval] [--timeout t] [-r] [--accept-foreign-resume-file]
+//                [--gpus a,b,..] [--pools K] scene.json...
 // -c / --timeout / -r / -i and the resume file are the reference's (Shared.hpp:134-145,262-319, Integrator.cpp:108-162).
 // --pools K (default 2): path pools per GPU, each a context on its own HIP stream; the image tiles are dealt over all
 // pools, which fill each other's kernel tails and host round trips (+10 % measured, same image bit for bit).
@@ -15,34 +16,39 @@
 
 using namespace tungsten_amd;
 
-// StringUtils::parseDuration (io/StringUtils.cpp:14-48): "90", "1.5h", "2m 30s", "500ms"; a bare number means minutes
-static double parseDuration(const std::string &str)
+// Durations of -c / --timeout (and of "checkpoint_interval" / "timeout" in a scene file): a sum of <number><unit> terms such as "90", "1.5h",
+// "2m 30s" or "500ms".  Units are recognised by their first letters in either case; a number without a unit counts minutes -- the reference's
+// convention (io/StringUtils.cpp:14-48), kept so that existing command lines mean the same.  Returns seconds.
+static double parseDuration(const std::string &text)
 {
-    double result = 0.0;
-    const char *buf = str.c_str(), *end = buf + str.size();
-    while (buf < end) {
-        char *next;
-        double number = std::strtod(buf, &next);
-        if (next == buf) break;
-        while (next < end && std::isspace(*next)) next++;
-        double unit = 60.0;
-        if (std::tolower(*next) == 'm' && std::tolower(*(next + 1)) == 's') unit = 0.001;
-        else if (std::tolower(*next) == 's') unit = 1.0;
-        else if (std::tolower(*next) == 'm') unit = 60.0;
-        else if (std::tolower(*next) == 'h') unit = 60.0*60.0;
-        else if (std::tolower(*next) == 'd') unit = 24.0*60.0*60.0;
-        result += number*unit;
-        while (next < end && std::isalpha(*next)) next++;
-        buf = next;
+    struct Unit { const char *letters; double seconds; };
+    static const Unit kUnits[] = {{"ms", 1e-3}, {"s", 1.0}, {"m", 60.0}, {"h", 3600.0}, {"d", 86400.0}}; // "ms" has to be tried before "m"
+    auto startsWith = [](const char *at, const char *letters) {
+        for (; *letters; ++letters, ++at)
+            if (std::tolower(static_cast<unsigned char>(*at)) != *letters) return false;
+        return true;
+    };
+    double seconds = 0.0;
+    const char *at = text.c_str();
+    for (;;) {
+        char *afterNumber;
+        const double value = std::strtod(at, &afterNumber);
+        if (afterNumber == at) return seconds; // no further term
+        at = afterNumber;
+        while (std::isspace(static_cast<unsigned char>(*at))) ++at;
+        double scale = 60.0;
+        for (const Unit &u : kUnits)
+            if (startsWith(at, u.letters)) { scale = u.seconds; break; }
+        seconds += value*scale;
+        while (std::isalpha(static_cast<unsigned char>(*at))) ++at; // the rest of the unit's name ("min", "hours", ...)
     }
-    return result;
 }
 
 int main(int argc, char **argv)
 {
     uint32_t spp = 0, seed = 0xBA5EBA11u; // default seed: Shared.hpp:246-248
     std::string outPng, outPfm, outDir, inDir, checkpointArg, timeoutArg;
-    bool restart = false, haveCheckpoint = false, haveTimeout = false;
+    bool restart = false, haveCheckpoint = false, haveTimeout = false, acceptForeignResume = false;
     std::vector<int> gpus = {0};
     int pools = 2;
     std::vector<std::string> scenes;
@@ -58,11 +64,12 @@ int main(int argc, char **argv)
         else if (a == "-c" || a == "--checkpoint") { checkpointArg = next(); haveCheckpoint = true; }
         else if (a == "--timeout") { timeoutArg = next(); haveTimeout = true; }
         else if (a == "-r" || a == "--restart") restart = true;
+        else if (a == "--accept-foreign-resume-file") acceptForeignResume = true; // a state file whose scene hash is not this loader's (the reference's)
         else if (a == "-t" || a == "--threads") next(); // host threads: meaningless here, accepted for compatibility
         else if (a == "--gpus") { gpus.clear(); std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) gpus.push_back(std::atoi(t.c_str())); }
         else if (a == "--pools") pools = std::max(1, std::atoi(next().c_str()));
         else if (a == "-h" || a == "--help") {
-            std::printf("usage: tungsten_amd [--spp N] [-s seed] [-o png] [-e pfm] [-d outdir] [-i indir] [-c checkpoint-interval] [--timeout duration] [-r]\n"
+            std::printf("usage: tungsten_amd [--spp N] [-s seed] [-o png] [-e pfm] [-d outdir] [-i indir] [-c checkpoint-interval] [--timeout duration] [-r] [--accept-foreign-resume-file]\n"
                         "                    [--gpus 0,1,..] [--pools K] scene.json...\n");
             return 0;
         }
@@ -97,8 +104,8 @@ int main(int argc, char **argv)
             if (resume && !restart) { // Shared.hpp:267-278
                 std::printf("Trying to resume render from saved state... \n");
                 bool hashMismatch = false;
-                if (integrator.resumeRender(&hashMismatch)) {
-                    if (hashMismatch) std::printf("Warning: the resume file was written for another scene text (or by the reference renderer, whose scene hash this loader cannot reproduce)\n");
+                if (integrator.resumeRender(acceptForeignResume, &hashMismatch)) {
+                    if (hashMismatch) std::printf("Warning: the resume file carries another scene hash (written by the reference renderer, or for another scene text); accepted on request\n");
                     std::printf("Resume successful\n");
                 } else {
                     std::printf("Resume unsuccessful. Starting from 0 spp\n");

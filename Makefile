@@ -41,7 +41,16 @@ $(CORE_LIB): $(CORE_OBJ)
 $(ORACLE_LIB): oracle/oracle.cpp oracle/oracle.h include/tungsten_amd.h include/tgpu_math.h
 	$(CXX) -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -mfma -shared -o $@ oracle/oracle.cpp -lpthread
 
+# host sanitizer build: the loader and its hand-written decoders under ASan + UBSan, CPU only.
+# build/asan/host_check <scene.json>... loads and flattens each scene; tests/test_host.py feeds it damaged inputs.
+ASAN_FLAGS := -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -ffp-contract=off \
+              -DTUNGSTEN_AMD_DEFAULT_ASSETS='"$(ROOT)/assets"'
+asan: build/asan/host_check
+build/asan/host_check: tungsten_amd/host/host_check.cpp tungsten_amd/host/scene.cpp $(wildcard tungsten_amd/host/*.hpp) include/tungsten_amd.h
+	@mkdir -p build/asan
+	$(CXX) $(ASAN_FLAGS) -o $@ tungsten_amd/host/host_check.cpp tungsten_amd/host/scene.cpp -lpthread
+
 clean:
 	rm -f $(HOST_LIB) $(CORE_LIB) $(ORACLE_LIB) $(CLI_BIN)
 	rm -rf build/core
-.PHONY: all host core oracle cli clean
+.PHONY: all host core oracle cli clean asan

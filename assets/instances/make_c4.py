@@ -11,7 +11,10 @@ line renderer cannot render file-backed mesh masters (Instance::fromJson instant
 calls loadResources() on them: the master stays empty and TriangleMesh::intersect dereferences a null Embree
 scene -- DESIGN.md section 7b), so for this scene the oracle, not a reference image, is the checker.
 
-usage: make_c4.py OUTDIR [n_per_axis=10] [res_x res_y]
+usage: make_c4.py OUTDIR [n_per_axis=10] [res_x res_y] [--flat]
+
+--flat additionally writes c4_flat.json: the same spheres baked into ONE mesh (n^3 x 10 000 triangles in c4_flat.wo3, two materials through the
+triangles' material index) -- the flat soup the device-side BVH builder (tungsten_amd/csrc/bvh_gpu.h) exists for.  Needs numpy.
 """
 import json
 import math
@@ -65,7 +68,38 @@ def write_sphere(path, slices=100, stacks=51):
     return len(verts), len(tris)
 
 
+def write_flat(out, instances, scene):
+    import numpy as np
+    raw = open(os.path.join(out, "sphere10k.wo3"), "rb").read()
+    nv = struct.unpack_from("<Q", raw, 0)[0]
+    verts = np.frombuffer(raw, np.float32, nv*8, 8).reshape(nv, 8)
+    nt = struct.unpack_from("<Q", raw, 8 + nv*32)[0]
+    tris = np.frombuffer(raw, np.uint32, nt*4, 16 + nv*32).reshape(nt, 4)
+    all_v = np.empty((len(instances), nv, 8), np.float32)
+    all_t = np.empty((len(instances), nt, 4), np.uint32)
+    for k, inst in enumerate(instances):
+        rx, ry, rz = (math.radians(a) for a in inst["transform"]["rotation"])
+        cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+        rot = (np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]) @ np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])).astype(np.float32)
+        all_v[k, :, 0:3] = verts[:, 0:3] @ rot.T + np.array(inst["transform"]["position"], np.float32)
+        all_v[k, :, 3:6] = verts[:, 3:6] @ rot.T
+        all_v[k, :, 6:8] = verts[:, 6:8]
+        all_t[k, :, 0:3] = tris[:, 0:3] + k*nv
+        all_t[k, :, 3] = inst["id"]
+    with open(os.path.join(out, "c4_flat.wo3"), "wb") as f:
+        f.write(struct.pack("<Q", len(instances)*nv)); all_v.tofile(f)
+        f.write(struct.pack("<Q", len(instances)*nt)); all_t.tofile(f)
+    flat = json.loads(json.dumps(scene))
+    flat["primitives"][0] = {"type": "mesh", "file": "c4_flat.wo3", "smooth": True, "bsdf": ["diffuse", "metal"], "transform": {}}
+    flat["renderer"].update({"output_file": "c4_flat.png", "hdr_output_file": "c4_flat.pfm"})
+    with open(os.path.join(out, "c4_flat.json"), "w") as f:
+        json.dump(flat, f)
+    print(f"wrote {out}/c4_flat.json: one mesh of {len(instances)*nt/1e6:.2f} M triangles")
+
+
 def main():
+    flat = "--flat" in sys.argv
+    sys.argv = [a for a in sys.argv if a != "--flat"]
     out = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     res = [int(sys.argv[3]), int(sys.argv[4])] if len(sys.argv) > 4 else [1280, 720]
@@ -105,6 +139,8 @@ def main():
     with open(os.path.join(out, "c4.json"), "w") as f:
         json.dump(scene, f)
     print(f"wrote {out}/c4.json: {len(instances)} instances x {nt} triangles = {len(instances)*nt/1e6:.1f} M instanced triangles")
+    if flat:
+        write_flat(out, instances, scene)
 
 
 if __name__ == "__main__":

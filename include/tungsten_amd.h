@@ -350,6 +350,10 @@ typedef struct tgpu_stats {
     uint64_t extend_launches, shadow_launches;
     uint64_t tail_launches;    /* fused tail-kernel launches                  */
     uint64_t shadow_vertices;  /* path vertices whose NEE rays went through the shadow kernel's queue form */
+    /* of the last tgpu_upload_scene (not reset by tgpu_reset_stats): wall time of the whole call, of the BVH build inside it
+     * (host builder, or device builder without its input copy), and which builder made the scene's tree                  */
+    double   upload_ms, bvh_build_ms;
+    uint64_t bvh_on_device;    /* 1 = tungsten_amd/csrc/bvh_gpu.h built the scene's BVH (TGPU_GPU_BVH / TGPU_GPU_BVH_MIN) */
 } tgpu_stats;
 
 typedef struct tgpu_ctx tgpu_ctx;

@@ -208,6 +208,65 @@ def test_edge_and_vertex_rays_match_the_definition(ta, oracle_py, gpu_ctx):
     assert np.array_equal(gpu_ctx.trace_closest(rays).view(np.uint32), orc.trace_closest(rays).view(np.uint32))
 
 
+def test_device_side_bvh_build(ta, oracle_py, monkeypatch, tmp_path):
+    """tungsten_amd/csrc/bvh_gpu.h: Morton sort + Karras hierarchy + bottom-up boxes + breadth-first collapse to the quantised BVH4, all on the device.
+    The nearest-hit contract (min (t, id) over every triangle whose test passes; conservative boxes) makes results independent of the tree, so
+      1. the benchmark scene forced through the device builder gives the oracle's image and the brute-force definition's hits on rays aimed at
+         edges and vertices, and
+      2. a flat soup above the default threshold (1.25 M triangles: 125 baked spheres of config 4) takes the device path by itself and renders the
+         image the host-built tree renders, bit for bit."""
+    import subprocess
+    import sys
+    monkeypatch.setenv("TGPU_GPU_BVH", "1")
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(96, 54))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    ctx = ta.Context(0)
+    try:
+        ctx.upload(hs, shard)
+        st = ctx.stats()
+        assert st["bvh_on_device"] == 1 and st["bvh_build_ms"] > 0 and st["upload_ms"] >= st["bvh_build_ms"]
+        ctx.render(16, spp_step=8)
+        ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 16, spp_step=8)
+        assert_bit_exact(ctx.download(), ref, "c2 through the device-built tree")
+        orc = oracle_py.Oracle(hs, **oracle_py.GPU)
+        orc.set_brute_force(True)
+        rays = edge_and_vertex_rays(hs, 12000, 5)
+        g, o = ctx.trace_closest(rays), orc.trace_closest(rays)
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+        rays[:, 7] = o[:, 0]*np.where(np.arange(len(rays)) % 2 == 0, np.float32(1.0 - 1e-6), np.float32(1.0 + 1e-6))
+        rays[~np.isfinite(rays[:, 7]), 7] = 1.0
+        assert np.array_equal(ctx.trace_occluded(rays), orc.trace_occluded(rays))
+        # the same through the wavefront kernels only (per-stage traversal kernels instead of the whole-path tail kernel)
+        monkeypatch.setenv("TGPU_TAIL_MAX", "0")
+        ctx.upload(hs, shard, 4096)
+        ctx.render(16, spp_step=8)
+        assert_bit_exact(ctx.download(), ref, "c2 through the device-built tree, wavefront kernels")
+        monkeypatch.delenv("TGPU_TAIL_MAX")
+        # a soup above the threshold: no environment variable needed
+        monkeypatch.delenv("TGPU_GPU_BVH")
+        subprocess.run([sys.executable, scene_path("instances/make_c4.py"), str(tmp_path), "5", "160", "90", "--flat"], check=True, stdout=subprocess.DEVNULL)
+        flat = ta.HostScene(str(tmp_path / "c4_flat.json"))
+        assert flat.desc.contents.n_tris == 1250000
+        fshard = ta.Shard(flat.res_x, flat.res_y)
+        ctx.upload(flat, fshard)
+        st = ctx.stats()
+        assert st["bvh_on_device"] == 1
+        device_ms = st["bvh_build_ms"]
+        ctx.render(8, spp_step=8)
+        device_image = ctx.download()
+        monkeypatch.setenv("TGPU_GPU_BVH", "0")
+        ctx.upload(flat, fshard)
+        st = ctx.stats()
+        assert st["bvh_on_device"] == 0
+        ctx.render(8, spp_step=8)
+        assert_bit_exact(device_image, ctx.download(), "1.25 M-triangle soup: device-built against host-built tree")
+        host_ms = st["bvh_build_ms"]
+        assert device_ms < host_ms, f"device build {device_ms:.0f} ms, host build {host_ms:.0f} ms"
+        print(f"BVH build of 1.25 M triangles: device {device_ms:.1f} ms, host {host_ms:.0f} ms")
+    finally:
+        ctx.close()
+
+
 def test_portable_math_is_bit_identical_on_device(ta, oracle_py, gpu_ctx):
     L = oracle_py.lib()
     L.oracle_eval_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]

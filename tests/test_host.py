@@ -251,3 +251,119 @@ def test_ldr_output_matches_the_reference_png(ta, tonemap, tmp_path):
     got = np.asarray(Image.open(out).convert("RGB"))
     assert np.array_equal(got, want), f"{int((got != want).any(axis=2).sum())} of {48*27} pixels differ from the reference's PNG"
     assert len(np.unique(want)) > 50   # a real image, not a constant
+
+
+def test_no_device_function_outgrows_the_branch_range():
+    """A leaf device function above 128 KB is miscompiled by this toolchain (far branches through the return-address register:
+    profiles/r03_nested_notes.txt) -- the cause of round 2's GPU fault.  Every non-kernel function of the built objects has to stay below."""
+    import glob
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "profiles"))
+    import check_leaf_functions as chk
+    objects = sorted(glob.glob(os.path.join(REPO, "build", "core", "*.o"))) or [os.path.join(REPO, "tungsten_amd", "libtungsten_amd.so")]
+    seen = 0
+    for obj in objects:
+        for name, size, kernel in chk.device_functions(obj):
+            if not kernel:
+                seen += 1
+                assert size < chk.LIMIT, f"{os.path.basename(obj)}: device function {name} is {size} bytes"
+    assert seen >= 3   # the out-of-line children of the nested BSDFs exist
+
+
+def _damaged_copies(tmp_path):
+    """Small scenes whose one resource file is a damaged copy of a vendored asset: truncated at several lengths, bytes flipped, counts blown up.
+    Yields (scene path, description)."""
+    import struct
+    rng = np.random.default_rng(7)
+    mt = os.path.join(REPO, "assets", "materialtest")
+    camera = {"type": "pinhole", "resolution": [32, 18], "fov": 40, "transform": {"position": [0, 1, 5], "look_at": [0, 0.5, 0], "up": [0, 1, 0]}}
+    common = {"camera": camera, "integrator": {"type": "path_tracer", "max_bounces": 4}, "renderer": {"spp": 1, "scene_bvh": True}}
+    floor = {"type": "quad", "bsdf": "grey", "transform": {"scale": [4, 1, 4]}}
+    case = 0
+
+    def scene_with(files, bsdfs, primitives):
+        nonlocal case
+        d = tmp_path / f"case{case}"
+        case += 1
+        os.makedirs(d)
+        for name, data in files.items():
+            (d / name).write_bytes(data)
+        (d / "scene.json").write_text(json.dumps(dict(common, bsdfs=bsdfs, primitives=primitives)))
+        return str(d / "scene.json")
+
+    grey = [{"name": "grey", "type": "lambert", "albedo": 0.5}]
+    mesh = lambda data: scene_with({"m.wo3": data}, grey, [floor, {"type": "mesh", "file": "m.wo3", "bsdf": "grey", "smooth": True}])
+    env = lambda data: scene_with({"e.hdr": data}, grey, [floor, {"type": "infinite_sphere", "emission": "e.hdr", "sample": True}])
+    tex = lambda data: scene_with({"t.png": data}, [{"name": "grey", "type": "lambert", "albedo": "t.png"}], [floor])
+
+    wo3 = open(os.path.join(mt, "Stand.wo3"), "rb").read()
+    hdr = open(os.path.join(mt, "envmap.hdr"), "rb").read()
+    yield mesh(wo3), "intact wo3 (control)"
+    for cut in (0, 4, 8, 9, 100, len(wo3)//2, len(wo3) - 1):
+        yield mesh(wo3[:cut]), f"wo3 truncated at {cut}"
+    nv = struct.unpack_from("<Q", wo3, 0)[0]
+    yield mesh(struct.pack("<Q", 1 << 60) + wo3[8:]), "wo3 vertex count 2^60"
+    yield mesh(struct.pack("<Q", (1 << 32) - 1) + wo3[8:]), "wo3 vertex count 2^32-1"
+    yield mesh(wo3[:8 + nv*32] + struct.pack("<Q", 1 << 59) + wo3[16 + nv*32:]), "wo3 triangle count 2^59"
+    yield mesh(wo3[:8 + nv*32] + struct.pack("<Q", (1 << 32) - 1) + wo3[16 + nv*32:]), "wo3 triangle count 2^32-1"
+    bad = bytearray(wo3)
+    off = 16 + nv*32
+    bad[off:off + 4] = struct.pack("<I", 0xFFFFFFF0)      # first triangle points outside the vertex array
+    yield mesh(bytes(bad)), "wo3 vertex index out of range"
+    yield env(hdr), "intact hdr (control)"
+    for cut in (0, 10, 60, 200, len(hdr)//3, len(hdr) - 5):
+        yield env(hdr[:cut]), f"hdr truncated at {cut}"
+    for k in range(6):
+        b = bytearray(hdr)
+        for pos in rng.integers(0, len(b), 40):
+            b[pos] = int(rng.integers(0, 256))
+        yield env(bytes(b)), f"hdr with 40 random bytes (#{k})"
+    assert b"-Y 512 +X 1024" in hdr
+    yield env(hdr.replace(b"-Y 512 +X 1024", b"-Y 99999999 +X 99999999")), "hdr with an absurd resolution"
+    yield env(hdr.replace(b"-Y 512 +X 1024", b"-Y 2000000000 +X 7")), "hdr with an absurd flat resolution"
+    # PNG textures (assets/next/textures): truncated, corrupted deflate stream, lying IHDR
+    tex_dir = os.path.join(REPO, "assets", "next", "textures")
+    png_name = sorted(f for f in os.listdir(tex_dir) if f.endswith(".png"))[0]
+    png = open(os.path.join(tex_dir, png_name), "rb").read()
+    yield tex(png), "intact png (control)"
+    for cut in (0, 8, 20, 33, 60, len(png)//2, len(png) - 13):
+        yield tex(png[:cut]), f"png truncated at {cut}"
+    for k in range(8):
+        b = bytearray(png)
+        for pos in rng.integers(33, len(b), 6):
+            b[pos] = int(rng.integers(0, 256))
+        yield tex(bytes(b)), f"png with 6 random bytes (#{k})"
+    b = bytearray(png)
+    b[16:24] = struct.pack(">II", 60000, 60000)               # IHDR width / height
+    yield tex(bytes(b)), "png claiming 60000 x 60000"
+    # instance file (Instance.cpp:207-232): truncated, count blown up
+    blob = struct.pack("<II6f", 3, 0, -1, -1, -1, 1, 1, 1) + struct.pack("<18f", *([0.1]*18)) + bytes([0, 0, 0])
+    inst = lambda data: scene_with({"i.bin": data}, grey, [floor, {"type": "instances", "masters": [{"type": "cube", "bsdf": "grey", "transform": {"scale": 0.2}}],
+                                                                  "instances": "i.bin"}])
+    yield inst(blob), "intact instance file (control)"
+    for data, what in ((blob[:7], "truncated header"), (blob[:40], "truncated body"), (struct.pack("<II", 1 << 30, 0) + blob[8:], "count 2^30"),
+                       (struct.pack("<II", 0xFFFFFFFF, 1) + blob[8:], "count 2^32-1, lossy"), (blob[:-1], "missing id")):
+        yield inst(data), f"instance file: {what}"
+
+
+def test_damaged_inputs_are_refused_with_a_message(ta, tmp_path):
+    """Truncated / corrupt .wo3, .hdr, .png and instance files must end in an error message, never in a crash or in memory the parsers do not
+    own.  Every case runs through the ordinary host library here and, in one batch, through the ASan + UBSan build of the loader
+    (`make asan`: build/asan/host_check), where an out-of-bounds read or an overflowing size computation aborts the process."""
+    cases = list(_damaged_copies(tmp_path))
+    assert len(cases) > 50
+    refused = 0
+    for path, what in cases:
+        try:
+            ta.HostScene(path)
+            assert "control" in what or "random bytes" in what, f"{what}: loaded without complaint"   # a few byte flips leave a decodable file
+        except RuntimeError as e:
+            assert str(e) and "control" not in what, f"{what}: {e}"
+            refused += 1
+    assert refused >= len(cases) - 4 - 14
+    r = subprocess.run(["make", "-s", "asan"], cwd=REPO, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(REPO, "build", "asan", "host_check")] + [p for p, _ in cases], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, "the sanitizer build died on a damaged input:\n" + r.stdout[-3000:] + r.stderr[-6000:]
+    assert f"of {len(cases)} refused" in r.stdout

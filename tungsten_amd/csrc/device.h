@@ -1271,6 +1271,34 @@ TG_DEV V3 forwardTransparency(const SC &sc, const tgpu_bsdf &d, float wiz, float
     return V3(0.0f);
 }
 
+// ---- the children of the nested BSDFs (Mixed, RoughCoat, Transparency), as real calls --------------------------------------------------
+// The four nested types evaluate, sample and take the pdf of one or two single-layer reflectors each; with those inlined, one nested entry point is
+// 120-270 KB of code and the whole-path tail kernel took 27 minutes to compile.  The children are therefore CALLED: three leaf functions
+// (__noinline__, a few tens of KB each), the nested code around them small enough to inline anywhere -- the tail kernels included.
+//
+// Why the size matters beyond compile time (round 2 lost nested scenes in the tail kernel to this; root cause found in round 3 with rocgdb on the
+// faulting wave, profiles/r03_nested_notes.txt): s_cbranch reaches +-128 KB.  In a larger function LLVM's branch relaxation expands far branches to
+// s_getpc_b64 / s_add_u32 / s_addc_u32 / s_setpc_b64 through a scavenged SGPR pair, and in a LEAF device function (ROCm 7.2, gfx950) the pair it takes
+// is s[30:31] -- the return address, which a leaf never saves.  The function then "returns" into the middle of itself with a stale EXEC mask, lanes
+// that were never called wake up with garbage in their argument registers, and the first flat_load through them is the
+// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Kernels are immune (no return address), callers of other functions too (they spill s[30:31] in their
+// prologue).  Rule kept here and checked by profiles/kernel_resources.sh: no leaf device function above 128 KB.
+struct MaterialTables { // what the single-layer reflectors read of a scene: 24 bytes by value instead of a reference to the 600-byte kernel argument
+    const tgpu_bsdf *bsdfs;
+    const tgpu_texture *textures;
+    const DBitmap *bitmaps;
+};
+template <class SC> TG_DEV MaterialTables materialTables(const SC &sc) { return MaterialTables{sc.bsdfs, sc.textures, sc.bitmaps}; }
+static __device__ __noinline__ V3 childEval(MaterialTables mt, const tgpu_bsdf *d, V3 wi, V3 wo, uint32_t requested, float uvx, float uvy)
+{
+    return baseEval(mt, *d, wi, wo, requested, uvx, uvy);
+}
+static __device__ __noinline__ float childPdf(MaterialTables mt, const tgpu_bsdf *d, V3 wi, V3 wo, uint32_t requested, float uvx, float uvy)
+{
+    return basePdf(mt, *d, wi, wo, requested, uvx, uvy);
+}
+static __device__ __noinline__ bool childSample(MaterialTables mt, const tgpu_bsdf *d, Event *e, Sampler *s) { return baseSample(mt, *d, *e, *s); }
+
 // RoughCoatBsdf (bsdfs/RoughCoatBsdf.cpp:47-307) over a base BSDF
 template <class SC>
 TG_DEV void roughCoatSubstrate(const SC &sc, const tgpu_bsdf &d, const tgpu_bsdf &sub, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy,
@@ -1285,10 +1313,10 @@ TG_DEV void roughCoatSubstrate(const SC &sc, const tgpu_bsdf &d, const tgpu_bsdf
     }
     V3 wiSubstrate(wi.x*eta, wi.y*eta, __builtin_copysignf(cosThetaTi, wi.z));
     V3 woSubstrate(wo.x*eta, wo.y*eta, __builtin_copysignf(cosThetaTo, wo.z));
-    pdf = basePdf(sc, sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
+    pdf = childPdf(materialTables(sc), &sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
     pdf *= eta*eta*__builtin_fabsf(wo.z/cosThetaTo);
     float compressionProjection = eta*eta*wo.z/cosThetaTo;
-    V3 substrateF = baseEval(sc, sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
+    V3 substrateF = childEval(materialTables(sc), &sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
     V3 ss(d.scaled_sigma_a);
     if (ss.max() > 0.0f) substrateF *= expV3(ss*(-1.0f/cosThetaTo - 1.0f/cosThetaTi));
     brdf = compressionProjection*(1.0f - Fi)*(1.0f - Fo)*substrateF;
@@ -1336,7 +1364,7 @@ TG_DEV float roughCoatPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const 
     if (sampleT && Fi < 1.0f && Fo < 1.0f) {
         V3 wiSubstrate(wi.x*eta, wi.y*eta, __builtin_copysignf(cosThetaTi, wi.z));
         V3 woSubstrate(wo.x*eta, wo.y*eta, __builtin_copysignf(cosThetaTo, wo.z));
-        substratePdf = basePdf(sc, sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
+        substratePdf = childPdf(materialTables(sc), &sub, wiSubstrate, woSubstrate, requested, uvx, uvy);
         substratePdf *= eta*eta*__builtin_fabsf(wo.z/cosThetaTo);
     }
     return glossyPdf*specularProbability + substratePdf*(1.0f - specularProbability);
@@ -1370,7 +1398,7 @@ TG_DEV bool roughCoatSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler 
     }
     V3 wiSubstrate(wi.x*eta, wi.y*eta, cosThetaTi);
     e.wi = wiSubstrate;
-    bool success = baseSample(sc, sub, e, s);
+    bool success = childSample(materialTables(sc), &sub, &e, &s);
     e.wi = wi;
     if (!success) return false;
     float cosThetaTo;
@@ -1413,17 +1441,17 @@ TG_DEV bool mixedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
     if (!mixedRatio(sc, d, e.requestedLobe, e.uvx, e.uvy, ratio)) return false;
     const tgpu_bsdf &b0 = sc.bsdfs[d.substrate], &b1 = sc.bsdfs[d.aux_bsdf];
     if (s.nextBoolean(ratio)) {
-        if (!baseSample(sc, b0, e, s)) return false;
+        if (!childSample(materialTables(sc), &b0, &e, &s)) return false;
         float pdf0 = e.pdf*ratio;
-        float pdf1 = basePdf(sc, b1, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*(1.0f - ratio);
-        V3 f = e.weight*e.pdf*ratio + baseEval(sc, b1, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*(1.0f - ratio);
+        float pdf1 = childPdf(materialTables(sc), &b1, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*(1.0f - ratio);
+        V3 f = e.weight*e.pdf*ratio + childEval(materialTables(sc), &b1, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*(1.0f - ratio);
         e.pdf = pdf0 + pdf1;
         e.weight = f/e.pdf;
     } else {
-        if (!baseSample(sc, b1, e, s)) return false;
-        float pdf0 = basePdf(sc, b0, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*ratio;
+        if (!childSample(materialTables(sc), &b1, &e, &s)) return false;
+        float pdf0 = childPdf(materialTables(sc), &b0, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*ratio;
         float pdf1 = e.pdf*(1.0f - ratio);
-        V3 f = baseEval(sc, b0, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*ratio + e.weight*e.pdf*(1.0f - ratio);
+        V3 f = childEval(materialTables(sc), &b0, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy)*ratio + e.weight*e.pdf*(1.0f - ratio);
         e.pdf = pdf0 + pdf1;
         e.weight = f/e.pdf;
     }
@@ -1431,22 +1459,14 @@ TG_DEV bool mixedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
     return true;
 }
 
-// ---- the nested BSDFs (mixtures, coats, cut-outs, thin sheets): rare, and large once their children are inlined.  The shade kernels
-// inline them; the tail kernels' translation units leave them out (TG_NO_NESTED_BSDFS: inlined into the whole-path kernel they
-// multiply its compile time, and out-of-line calls of functions this size fault on gfx950 with ROCm 7.2 -- measured, profiles/r02_ab_notes.txt),
-// and the launcher keeps scenes that use them out of the tail kernel (ctx->hasNested)
-#ifdef TG_NESTED_OUT_OF_LINE
-#define TG_NESTED_FN __device__ __noinline__
-#else
-#define TG_NESTED_FN TG_DEV
-#endif
+// ---- the nested BSDFs (mixtures, coats, cut-outs, thin sheets) over the children above
 template <class SC>
-TG_NESTED_FN V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+TG_DEV V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
 {
     if (d.type == TGPU_BSDF_MIXED) { // MixedBsdf.cpp:104-108
         float ratio = texEval(sc, d.aux_tex, uvx, uvy).x;
-        return texEval(sc, d.albedo_tex, uvx, uvy)*(baseEval(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy)*ratio +
-                                                      baseEval(sc, sc.bsdfs[d.aux_bsdf], wi, wo, requested, uvx, uvy)*(1.0f - ratio));
+        return texEval(sc, d.albedo_tex, uvx, uvy)*(childEval(materialTables(sc), &sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy)*ratio +
+                                                      childEval(materialTables(sc), &sc.bsdfs[d.aux_bsdf], wi, wo, requested, uvx, uvy)*(1.0f - ratio));
     }
     if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatEval(sc, d, wi, wo, requested, uvx, uvy);
     if (d.type == TGPU_BSDF_TRANSPARENCY || d.type == TGPU_BSDF_THINSHEET) { // TransparencyBsdf.cpp:47-53, ThinSheetBsdf.cpp:83-103
@@ -1455,30 +1475,30 @@ TG_NESTED_FN V3 nestedEval(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const
             return (nwi.x == wo.x && nwi.y == wo.y && nwi.z == wo.z) ? forwardTransparency(sc, d, wi.z, uvx, uvy) : V3(0.0f);
         }
         if (d.type == TGPU_BSDF_THINSHEET) return V3(0.0f);
-        return baseEval(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy);
+        return childEval(materialTables(sc), &sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy);
     }
     return V3(0.0f);
 }
 template <class SC>
-TG_NESTED_FN float nestedPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
+TG_DEV float nestedPdf(const SC &sc, const tgpu_bsdf &d, const V3 &wi, const V3 &wo, uint32_t requested, float uvx, float uvy)
 {
     if (d.type == TGPU_BSDF_MIXED) { // MixedBsdf.cpp:125-131
         float ratio;
         if (!mixedRatio(sc, d, requested, uvx, uvy, ratio)) return 0.0f;
-        return basePdf(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy)*ratio +
-               basePdf(sc, sc.bsdfs[d.aux_bsdf], wi, wo, requested, uvx, uvy)*(1.0f - ratio);
+        return childPdf(materialTables(sc), &sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy)*ratio +
+               childPdf(materialTables(sc), &sc.bsdfs[d.aux_bsdf], wi, wo, requested, uvx, uvy)*(1.0f - ratio);
     }
     if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatPdf(sc, d, wi, wo, requested, uvx, uvy);
-    if (d.type == TGPU_BSDF_TRANSPARENCY) return basePdf(sc, sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy); // TransparencyBsdf.cpp:60-63
+    if (d.type == TGPU_BSDF_TRANSPARENCY) return childPdf(materialTables(sc), &sc.bsdfs[d.substrate], wi, wo, requested, uvx, uvy); // TransparencyBsdf.cpp:60-63
     if (d.type == TGPU_BSDF_THINSHEET) return ((requested & SpecularReflectionLobe) && checkReflectionConstraint(wi, wo)) ? 1.0f : 0.0f; // :111-118
     return 0.0f;
 }
 template <class SC>
-TG_NESTED_FN bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
+TG_DEV bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
     if (d.type == TGPU_BSDF_MIXED) return mixedSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_ROUGH_COAT) return roughCoatSample(sc, d, e, s);
-    if (d.type == TGPU_BSDF_TRANSPARENCY) return baseSample(sc, sc.bsdfs[d.substrate], e, s); // TransparencyBsdf.cpp:42-45
+    if (d.type == TGPU_BSDF_TRANSPARENCY) return childSample(materialTables(sc), &sc.bsdfs[d.substrate], &e, &s); // TransparencyBsdf.cpp:42-45
     if (d.type == TGPU_BSDF_THINSHEET) { // ThinSheetBsdf.cpp:50-81
         if (!(e.requestedLobe & SpecularReflectionLobe)) return false;
         e.wo = V3(-e.wi.x, -e.wi.y, e.wi.z);
@@ -1499,13 +1519,13 @@ TG_NESTED_FN bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampl
     }
     return false;
 }
+// KNOWN: the BSDF type when the caller knows it at compile time (the per-class shade kernels), -1 otherwise.  The nested types never have a class
+// of their own, so a kernel that knows its type carries none of their code -- stated here rather than left to __builtin_assume on d.type, which
+// stops propagating at the first real call (the children of the nested BSDFs are calls, see above).
+template <int KNOWN = -1>
 TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
-#ifdef TG_NO_NESTED_BSDFS
-    if (d.type >= TGPU_BSDF_MIXED) return V3(0.0f);
-#else
-    if (d.type >= TGPU_BSDF_MIXED) return nestedEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
-#endif
+    if (KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
@@ -1534,13 +1554,10 @@ TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
     return V3(0.0f);
 }
 
+template <int KNOWN = -1>
 TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
-#ifdef TG_NO_NESTED_BSDFS
-    if (d.type >= TGPU_BSDF_MIXED) return 0.0f;
-#else
-    if (d.type >= TGPU_BSDF_MIXED) return nestedPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
-#endif
+    if (KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularPdf(d, e.wi, e.wo, e.requestedLobe);
@@ -1573,13 +1590,10 @@ TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
     return 0.0f;
 }
 
+template <int KNOWN = -1>
 TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
-#ifdef TG_NO_NESTED_BSDFS
-    if (d.type >= TGPU_BSDF_MIXED) return false;
-#else
-    if (d.type >= TGPU_BSDF_MIXED) return nestedSample(sc, d, e, s);
-#endif
+    if (KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticSample(sc, d, e, s);
     if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularSample(sc, d, e, s);

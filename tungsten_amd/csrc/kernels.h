@@ -2830,7 +2830,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
                             consistent = geometricBackside == shadingBackside;
                         }
                         ev.requestedLobe = AllButSpecular;
-                        V3 f = consistent ? bsdfEval(sc, bsdf, ev) : V3(0.0f);
+                        V3 f = consistent ? bsdfEval<CLASS>(sc, bsdf, ev) : V3(0.0f);
                         if (!f.isZero()) {
                             // attenuatedEmission (TraceBase.cpp:144-174) up to the shadow test
                             V3 E(0.0f);
@@ -2862,7 +2862,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
                             if (lit && shadowPasses && (!E.isZero() || aovOpen)) {
                                 if (!E.isZero()) { // (e == 0 returns before f*e/pdf, TraceBase.cpp:276-279)
                                     V3 lightF = f*E/ls.pdf;
-                                    const float mis = powerHeuristic(ls.pdf, bsdfPdf(sc, bsdf, ev));
+                                    const float mis = powerHeuristic(ls.pdf, bsdfPdf<CLASS>(sc, bsdf, ev));
                                     lightF *= mis;
                                     L = lightF;
                                     misL = mis;
@@ -2877,7 +2877,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
                 // ---- bsdfSample (TraceBase.cpp:287-321) ----
                 {
                     ev.requestedLobe = AllButSpecular;
-                    if (bsdfSample(sc, bsdf, ev, smp) && !ev.weight.isZero()) {
+                    if (bsdfSample<CLASS>(sc, bsdf, ev, smp) && !ev.weight.isZero()) {
                         V3 wo = ev.frame.toGlobal(ev.wo);
                         bool consistent = true;
                         if (sc.settings.enable_consistency_checks) {
@@ -2930,7 +2930,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
 
         // continuation (TraceBase.cpp:546-565)
         ev.requestedLobe = AllLobes;
-        bool sampled = !passThrough && bsdfSample(sc, bsdf, ev, smp);
+        bool sampled = !passThrough && bsdfSample<CLASS>(sc, bsdf, ev, smp);
         V3 wo(0.0f);
         bool alive = sampled;
         if (passThrough) { // wo = ray.dir(); weight = transparency/transparencyScalar; sampledLobe = ForwardLobe

@@ -4,6 +4,7 @@
 #define TG_TU_MAIN
 #include "kernels.h"
 #include "bvh_build.h"
+#include "bvh_gpu.h"
 #include "instance_bvh.h"
 
 #include <algorithm>
@@ -92,7 +93,6 @@ struct tgpu_ctx {
     uint32_t nCur = 0, freeCount = 0;
     uint32_t listCount[TG_LISTS] = {0};
     uint64_t tailMax = 65536; // switch to the tail kernel below this many live paths
-    bool hasNested = false;   // the scene uses BSDF types the tail kernel is compiled without
     uint32_t tailSpread = 2;  // lanes per path in the tail kernel (power of two; TGPU_TAIL_SPREAD)
     uint64_t aliveCount = 0, hostExtendRays = 0;
     int curQ = 0;
@@ -101,6 +101,8 @@ struct tgpu_ctx {
     int maxGrid = 2048;
     int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
     bool extendPersistent = true;  // the persistent-lane form of the queue kernel (k_extend_p); TGPU_EXTEND_P=0: k_extend_q (A/B)
+    double uploadMs = 0.0, bvhBuildMs = 0.0; // of the last tgpu_upload_scene
+    bool bvhOnDevice = false;
     uint32_t nodeletCount = 0;   // nodes of the top BVH4 levels staged in LDS by the queue kernels (TGPU_LDS_NODELETS)
     bool instExtendQueue = false; // TGPU_INST_EXTEND_Q=1: k_extend_iq + k_classify for scenes with instances / spheres / disks (A/B)
     int shadowQueue = 4;        // vertices (= 2 rays each) per lane of the shadow kernel's queue form: 4 or 8; TGPU_SHADOW_Q=0: k_shadow (A/B)
@@ -407,6 +409,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     int rc = validate(ctx, s);
     if (rc != TGPU_OK) return rc;
     if (!shard || shard->n_pixels == 0 || !shard->pixel_index || !shard->tile_seed) { fail(ctx, "empty shard"); return TGPU_ERR_INVALID; }
+    const auto uploadStart = std::chrono::steady_clock::now();
+    double bvhBuildMs = 0.0;
     const uint32_t nImagePixels = s->camera.res_x*s->camera.res_y;
     for (uint32_t i = 0; i < shard->n_pixels; ++i)
         if (shard->pixel_index[i] >= nImagePixels) { fail(ctx, "shard pixel %u out of range", i); return TGPU_ERR_INVALID; }
@@ -438,7 +442,34 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     // no gain measured, profiles/r02_ab_notes.txt)
     const int nodeletLevels = getenv("TGPU_LDS_NODELETS") ? std::min(std::max(atoi(getenv("TGPU_LDS_NODELETS")), 0), 5) : 0;
     uint32_t nodeletCount = 0;
+    // Large flat soups get their tree from the device builder (bvh_gpu.h): the host's binned SAH is one thread and O(n log n).
+    // TGPU_GPU_BVH=1 / 0 forces / forbids it; TGPU_GPU_BVH_MIN sets the triangle count from which it is used (default 1 Mi).
+    // Scenes with mesh masters keep the host path for everything (their BVHs share one node array).
+    tg_lbvh::Result deviceBvh;
+    bool useDeviceBvh = s->n_master_tris == 0 && s->n_tris >= 3;
+    {
+        uint32_t minTris = 1u << 20;
+        if (const char *e = getenv("TGPU_GPU_BVH_MIN")) minTris = uint32_t(strtoul(e, nullptr, 10));
+        if (const char *e = getenv("TGPU_GPU_BVH")) useDeviceBvh = useDeviceBvh && atoi(e) != 0;
+        else useDeviceBvh = useDeviceBvh && s->n_tris >= minTris;
+    }
     auto appendBvh = [&](uint32_t first, uint32_t count, const char *what) -> uint32_t {
+        const auto buildStart = std::chrono::steady_clock::now();
+        if (useDeviceBvh && first == 0) {
+            uint32_t maxLeaf = 2;
+            if (const char *e = getenv("TGPU_BVH_LEAF")) maxLeaf = uint32_t(std::min(std::max(atoi(e), 1), 8));
+            if (const char *msg = tg_lbvh::build(s->tri_pos, count, triPad, maxLeaf, ctx->stream, deviceBvh)) {
+                fail(ctx, "device BVH build failed: %s", msg);
+                return 0xFFFFFFFEu;
+            }
+            ctx->allocs.push_back(deviceBvh.nodes);
+            ctx->allocs.push_back(deviceBvh.tris);
+            maxDepth4 = std::max(maxDepth4, deviceBvh.maxDepth4);
+            bvhBuildMs += deviceBvh.buildMs;
+            if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] %s: %u tris, device LBVH -> bvh4 %u nodes depth %d in %.1f ms (+ %.1f ms copy)\n", what, count, deviceBvh.nodeCount,
+                                              deviceBvh.maxDepth4, deviceBvh.buildMs, deviceBvh.copyMs);
+            return deviceBvh.rootChild;
+        }
         tgpu_bvh::Builder builder(s->tri_pos + size_t(first)*9, count, triPad);
         tgpu_bvh::Bvh bvh = builder.build();
         tgpu_bvh::Bvh4 bvh4 = tgpu_bvh::Collapser(bvh).run(); // the quantised BVH4 the kernels traverse (bvh_build.h)
@@ -477,11 +508,13 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
             allTris.push_back(tail);
         }
         maxDepth4 = std::max(maxDepth4, bvh4.maxDepth);
+        bvhBuildMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - buildStart).count();
         if (getenv("TGPU_DEBUG")) fprintf(stderr, "[tgpu] %s: %u tris, bvh2 %u nodes depth %d -> bvh4 %u nodes depth %d\n", what, count, bvh.nodeCount, bvh.maxDepth, bvh4.nodeCount, bvh4.maxDepth);
         return rebase(bvh4.rootChild);
     };
     sc.nTris = s->n_tris;
     sc.rootChild = appendBvh(0, s->n_tris, "scene");
+    if (sc.rootChild == 0xFFFFFFFEu) return TGPU_ERR_HIP;
     // ---- "instances" (Instance::prepareForRender: the BVH2 over instance boxes is built in instance_bvh.h) ----
     auto bitsToFloat = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
     std::vector<DInstSet> instSets(s->n_instance_sets);
@@ -550,10 +583,14 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
     ctx->traceSlots = getenv("TGPU_TRACE_SLOTS") != nullptr;
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
-    if (const char *e = getenv("TGPU_STACK_ENTRIES")) sc.stackEntries = atoi(e); // perf experiments only: may drop nodes
     float4 *dNodes, *dTris;
-    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allNodes.data()), allNodes.size(), &dNodes))) return rc;
-    if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allTris.data()), allTris.size(), &dTris))) return rc;
+    if (deviceBvh.nodes) { // the scene's tree was built in place (no mesh masters: nothing else shares the arrays)
+        dNodes = deviceBvh.nodes;
+        dTris = deviceBvh.tris;
+    } else {
+        if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allNodes.data()), allNodes.size(), &dNodes))) return rc;
+        if ((rc = upload(ctx, ctx->allocs, reinterpret_cast<const float4 *>(allTris.data()), allTris.size(), &dTris))) return rc;
+    }
     sc.nodes = dNodes;
     sc.tris = dTris;
     // 20 levels of LDS stack = 20 KB per block: 8 blocks (32 waves) fit a CU, so registers, not LDS, set the occupancy
@@ -636,8 +673,6 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if (sc.hasForward) ctx->generalShading = true; // the shadow walk needs the NEE factors the general shade kernels store
     for (int t = TGPU_OUTPUT_DEPTH; t < TGPU_OUTPUT_COUNT; ++t) // only the general shade kernels record the auxiliary output values
         if (s->output_buffers[t].enabled) ctx->generalShading = true;
-    ctx->hasNested = false; // mixtures, coats, cut-outs, thin sheets: shaded by the wavefront kernels only (device.h, TG_NO_NESTED_BSDFS)
-    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type >= TGPU_BSDF_MIXED) ctx->hasNested = true;
     sc.textures = dTex;
     sc.lights = dLights; sc.nLights = s->n_lights;
     {   // media + the table of fmath::exp_ps (fmath.hpp:106-126: a = n/logf(2), b = logf(2)/n, tbl[i] = mantissa(pow(2.0f, i/n)))
@@ -879,6 +914,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     }
 
     ctx->stats = tgpu_stats{};
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - uploadStart).count();
+    ctx->bvhBuildMs = bvhBuildMs;
+    ctx->bvhOnDevice = deviceBvh.nodes != nullptr;
     ctx->uploaded = true;
     ctx->abortFlag = false;
     if (!ctx->worker.joinable()) ctx->worker = std::thread(workerMain, ctx);
@@ -976,7 +1015,7 @@ static int driveIteration(tgpu_ctx *ctx)
     }
     // tail mode: nothing left to start and only a few long paths alive -> one launch finishes them all
     bool tail = false;
-    if (nCur > 0 && ctx->aliveCount > 0 && ctx->aliveCount <= ctx->tailMax && !ctx->hasNested && ctx->sampleBase == limit) {
+    if (nCur > 0 && ctx->aliveCount > 0 && ctx->aliveCount <= ctx->tailMax && ctx->sampleBase == limit) {
         std::lock_guard<std::mutex> lk(ctx->mtx);
         tail = ctx->pending.empty();
     }
@@ -1517,6 +1556,9 @@ int tgpu_get_stats(tgpu_ctx *ctx, tgpu_stats *out)
         ctx->stats.extend_rays = ctx->hostExtendRays + d[6];
         ctx->stats.shadow_vertices = d[7];
     }
+    ctx->stats.upload_ms = ctx->uploadMs;
+    ctx->stats.bvh_build_ms = ctx->bvhBuildMs;
+    ctx->stats.bvh_on_device = ctx->bvhOnDevice ? 1u : 0u;
     *out = ctx->stats;
     return TGPU_OK;
 }

@@ -1,6 +1,5 @@
 // One kernel of kernels.h, instantiated here so that the library builds in parallel (see the end of kernels.h): the whole-path tail kernel is the
 // slowest thing to compile in the tree, one instantiation per file keeps the critical path of `make -j` short.
-#define TG_NO_NESTED_BSDFS /* see device.h: scenes with nested BSDFs never run the tail kernel */
 #include "kernels.h"
 
 namespace tg {

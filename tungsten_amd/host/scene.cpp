@@ -162,16 +162,20 @@ bool loadWo3(const std::string &path, std::vector<float> &verts, std::vector<uin
 {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
+    // counts come from the file: nothing is allocated before they have been checked against the file's size
+    std::fseek(f, 0, SEEK_END);
+    const uint64_t fileBytes = uint64_t(std::ftell(f));
+    std::fseek(f, 0, SEEK_SET);
     uint64_t nv = 0, nt = 0;
     bool ok = std::fread(&nv, 8, 1, f) == 1;
-    if (ok && nv < (1ull << 32)) {
+    if (ok && nv < (1ull << 32) && 16 + nv*32 <= fileBytes) {
         verts.resize(size_t(nv)*8);
         ok = nv == 0 || std::fread(verts.data(), 32, size_t(nv), f) == size_t(nv);
     } else {
         ok = false;
     }
     ok = ok && std::fread(&nt, 8, 1, f) == 1;
-    if (ok && nt < (1ull << 32)) {
+    if (ok && nt < (1ull << 32) && 16 + nv*32 + nt*16 <= fileBytes) {
         tris.resize(size_t(nt)*4);
         ok = nt == 0 || std::fread(tris.data(), 16, size_t(nt), f) == size_t(nt);
     } else {
@@ -223,13 +227,17 @@ bool loadRadianceHdr(const std::string &path, int &w, int &h, std::vector<float>
     readLine(line);
     if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) return false;
     if (w <= 0 || h <= 0) return false;
-    rgb.resize(size_t(w)*h*3);
-
     const uint8_t *p = reinterpret_cast<const uint8_t *>(data.data());
     size_t n = data.size();
-    if (w < 8 || w >= 32768) {
+    // the resolution comes from the file: a scanline costs at least its 4-byte header (run-length form) or 4 bytes per pixel (flat form),
+    // so a header that promises more rows or pixels than the file can hold is refused before anything is allocated
+    const bool flat = w < 8 || w >= 32768;
+    const size_t pixels = size_t(w)*size_t(h), available = n - pos;
+    if (flat ? pixels > available/4 : size_t(h) > available/4) return false;
+    rgb.resize(pixels*3);
+    if (flat) {
         // flat data
-        for (int i = 0; i < w*h; ++i) {
+        for (size_t i = 0; i < pixels; ++i) {
             if (pos + 4 > n) return false;
             rgbeToFloat(p + pos, &rgb[size_t(i)*3]);
             pos += 4;
@@ -243,8 +251,8 @@ bool loadRadianceHdr(const std::string &path, int &w, int &h, std::vector<float>
         if (c1 != 2 || c2 != 2 || (len & 0x80)) {
             // not RLE: the whole image is flat (stb falls back for the full image from this pixel on
             // only when j == 0)
-            if (j != 0) return false;
-            for (int i = 0; i < w*h; ++i) {
+            if (j != 0 || pixels > (n - pos)/4) return false;
+            for (size_t i = 0; i < pixels; ++i) {
                 if (pos + 4 > n) return false;
                 rgbeToFloat(p + pos, &rgb[size_t(i)*3]);
                 pos += 4;
@@ -298,6 +306,14 @@ bool loadPfm(const std::string &path, int &w, int &h, std::vector<float> &rgb)
         return false;
     }
     std::fgetc(f);
+    const long dataStart = std::ftell(f);
+    std::fseek(f, 0, SEEK_END);
+    const uint64_t dataBytes = uint64_t(std::ftell(f) - dataStart);
+    std::fseek(f, dataStart, SEEK_SET);
+    if (w <= 0 || h <= 0 || uint64_t(w)*uint64_t(h) > dataBytes/12) { // the header promises more pixels than the file holds
+        std::fclose(f);
+        return false;
+    }
     rgb.resize(size_t(w)*h*3);
     bool ok = true;
     for (int y = h - 1; y >= 0 && ok; --y) ok = std::fread(&rgb[size_t(y)*w*3], sizeof(float), size_t(w)*3, f) == size_t(w)*3;
@@ -1165,6 +1181,7 @@ bool loadInstanceFile(const std::string &path, std::vector<float> &pos, std::vec
     uint32_t count, compressed;
     float bounds[6];
     if (!rd(&count, 4) || !rd(&compressed, 4) || !rd(bounds, 24)) return false;
+    if (size_t(count)*((compressed & 1u) ? 12u : 24u) + count > size_t(end - p)) return false; // more instances than the file can hold
     pos.resize(size_t(count)*3);
     rot.resize(count);
     id.resize(count);

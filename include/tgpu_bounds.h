@@ -21,6 +21,19 @@
 #include <math.h>
 
 #define TGPU_BVH_T_SLACK 0.0009765625f /* 2^-10 */
+/* (3) Round 3: a triangle's binary32 test can pass with a distance that is far off when the ray grazes the triangle (t = T/den with den -> 0:
+ * a ray 1e-5 rad off the plane gives |dt|/t ~ 6e-3, more than any fixed slack; found by tests/test_gpu_parity.py::test_device_side_bvh_build
+ * on a ray whose reported hit lay 9e-4 in FRONT of its own padded box).  A walk prunes by the boxes the ray really enters, so such a hit is found or
+ * lost depending on the tree -- the reference's too (Embree prunes with exact boxes).  The contract therefore counts a hit only when the point
+ * O + t*D it reports lies inside the triangle's own box grown by TGPU_HIT_PAD_FRACTION * tgpu_bvh_pad: then every box that contains the padded
+ * triangle box is entered before t and left after it, whatever the tree.  Evaluated for candidates that passed everything else (device:
+ * kernels.h triTest, oracle: triTest in GPU mode and in brute-force mode); the oracle's reference mode keeps Embree's behaviour.               */
+#define TGPU_HIT_PAD_FRACTION 0.5f
+/* Candidates whose ray is at least this far off the triangle's plane (|cos| between ray and normal) skip the box test: with e = 2^-24, the reported
+ * point is off by at most |D| dt <= 3e |Ng||D| (|C| + t|D|)/|den| <= 6 e M/|cos| (M = tgpu_scene_extent, the bound of every distance involved), and
+ * 6 e M/|cos| <= hitPad = 2^-17 M  <=>  |cos| >= 6 * 2^-24 * 2^17 = 0.047.  0.0625 leaves a margin; below it (0.4 % of cosine-weighted hits) the
+ * box test decides.  Both sides evaluate  den^2 >= cos^2 * (|Ng|^2 |D|^2)  in binary32 with |Ng|^2 = fl(Ng.x^2 + (Ng.y^2 + Ng.z^2)).           */
+#define TGPU_HIT_SURE_COS 0.0625f
 
 /* M: the diagonal of the box around everything a ray can start on or hit (scene geometry in world space, camera) or the
  * largest absolute coordinate of any of it or of an instance master's own frame, whichever is larger. */

@@ -261,6 +261,7 @@ struct oracle_ctx {
     tgpu_scene_desc sc;
     int rngMode, mathMode, rcpMode;
     bool brute = g_brute; // oracle_set_brute_force: triangle queries test every triangle (the definition the BVH walks must meet)
+    float hitPad = 0.0f;             // GPU mode: TGPU_HIT_PAD_FRACTION * tgpu_bvh_pad (include/tgpu_bounds.h (3)); unused in reference mode
     TriBvh sceneBvh;                 // scene finites: triangles [0, n_tris)
     std::vector<TriIsect> tris;      // all triangles incl. the instance masters' (n_tris + n_master_tris)
     std::vector<Pcg32> tilePcg;
@@ -532,7 +533,8 @@ struct TriHit { bool valid; float t, u, v; };
 
 // Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113,
 // finalize :43-49; dot/cross order common/math/vec3.h:182,187)
-static inline TriHit triTest(const TriIsect &tri, const Ray &ray, float tfar0, int rcpMode)
+// hitPad (GPU mode only, include/tgpu_bounds.h (3)): the reported point must lie inside the triangle's own box grown by that much
+static inline TriHit triTest(const TriIsect &tri, const Ray &ray, float tfar0, int rcpMode, float hitPad = 0.0f)
 {
     auto edot = [](const V3 &a, const V3 &b) { return a.x*b.x + (a.y*b.y + a.z*b.z); };
     TriHit h{false, 0, 0, 0};
@@ -558,6 +560,13 @@ static inline TriHit triTest(const TriIsect &tri, const Ray &ray, float tfar0, i
 #endif
     (void)rcpMode;
     h.t = T/absDen; h.u = U/absDen; h.v = V/absDen;
+    if (!(absDen*absDen >= (TGPU_HIT_SURE_COS*TGPU_HIT_SURE_COS)*(edot(tri.Ng, tri.Ng)*edot(D, D)))) { // grazing: the box test decides
+        const V3 P(O.x + D.x*h.t, O.y + D.y*h.t, O.z + D.z*h.t), v1 = tri.v0 - tri.e1, v2 = tri.v0 + tri.e2;
+        for (int k = 0; k < 3; ++k) {
+            const float lo = fmin2(tri.v0[k], fmin2(v1[k], v2[k])) - hitPad, hi = fmax2(tri.v0[k], fmax2(v1[k], v2[k])) + hitPad;
+            if (!(P[k] >= lo && P[k] <= hi)) { h.valid = false; return h; }
+        }
+    }
     return h;
 }
 
@@ -580,7 +589,7 @@ void oracle_ctx::intersectTris(const TriBvh &bvh, const Ray &ray, float &bestT, 
             for (uint32_t i = n.first; i < n.first + n.count; ++i) {
                 uint32_t id = triOrder[i];
                 c.tris++;
-                TriHit h = triTest(tris[id], ray, tfar0, rcpMode);
+                TriHit h = triTest(tris[id], ray, tfar0, rcpMode, hitPad);
                 if (h.valid) TRC("    valid tri=%u t=%08x u=%08x v=%08x\n", id, hx(h.t), hx(h.u), hx(h.v));
                 if (h.valid && (h.t < bestT || (h.t == bestT && id < bestPrim))) {
                     bestT = h.t; bestU = h.u; bestV = h.v; bestPrim = id;
@@ -610,7 +619,7 @@ bool oracle_ctx::occludedTris(const TriBvh &bvh, const Ray &ray, Counters &c) co
         if (n.left < 0) {
             for (uint32_t i = n.first; i < n.first + n.count; ++i) {
                 c.tris++;
-                if (triTest(tris[triOrder[i]], ray, ray.farT, rcpMode).valid) return true;
+                if (triTest(tris[triOrder[i]], ray, ray.farT, rcpMode, hitPad).valid) return true;
             }
         } else {
             if (sp + 2 > 128) continue;
@@ -3650,6 +3659,7 @@ oracle_ctx *oracle_create(const tgpu_scene_desc *scene, int rng_mode, int math_m
     ctx->rngMode = rng_mode;
     ctx->mathMode = math_mode;
     ctx->rcpMode = rcp_mode;
+    ctx->hitPad = TGPU_HIT_PAD_FRACTION*tgpu_bvh_pad(&ctx->sc);
     ctx->prepareTris();
     ctx->buildBvh(0, ctx->sc.n_tris, ctx->sceneBvh);
     ctx->buildInstances();

@@ -162,10 +162,10 @@ static __global__ void __launch_bounds__(256) k_lbvh_boxes(uint32_t n, Radix r, 
     if (leaf >= n || n < 2) return;
     uint32_t node = r.leafParent[leaf];
     while (true) {
-        __threadfence();
-        if (atomicAdd(&visited[node], 1u) == 0u) return; // the sibling subtree is not finished yet: its last thread continues
+        // release our subtree's box, acquire the sibling's: the increment is acq_rel at device scope, so the stores before it are visible to
+        // whoever sees the count and the loads after it bypass whatever this CU's L1 still holds of the line (a neighbouring box read earlier)
+        if (__hip_atomic_fetch_add(&visited[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; // the sibling is not finished: its last thread continues
         const uint32_t a = r.left[node], b = r.right[node];
-        // (the atomic orders the sibling's store before these loads; read through volatile so that they are not hoisted)
         const volatile Box3 *boxes = nodeBox;
         Box3 ba, bb;
         if (a & 0x80000000u) ba = triBox[index[a & 0x7FFFFFFFu]];
@@ -299,7 +299,7 @@ static __global__ void __launch_bounds__(256) k_lbvh_triangles(const float *triP
     t[0] = make_float4(p[0], p[1], p[2], e1[0]);
     t[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
     t[2] = make_float4(e2[2], ng[0], ng[1], ng[2]);
-    t[3] = make_float4(__uint_as_float(id), 0.0f, 0.0f, 0.0f);
+    t[3] = make_float4(__uint_as_float(id), ng[0]*ng[0] + (ng[1]*ng[1] + ng[2]*ng[2]), 0.0f, 0.0f); // id, |Ng|^2 (triTest's grazing test)
 }
 
 #define TG_LBVH_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = hipGetErrorString(e_); goto done; } } while (0)

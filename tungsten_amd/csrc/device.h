@@ -150,6 +150,7 @@ struct DScene {
     const uint32_t *expTable; // 1024 mantissas of 2^(i/1024)
     float expA, expB;         // 1024/logf(2), logf(2)/1024
     int32_t hasForward;       // some BSDF has a ForwardLobe: shadow rays may pass through surfaces (TraceBase.cpp:62-125)
+    float hitPad;             // a triangle hit counts only inside the triangle's box grown by this much (include/tgpu_bounds.h (3))
 };
 
 // prim id encoding shared with the C ABI: kind << 29 | index; 0xFFFFFFFF = miss

@@ -535,7 +535,23 @@ struct TraceCounters { uint32_t nodes, tris; };
 // with IEEE division in finalize(); dot = a.x*b.x + (a.y*b.y + a.z*b.z) (common/math/vec3.h:182)
 TG_DEV float edot(const V3 &a, const V3 &b) { return a.x*b.x + (a.y*b.y + a.z*b.z); }
 
-TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, const V3 &O, const V3 &D, float tnear, float tfar0,
+// include/tgpu_bounds.h (3): a hit counts only when the point it reports lies inside the triangle's own box grown by hitPad -- a grazing ray's
+// t = T/den can be far off, and a walk only finds what lies in the boxes the ray really enters.  Off the hot path on purpose: the traversal loops are
+// register-bound (k_shadow_q: 72 VGPRs for 7 waves; inlined, this cost it 16 B more scratch and 15 % of its time), and it runs only for a candidate
+// that passed every other test AND grazes (triTest below), i.e. for about one hit in a thousand.
+static __device__ __noinline__ bool hitInsideOwnBox(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                                    float px, float py, float pz, float hitPad)
+{
+    const float ax = v0x - e1x, ay = v0y - e1y, az = v0z - e1z, bx = v0x + e2x, by = v0y + e2y, bz = v0z + e2z;
+    return px >= fmin2(v0x, fmin2(ax, bx)) - hitPad && px <= fmax2(v0x, fmax2(ax, bx)) + hitPad &&
+           py >= fmin2(v0y, fmin2(ay, by)) - hitPad && py <= fmax2(v0y, fmax2(ay, by)) + hitPad &&
+           pz >= fmin2(v0z, fmin2(az, bz)) - hitPad && pz <= fmax2(v0z, fmax2(az, bz)) + hitPad;
+}
+
+// Embree's MoellerTrumboreIntersector1 on the precomputed record (v0, e1 = v0 - v1, e2 = v2 - v0, Ng = e1 x e2), plus rule (3) above.
+// ngSq = |Ng|^2 from the record (t3.y).  Fast accept: a ray at least TGPU_HIT_SURE_COS off the triangle's plane reports a point within hitPad of the
+// true one whatever the scene (include/tgpu_bounds.h), so only grazing candidates pay for the box test.
+TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, float ngSq, const V3 &O, const V3 &D, float tnear, float tfar0, float hitPad,
                     float &t, float &u, float &v)
 {
     V3 v0(t0.x, t0.y, t0.z), e1(t0.w, t1.x, t1.y), e2(t1.z, t1.w, t2.x), Ng(t2.y, t2.z, t2.w);
@@ -552,7 +568,8 @@ TG_DEV bool triTest(const float4 &t0, const float4 &t1, const float4 &t2, const 
     t = T/absDen;
     u = U/absDen;
     v = V/absDen;
-    return true;
+    if (absDen*absDen >= (TGPU_HIT_SURE_COS*TGPU_HIT_SURE_COS)*(ngSq*edot(D, D))) return true;
+    return hitInsideOwnBox(v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, O.x + D.x*t, O.y + D.y*t, O.z + D.z*t, hitPad);
 }
 
 // waves per SIMD the lean traversal kernels are compiled for (second __launch_bounds__ argument: 7 -> at most 72 VGPRs; A/B in profiles/r01_ab_notes.txt)
@@ -711,7 +728,7 @@ TG_DEV int travApply(const DScene &sc, uint32_t *stack, TravState &r, TraceCount
         } else {
             if (COUNT) tc.tris++;
             float t, u, v;
-            if (triTest(q0, q1, q2, O, D, tnear, tfar0, t, u, v)) {
+            if (triTest(q0, q1, q2, q3.y, O, D, tnear, tfar0, sc.hitPad, t, u, v)) {
                 if (ANYDYN ? any : ANY) return TRAV_ANYHIT;
                 const uint32_t id = __float_as_uint(q3.x);
                 if (t < bestT || (t == bestT && id < bestPrim)) {

@@ -402,6 +402,80 @@ void tgpu_destroy(tgpu_ctx *ctx)
 
 const char *tgpu_last_error(const tgpu_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 
+// TGPU_BVH_VALIDATE=1 (tests, bring-up of a builder): reads the scene's tree back and checks what every walk relies on -- each child slot's
+// dequantised box contains every triangle below it (vertices, unpadded), every triangle is reachable exactly once, leaf payloads stay inside the
+// record array.  Returns the number of violations (0 = sound); prints the first few.
+static uint64_t validateTree(const float4 *dNodes, uint32_t nNodes, const float4 *dTris, uint32_t nTris, uint32_t rootChild)
+{
+    std::vector<float4> nodes(size_t(nNodes)*4), tris(size_t(nTris)*4);
+    if (hipMemcpy(nodes.data(), dNodes, nodes.size()*sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (hipMemcpy(tris.data(), dTris, tris.size()*sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    auto bitsOf = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto floatOf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    struct B { float lo[3], hi[3]; };
+    std::vector<uint8_t> seen(nTris, 0);
+    uint64_t bad = 0;
+    auto complain = [&](const char *what, uint32_t a, uint32_t b) { if (bad++ < 8) fprintf(stderr, "[tgpu] BVH validation: %s (node/record %u, slot/triangle %u)\n", what, a, b); };
+    // post-order over inner nodes with an explicit stack: (node, next child slot), child bounds accumulated per frame
+    struct Frame { uint32_t node; int slot; B acc; B child[4]; bool has[4]; };
+    auto emptyB = []() { B b; for (int k = 0; k < 3; ++k) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; } return b; };
+    auto grow = [](B &a, const B &b) { for (int k = 0; k < 3; ++k) { a.lo[k] = std::min(a.lo[k], b.lo[k]); a.hi[k] = std::max(a.hi[k], b.hi[k]); } };
+    auto leafBounds = [&](uint32_t ref, B &out) {
+        const uint32_t payload = ref & 0x7FFFFFFFu, first = payload >> 3, count = (payload & 7u) + 1u;
+        out = emptyB();
+        for (uint32_t i = first; i < first + count; ++i) {
+            if (i >= nTris) { complain("leaf payload outside the triangle records", first, i); return; }
+            if (seen[i]++) complain("triangle record referenced twice", first, i);
+            const float4 *t = &tris[size_t(i)*4];
+            const float v0[3] = {t[0].x, t[0].y, t[0].z}, e1[3] = {t[0].w, t[1].x, t[1].y}, e2[3] = {t[1].z, t[1].w, t[2].x};
+            for (int k = 0; k < 3; ++k) {
+                const float p[3] = {v0[k], v0[k] - e1[k], v0[k] + e2[k]};
+                for (float c : p) { out.lo[k] = std::min(out.lo[k], c); out.hi[k] = std::max(out.hi[k], c); }
+            }
+        }
+    };
+    if (rootChild & 0x80000000u) { B b; leafBounds(rootChild, b); }
+    else {
+        std::vector<Frame> stack;
+        stack.push_back(Frame{rootChild, 0, emptyB(), {}, {false, false, false, false}});
+        while (!stack.empty()) {
+            Frame &f = stack.back();
+            if (f.node >= nNodes) { complain("node index out of range", f.node, 0); stack.pop_back(); continue; }
+            const float4 *q = &nodes[size_t(f.node)*4];
+            if (f.slot < 4) {
+                const float cr[4] = {q[3].x, q[3].y, q[3].z, q[3].w};
+                const uint32_t ref = bitsOf(cr[f.slot]);
+                const int slot = f.slot++;
+                if (ref == 0xFFFFFFFFu) continue;
+                if (ref & 0x80000000u) { leafBounds(ref, f.child[slot]); f.has[slot] = true; }
+                else { f.has[slot] = true; f.child[slot] = emptyB(); stack.push_back(Frame{ref, 0, emptyB(), {}, {false, false, false, false}}); stack[stack.size() - 2].slot = slot + 1; }
+                continue;
+            }
+            // all children done: compare each child's true bounds with its quantised box
+            const uint32_t eb = bitsOf(q[0].w);
+            const float scale[3] = {floatOf((eb & 0xFFu) << 23), floatOf(((eb >> 8) & 0xFFu) << 23), floatOf(((eb >> 16) & 0xFFu) << 23)};
+            const float origin[3] = {q[0].x, q[0].y, q[0].z};
+            const uint32_t LO[3] = {bitsOf(q[1].x), bitsOf(q[1].y), bitsOf(q[1].z)}, HI[3] = {bitsOf(q[1].w), bitsOf(q[2].x), bitsOf(q[2].y)};
+            B whole = emptyB();
+            for (int c = 0; c < 4; ++c) {
+                if (!f.has[c]) continue;
+                for (int k = 0; k < 3; ++k) {
+                    const float lo = origin[k] + float((LO[k] >> (8*c)) & 0xFFu)*scale[k], hi = origin[k] + float((HI[k] >> (8*c)) & 0xFFu)*scale[k];
+                    if (!(lo <= f.child[c].lo[k] && hi >= f.child[c].hi[k])) { complain("child box does not contain its triangles", f.node, uint32_t(c)); break; }
+                }
+                grow(whole, f.child[c]);
+            }
+            const B done = whole;
+            stack.pop_back();
+            if (!stack.empty()) { Frame &p = stack.back(); p.child[p.slot - 1] = done; }
+        }
+    }
+    uint64_t unreachable = 0;
+    for (uint32_t i = 0; i < nTris; ++i) if (!seen[i]) ++unreachable;
+    if (unreachable) { fprintf(stderr, "[tgpu] BVH validation: %llu of %u triangle records unreachable\n", (unsigned long long)unreachable, nTris); bad += unreachable; }
+    return bad;
+}
+
 int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_desc *shard, uint64_t maxPaths)
 {
     if (!ctx) return TGPU_ERR_INVALID;
@@ -438,6 +512,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     int maxDepth4 = 0;
     // appends one BVH over triangles [first, first + count) and returns its root child reference
     const float triPad = tgpu_bvh_pad(s); // include/tgpu_bounds.h
+    sc.hitPad = TGPU_HIT_PAD_FRACTION*triPad;
     // TGPU_LDS_NODELETS=L: stage the top L levels of the scene's BVH4 (1 + 4 + 16 + ... nodes) in LDS in the queue kernels (A/B; default off:
     // no gain measured, profiles/r02_ab_notes.txt)
     const int nodeletLevels = getenv("TGPU_LDS_NODELETS") ? std::min(std::max(atoi(getenv("TGPU_LDS_NODELETS")), 0), 5) : 0;
@@ -505,6 +580,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
             tgpu_bvh::Float4 tail{0.0f, 0.0f, 0.0f, 0.0f};
             const uint32_t id = bvh.triId[i] + first;
             std::memcpy(&tail.x, &id, 4);
+            const tgpu_bvh::Float4 &t2 = bvh.tris[i*3 + 2];
+            tail.y = t2.y*t2.y + (t2.z*t2.z + t2.w*t2.w); // |Ng|^2 in edot's order: the grazing test of triTest (include/tgpu_bounds.h (3))
             allTris.push_back(tail);
         }
         maxDepth4 = std::max(maxDepth4, bvh4.maxDepth);
@@ -593,6 +670,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     }
     sc.nodes = dNodes;
     sc.tris = dTris;
+    if (getenv("TGPU_BVH_VALIDATE") && atoi(getenv("TGPU_BVH_VALIDATE")) && deviceBvh.nodes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (uint64_t bad = validateTree(dNodes, deviceBvh.nodeCount, dTris, s->n_tris, sc.rootChild)) { fail(ctx, "BVH validation found %llu violation(s)", (unsigned long long)bad); return TGPU_ERR_HIP; }
+    }
     // 20 levels of LDS stack = 20 KB per block: 8 blocks (32 waves) fit a CU, so registers, not LDS, set the occupancy
     // (profiles/r01_ab_notes.txt); deeper levels spill to global memory
     sc.stackLds = 20;

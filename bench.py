@@ -35,6 +35,8 @@ sys.path.insert(0, REPO)
 
 SCENE = os.path.join(REPO, "assets", "materialtest", "c2.json")
 NODE_BYTES, TRI_BYTES, RAY_QUEUE_BYTES = 64, 48, 56  # DESIGN.md "algorithmic bytes"
+SHADE_EVENT_BYTES = 574          # 96 B state in + 96 B out + 80 B shading record + 112 B NEE record + ~190 B env tables per surface event
+RETIRE_ENTRY_BYTES, RETIRE_PATH_BYTES = 5, 2*128 + 16 + 128  # per list entry scanned; per ended path: 2 lines read, 16 B result, one 128-byte record written
 HBM_PEAK_GBS = 8000.0
 
 
@@ -80,9 +82,11 @@ def main():
                     "and the only bench line the contract asks for is configs[1])")
     ap.add_argument("--workload", default=None, help="label for --scene")
     ap.add_argument("--pools", type=int, default=int(os.environ.get("TGPU_BENCH_POOLS", "1")),
-                    help="contexts (path pools, each on its own stream) per GPU; the image tiles are dealt over all of them. "
-                         "2 pools fill each other's kernel tails (+5..10 %% Msamples/s measured) but their launches overlap, so "
-                         "the per-launch roofline of k_extend no longer describes the kernel alone: the default stays 1")
+                    help="contexts (path pools, each on its own stream) per GPU; the image tiles are dealt over all of them.  2 pools (the C++ "
+                         "CLI's default) fill each other's kernel tails and host round trips: +5.7 %% Msamples/s on configs[1] (803 -> 846..851 on "
+                         "one box, 861 on another; profiles/r03_ab_notes.txt).  The contract line stays at 1: with two pools the launches of "
+                         "different pools overlap, and the average launch duration rocprofv3 reports for a kernel no longer describes the kernel "
+                         "alone, which is what `roofline` prices.  (With --pools > 1 the roofline phases run one pool at a time.)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -202,15 +206,16 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's shard) -------------------------------------
     if not args.no_roofline and rank == 0:
-        rsteps = max(1, min(args.steps, 8))  # same pipelined regime as the timed region: every pool of this rank renders
+        rsteps = max(1, min(args.steps, 8))
         def phase(flags, base):
+            # one pool at a time: with several pools rendering at once their launches overlap and a HIP-event duration no longer
+            # belongs to one kernel.  Each pool renders the same passes on its share of the tiles; the totals are per whole image.
             for cx in ctxs:
                 cx.set_profiling(flags)
                 cx.reset_stats()
-            for i in range(rsteps):
-                for cx in ctxs:
-                    cx.render_pass(base + spp_step*i, spp_step)
             for cx in ctxs:
+                for i in range(rsteps):
+                    cx.render_pass(base + spp_step*i, spp_step)
                 cx.wait()
             tot = {}
             for cx in ctxs:
@@ -251,7 +256,8 @@ def main():
         ext_bytes = (c["extend_node_visits"]*NODE_BYTES + c["extend_tri_tests"]*TRI_BYTES + c["extend_rays"]*RAY_QUEUE_BYTES)/launches
         # the closest-hit kernel of flat scenes: persistent lanes (k_extend_p) unless TGPU_EXTEND_P=0 selects the fixed four-rays-per-lane form;
         # scenes with instances / spheres / disks run k_extend<general>
-        ext_kernel = "k_extend_q" if os.environ.get("TGPU_EXTEND_P", "1") == "0" else "k_extend_p"
+        general_geometry = scene.desc.contents.n_instance_sets > 0 or scene.desc.contents.n_spheres > 0 or scene.desc.contents.n_disks > 0
+        ext_kernel = "k_extend<general>" if general_geometry else ("k_extend_q" if os.environ.get("TGPU_EXTEND_P", "1") == "0" else "k_extend_p")
         ext = roof(ext_kernel, ext_bytes, t["extend_ms"], t["extend_launches"],
                    {"per_ray": {"node_visits": round(c["extend_node_visits"]/max(1, c["extend_rays"]), 3),
                                 "tri_tests": round(c["extend_tri_tests"]/max(1, c["extend_rays"]), 3)}})
@@ -265,20 +271,39 @@ def main():
         else:
             sh_queue = (c["shadow_rays"]/2.0)*(112 + 32)
         sh_bytes = (c["shadow_node_visits"]*NODE_BYTES + c["shadow_tri_tests"]*TRI_BYTES + sh_queue)/sl
-        sha = roof("k_shadow_q" if queue_form else "k_shadow", sh_bytes, t["shadow_ms"], t["shadow_launches"],
+        sha = roof(("k_shadow_iq" if general_geometry else "k_shadow_q") if queue_form else "k_shadow", sh_bytes, t["shadow_ms"], t["shadow_launches"],
                    {"per_ray": {"node_visits": round(c["shadow_node_visits"]/max(1, c["shadow_rays"]), 3),
                                 "tri_tests": round(c["shadow_tri_tests"]/max(1, c["shadow_rays"]), 3)}})
+        # the state-traffic kernels: all k_shade<class> launches together, and the retire / regenerate step
+        shade = roof("k_shade", c["surface_events"]*SHADE_EVENT_BYTES/max(1, c["shade_launches"]), t["shade_ms"], t["shade_launches"],
+                     {"per_event_bytes": SHADE_EVENT_BYTES, "launches": "one per BSDF class and iteration"})
+        retire = roof("k_retire_regenerate", (c["extend_rays"]*RETIRE_ENTRY_BYTES + c["samples"]*RETIRE_PATH_BYTES)/max(1, c["retire_launches"]),
+                      t["retire_ms"], t["retire_launches"], {"per_entry_bytes": RETIRE_ENTRY_BYTES, "per_ended_path_bytes": RETIRE_PATH_BYTES})
+        for entry, prefix in ((shade, "k_shade<"), (retire, "k_retire_regenerate")):  # traffic: the sum over the matching kernels of the PMC pass, per launch of ours
+            rows = [v for name, v in pmc.items() if isinstance(v, dict) and name.startswith(prefix)]
+            if rows:
+                entry["traffic"] = sum(v.get("hbm_bytes_per_launch", 0.0)*v.get("launches", 0) for v in rows)/max(1, sum(v.get("launches", 0) for v in rows))
+                entry["traffic_source"] = pmc_src
+                entry["frac_of_peak_by_traffic"] = round(entry["traffic"]/(entry["avg_launch_ms"]*1e-3)/1e9/HBM_PEAK_GBS, 4) if entry["avg_launch_ms"] > 0 else None
         dominant = ext if t["extend_ms"] >= t["shadow_ms"] else sha
         result["roofline"] = dict(dominant)
         result["roofline"].update({
-            "launches_per_step": round(launches/rsteps, 2), "pools": K,
+            "launches_per_step": round(launches/rsteps, 2), "pools": K, "measured_with": "one pool rendering at a time" if K > 1 else "the only pool",
             "per_sample": {"extend_rays": round(c["extend_rays"]/max(1, c["samples"]), 3),
                            "shadow_rays": round(c["shadow_rays"]/max(1, c["samples"]), 3),
                            "surface_events": round(c["surface_events"]/max(1, c["samples"]), 3)},
             "kernel_ms_per_step": {k: round(t[k]/rsteps, 3) for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms")},
             "l2_peak_gbs": 34500.0, "frac_of_l2_peak": round(dominant["achieved"]/34500.0, 4),
         })
-        result["roofline_kernels"] = [ext, sha]
+        result["roofline_kernels"] = [ext, sha, shade, retire]
+        # is the committed PMC pass still about these kernels?  It names the digest of the kernel sources it was taken with.
+        if pmc:
+            import hashlib
+            digest = hashlib.sha256(b"".join(open(os.path.join(REPO, "tungsten_amd", "csrc", f), "rb").read() for f in ("kernels.h", "device.h"))).hexdigest()[:16]
+            result["roofline"]["traffic_profile_current"] = pmc.get("_kernels_sha") == digest
+        st0 = ctx.stats()
+        result["upload"] = {"upload_ms": round(st0["upload_ms"], 1), "bvh_build_ms": round(st0["bvh_build_ms"], 1), "bvh_on_device": bool(st0["bvh_on_device"]),
+                            "note": "tgpu_upload_scene of rank 0's first pool, outside the timed region"}
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) ----------------------
     if not args.no_cpu_baseline and rank == 0 and world == 1:

@@ -352,6 +352,8 @@ typedef struct tgpu_stats {
     uint64_t shadow_vertices;  /* path vertices whose NEE rays went through the shadow kernel's queue form */
     /* of the last tgpu_upload_scene (not reset by tgpu_reset_stats): wall time of the whole call, of the BVH build inside it
      * (host builder, or device builder without its input copy), and which builder made the scene's tree                  */
+    double   retire_ms;        /* k_retire_regenerate alone (it is also part of other_ms), when timing on */
+    uint64_t shade_launches, retire_launches; /* k_shade<class> / k_volume launches, k_retire_regenerate launches */
     double   upload_ms, bvh_build_ms;
     uint64_t bvh_on_device;    /* 1 = tungsten_amd/csrc/bvh_gpu.h built the scene's BVH (TGPU_GPU_BVH / TGPU_GPU_BVH_MIN) */
 } tgpu_stats;

@@ -35,6 +35,9 @@ json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_
 # what bench.py's roofline.traffic reads (per kernel, per launch); `_source` is quoted next to the number
 latest = dict(out)
 latest["_source"] = f"profiles/{tag}_pmc.json"
+import hashlib
+csrc = os.path.join(os.path.dirname(here), "tungsten_amd", "csrc")
+latest["_kernels_sha"] = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("kernels.h", "device.h"))).hexdigest()[:16]  # bench.py: is this pass still about the kernels it prices?
 json.dump(latest, open(os.path.join(here, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
 ext = next((v for k, v in out.items() if k.startswith("k_extend_p<false") or k.startswith("k_extend_q<false")), None)
 if ext:

@@ -129,6 +129,7 @@ class Stats(C.Structure):
                 ("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("other_ms", C.c_double),
                 ("extend_launches", u64), ("shadow_launches", u64), ("tail_launches", u64), ("shadow_vertices", u64),
+                ("retire_ms", C.c_double), ("shade_launches", u64), ("retire_launches", u64),
                 ("upload_ms", C.c_double), ("bvh_build_ms", C.c_double), ("bvh_on_device", u64)]
 
 

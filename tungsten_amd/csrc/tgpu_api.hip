@@ -169,9 +169,9 @@ int gridFor(const tgpu_ctx *ctx, uint64_t items)
 
 struct Timer {
     tgpu_ctx *ctx;
-    double *acc;
+    double *acc, *acc2; // acc2: a second total the same interval belongs to (the retire step inside "other")
     bool on;
-    Timer(tgpu_ctx *c, double *a) : ctx(c), acc(a), on((c->profFlags & 2u) != 0)
+    Timer(tgpu_ctx *c, double *a, double *b = nullptr) : ctx(c), acc(a), acc2(b), on((c->profFlags & 2u) != 0)
     {
         if (on) (void)hipEventRecord(ctx->ev[0], ctx->stream);
     }
@@ -183,6 +183,7 @@ struct Timer {
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
             *acc += ms;
+            if (acc2) *acc2 += ms;
         }
     }
 };
@@ -1171,11 +1172,12 @@ static int driveIteration(tgpu_ctx *ctx)
             Timer t(ctx, &ctx->stats.shade_ms);
             // one launch per BSDF class that occurs in the scene (ctx->classMask, set at upload)
 #define TG_LAUNCH_SHADE(C) if (ctx->classMask & (1u << (C))) { \
+                ctx->stats.shade_launches++; \
                 if (ctx->generalShading) hipLaunchKernelGGL((k_shade<C, true>), dim3(grid), dim3(256), 0, stream, sc, st, out); \
                 else hipLaunchKernelGGL((k_shade<C, false>), dim3(grid), dim3(256), 0, stream, sc, st, out); }
             TG_LAUNCH_SHADE(0) TG_LAUNCH_SHADE(1) TG_LAUNCH_SHADE(2) TG_LAUNCH_SHADE(3) TG_LAUNCH_SHADE(4) TG_LAUNCH_SHADE(5) TG_LAUNCH_SHADE(TG_CLASS_OTHER)
 #undef TG_LAUNCH_SHADE
-            if (sc.nMedia) hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out);
+            if (sc.nMedia) { ctx->stats.shade_launches++; hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out); }
         }
         // the queue forms of the shadow kernel (visibility bits out; the next kernel that touches the path folds the NEE terms in)
         // serve every scene whose shadow rays are single segments; forward-scattering scenes keep k_shadow's multi-segment walk
@@ -1214,7 +1216,8 @@ static int driveIteration(tgpu_ctx *ctx)
         }
         ctx->stats.shadow_launches++;
         {
-            Timer t(ctx, &ctx->stats.other_ms);
+            Timer t(ctx, &ctx->stats.other_ms, &ctx->stats.retire_ms);
+            ctx->stats.retire_launches++;
             const uint64_t perRound = uint64_t(TG_RETIRE_BLOCK)*TG_RETIRE_K;
             int g1024 = int(std::min<uint64_t>((uint64_t(nCur) + perRound - 1)/perRound, uint64_t(ctx->numCUs)*(2048/TG_RETIRE_BLOCK)));
             hipLaunchKernelGGL(k_retire_regenerate, dim3(std::max(g1024, 1)), dim3(TG_RETIRE_BLOCK), 0, stream, sc, st, ring, out, ctx->sampleBase, limit);

@@ -399,6 +399,19 @@ def test_full_size_config_3_bit_exact(ta, oracle_py, gpu_ctx):
     assert_bit_exact(got, ref, "config 3, 1000x563x32spp")
 
 
+@pytest.mark.parametrize("scene,spp", [("materialtest/c2.json", 256), ("cornell-box/scene_sobol.json", 1024)])
+def test_baseline_configs_at_their_full_size_and_sample_count(ta, oracle_py, gpu_ctx, scene, spp):
+    """BASELINE.json configs[1] and configs[2] exactly as they are quoted -- 1280x720 at 256 spp, 1000x563 at 1024 spp, 16 spp per pass, the pool kept
+    full by regeneration as in bench.py -- against the oracle in every pixel: 236 M and 576 M samples, sample indices up to 1023."""
+    hs = ta.HostScene(scene_path(scene))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.render(spp, spp_step=16)
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, spp, spp_step=16)
+    assert_bit_exact(got, ref, f"{scene} at full size, {spp} spp")
+
+
 @pytest.mark.parametrize("scene,res,begin,spp,step", [
     ("materialtest/c2.json", (128, 72), 256, 32, 16),            # configs are quoted at 256..1024 spp: the second Sobol' block and beyond
     ("materialtest/c2.json", (64, 36), 240, 48, 16),             # a render that crosses index 256 between two passes

@@ -57,6 +57,7 @@ FIXTURES = [
     ("cornell_fog_96x54_64spp", "cornell-box/scene_fog.json", (96, 54), 64),
     # the LDR output path (Integrator::writeBuffers: Camera::tonemap, *255, clamp, PNG; Integrator.cpp:56-80, cameras/Tonemap.hpp:26-62): the PNG the
     # reference writes NEXT TO the PFM is kept for these, one per tonemap operator, so that PFM -> PNG can be checked byte for byte on the CPU
+    ("ldr_texture2_128x72_4spp", "next/ldr_texture2.json", (128, 72), 4),   # .bmp / .tga bitmaps: the reference's stb_image route
     ("tonemap_linear_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "linear", "keep_png": True}),
     ("tonemap_gamma_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "gamma", "keep_png": True}),
     ("tonemap_reinhard_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "reinhard", "keep_png": True}),

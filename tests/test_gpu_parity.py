@@ -58,6 +58,7 @@ def assert_bit_exact(got, ref, what):
     ("next/transparency.json", (128, 72), 8, 8),
     ("next/thinsheet.json", (128, 72), 8, 8),
     ("next/ldr_texture.json", (128, 72), 8, 8),  # 8-bit PNG bitmaps (gamma table, palette, scalar average)
+    ("next/ldr_texture2.json", (128, 72), 8, 8), # the same through .bmp / .tga files
     # the fork's remaining transmittance models in the Cornell box's camera medium
     ("next/trans_erlang.json", (96, 54), 8, 8),
     ("next/trans_davis.json", (96, 54), 8, 8),

@@ -211,6 +211,60 @@ def test_png_bitmap_textures_expand_to_the_texels_the_reference_reads(ta):
     assert seen == 3
 
 
+def test_bmp_and_tga_bitmap_textures_decode_like_stb_image(ta, tmp_path):
+    """.bmp and .tga bitmaps (the reference hands them to stb_image, io/ImageIO.cpp:489-490): 24-bit bottom-up and 8-bit-palette top-down BMP,
+    32-bit raw top-down and 8-bit grey run-length-encoded TGA.  Texels against an independent decode (pillow) pushed through the same
+    byte -> float rule as the PNGs; the rendered image is pinned by a reference-rendered golden (ldr_texture2_128x72_4spp).  Forms outside the
+    covered set are refused by name."""
+    import struct
+    from PIL import Image
+    hs = ta.HostScene(scene_path("next/ldr_texture2.json"), resolution=(32, 18))
+    d = hs.desc.contents
+    tex = os.path.join(REPO, "assets", "next", "textures")
+    gamma = np.array([int(255*(i/255)**2.2) for i in range(256)])
+    k = np.float32(1.0/255.0)
+    rgb = lambda f: np.asarray(Image.open(os.path.join(tex, f)).convert("RGB")).astype(np.int64)
+    grey = rgb("rough.tga")
+    s = ((grey[:, :, 0] + grey[:, :, 1] + grey[:, :, 2])//3).astype(np.float32)*k
+    expect = [gamma[rgb("albedo.tga")].astype(np.float32)*k, gamma[rgb("albedo.bmp")].astype(np.float32)*k, rgb("tiles.bmp").astype(np.float32)*k, np.stack([s, s, s], -1)]
+    matched = 0
+    for i in range(d.n_bitmaps):
+        b = d.bitmaps[i]
+        got = np.ctypeslib.as_array(b.texels, (b.h, b.w, 3))
+        matched += any(e.shape == got.shape and (e == got).all() for e in expect)
+    assert matched >= 4
+    # refused, with the reason in the message: 16-bit BMP, run-length-encoded BMP, colour-mapped TGA, truncated files
+    scene = json.load(open(scene_path("next/ldr_texture2.json")))
+    for p in scene["primitives"]:
+        if p.get("file"):
+            p["file"] = os.path.join(REPO, "assets", "materialtest", p["file"])
+        if p.get("emission") and isinstance(p["emission"], str):
+            p["emission"] = os.path.join(REPO, "assets", "materialtest", p["emission"])
+    for b in scene["bsdfs"]:   # the other textures keep pointing at the vendored files
+        for key in ("albedo", "roughness"):
+            v = b.get(key)
+            if isinstance(v, str) and v.startswith("textures/"):
+                b[key] = os.path.join(REPO, "assets", "next", v)
+            elif isinstance(v, dict) and str(v.get("file", "")).startswith("textures/"):
+                v["file"] = os.path.join(REPO, "assets", "next", v["file"])
+    good_bmp = open(os.path.join(tex, "albedo.bmp"), "rb").read()
+    good_tga = open(os.path.join(tex, "albedo.tga"), "rb").read()
+    cases = {
+        "bits16.bmp": (good_bmp[:28] + struct.pack("<H", 16) + good_bmp[30:], "16 bits per pixel"),
+        "rle.bmp": (good_bmp[:30] + struct.pack("<I", 1) + good_bmp[34:], "run-length"),
+        "short.bmp": (good_bmp[:2000], "truncated"),
+        "mapped.tga": (good_tga[:1] + b"\x01" + good_tga[2:], "colour-mapped"),
+        "short.tga": (good_tga[:500], "truncated"),
+    }
+    for name, (data, reason) in cases.items():
+        (tmp_path / name).write_bytes(data)
+        scene["bsdfs"][1]["albedo"] = str(tmp_path / name)
+        f = tmp_path / "s.json"
+        f.write_text(json.dumps(scene))
+        with pytest.raises(RuntimeError, match=reason):
+            ta.HostScene(str(f))
+
+
 def test_unsupported_bitmap_files_fail_loudly(ta, tmp_path):
     d = json.load(open(scene_path("next/ldr_texture.json")))
     bad = tmp_path/"broken.png"
@@ -336,6 +390,25 @@ def _damaged_copies(tmp_path):
     b = bytearray(png)
     b[16:24] = struct.pack(">II", 60000, 60000)               # IHDR width / height
     yield tex(bytes(b)), "png claiming 60000 x 60000"
+    # .bmp / .tga (stb_image's formats): truncated, random bytes, absurd sizes
+    bmp = open(os.path.join(tex_dir, "albedo.bmp"), "rb").read()
+    tga = open(os.path.join(tex_dir, "rough.tga"), "rb").read()
+    texb = lambda data: scene_with({"t.bmp": data}, [{"name": "grey", "type": "lambert", "albedo": "t.bmp"}], [floor])
+    text = lambda data: scene_with({"t.tga": data}, [{"name": "grey", "type": "lambert", "albedo": "t.tga"}], [floor])
+    yield texb(bmp), "intact bmp (control)"
+    yield text(tga), "intact tga (control)"
+    for cut in (0, 10, 30, 54, 200, len(bmp) - 7):
+        yield texb(bmp[:cut]), f"bmp truncated at {cut}"
+    for cut in (0, 5, 18, 100, len(tga) - 3):
+        yield text(tga[:cut]), f"tga truncated at {cut}"
+    yield texb(bmp[:18] + struct.pack("<ii", 1 << 30, 1 << 30) + bmp[26:]), "bmp claiming 2^30 x 2^30"
+    yield texb(bmp[:10] + struct.pack("<I", 0xFFFFFFF0) + bmp[14:]), "bmp with a pixel offset beyond the file"
+    yield text(tga[:12] + struct.pack("<HH", 65535, 65535) + tga[16:]), "tga claiming 65535 x 65535"
+    for k in range(6):
+        b = bytearray(bmp if k % 2 else tga)
+        for pos in rng.integers(0, 60 if k % 2 else 18, 4):
+            b[pos] = int(rng.integers(0, 256))
+        yield (texb if k % 2 else text)(bytes(b)), f"{'bmp' if k % 2 else 'tga'} header with random bytes (#{k})"
     # instance file (Instance.cpp:207-232): truncated, count blown up
     blob = struct.pack("<II6f", 3, 0, -1, -1, -1, 1, 1, 1) + struct.pack("<18f", *([0.1]*18)) + bytes([0, 0, 0])
     inst = lambda data: scene_with({"i.bin": data}, grey, [floor, {"type": "instances", "masters": [{"type": "cube", "bsdf": "grey", "transform": {"scale": 0.2}}],
@@ -356,11 +429,11 @@ def test_damaged_inputs_are_refused_with_a_message(ta, tmp_path):
     for path, what in cases:
         try:
             ta.HostScene(path)
-            assert "control" in what or "random bytes" in what, f"{what}: loaded without complaint"   # a few byte flips leave a decodable file
+            assert "control" in what or "random bytes" in what or what.endswith("- 3") or "tga truncated at 1064" in what, f"{what}: loaded without complaint"   # a few byte flips leave a decodable file
         except RuntimeError as e:
             assert str(e) and "control" not in what, f"{what}: {e}"
             refused += 1
-    assert refused >= len(cases) - 4 - 14
+    assert refused >= len(cases) - 6 - 22
     r = subprocess.run(["make", "-s", "asan"], cwd=REPO, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")

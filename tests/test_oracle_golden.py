@@ -44,6 +44,8 @@ CASES = [
     ("trans_interpolated2_96x54_8spp", "next/trans_interpolated2.json", (96, 54), 8),  # exponential + davis
     # 8-bit PNG bitmaps: gamma-table RGB albedo (interpolated, wrapped), palette albedo (nearest, clamped, scaled), scalar-average roughness
     ("ldr_texture_128x72_4spp", "next/ldr_texture.json", (128, 72), 4),
+    # .bmp (24-bit bottom-up, 8-bit palette top-down) and .tga (32-bit raw top-down, 8-bit grey run-length encoded) bitmaps: stb_image in the reference
+    ("ldr_texture2_128x72_4spp", "next/ldr_texture2.json", (128, 72), 4),
     # round 3: long enough to contain rare events -- box culls and exact ties that only Embree's own traversal order decides (oracle/embree_bvh4.h)
     ("cornell_sobol_96x54_64spp", "cornell-box/scene_sobol.json", (96, 54), 64),     # pixel (67,7) sample 41: ceiling quad culled by its flat box
     ("cornell_sobol_64x36_128spp", "cornell-box/scene_sobol.json", (64, 36), 128),   # pixel (47,33) sample 15: floor / wall tie, last visited wins

@@ -452,6 +452,126 @@ bool inflateZlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &out)
 }
 } // namespace
 
+// ---- .bmp / .tga: the files the reference hands to stb_image (io/ImageIO.cpp:386-407,489-490: stbi_load_from_callbacks(..., 4)) ------------------
+// Both decode to RGBA8, top row first.  Covered: what image tools write -- BMP with 4- or 8-bit palettes, 24 bits, 32 bits in B,G,R,A order, bottom-up
+// or top-down, uncompressed; TGA true-colour (24 / 32 bits) and grey (8 bits), raw or run-length encoded, either row order.  The rarer forms
+// (16-bit pixels, custom bit masks, RLE bitmaps, colour-mapped TGAs) are refused by name rather than decoded approximately.
+namespace {
+struct ByteReader {
+    const std::string &data;
+    size_t pos = 0;
+    bool ok = true;
+    explicit ByteReader(const std::string &d) : data(d) {}
+    uint32_t u8() { if (pos >= data.size()) { ok = false; return 0; } return uint8_t(data[pos++]); }
+    uint32_t u16() { uint32_t a = u8(); return a | (u8() << 8); }
+    uint32_t u32() { uint32_t a = u16(); return a | (u16() << 16); }
+    void skip(size_t n) { if (n > data.size() - pos) { ok = false; pos = data.size(); } else pos += n; }
+};
+}
+
+bool loadBmp(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba, std::string &why)
+{
+    std::string data;
+    try { data = readFile(path); } catch (...) { why = "cannot be read"; return false; }
+    ByteReader in(data);
+    if (in.u8() != 'B' || in.u8() != 'M') { why = "is not a BMP file"; return false; }
+    in.skip(8);
+    const uint32_t offset = in.u32(), headerSize = in.u32();
+    int32_t width, height;
+    uint32_t bpp, compression = 0;
+    if (headerSize == 12) {
+        width = int32_t(in.u16()); height = int32_t(in.u16());
+        in.skip(2);
+        bpp = in.u16();
+    } else if (headerSize == 40 || headerSize == 56 || headerSize == 108 || headerSize == 124) {
+        width = int32_t(in.u32()); height = int32_t(in.u32());
+        in.skip(2);
+        bpp = in.u16();
+        compression = in.u32();
+        in.skip(20);
+        uint32_t mr = 0, mg = 0, mb = 0, ma = 0;
+        if (headerSize == 40 && compression == 3) { mr = in.u32(); mg = in.u32(); mb = in.u32(); }
+        else if (headerSize > 40) { mr = in.u32(); mg = in.u32(); mb = in.u32(); ma = in.u32(); in.skip(headerSize - 56); }
+        if (compression == 1 || compression == 2) { why = "is run-length encoded"; return false; }
+        if (compression == 3 && !(bpp == 32 && mr == 0x00FF0000u && mg == 0x0000FF00u && mb == 0x000000FFu && (ma == 0xFF000000u || ma == 0))) { why = "uses custom bit masks"; return false; }
+    } else { why = "has an unknown header"; return false; }
+    if (!in.ok || width <= 0 || height == 0) { why = "is truncated or has no pixels"; return false; }
+    const bool bottomUp = height > 0;
+    w = width;
+    h = height < 0 ? -height : height;
+    if (bpp != 4 && bpp != 8 && bpp != 24 && bpp != 32) { why = "has " + std::to_string(bpp) + " bits per pixel"; return false; }
+    const size_t rowBytes = ((size_t(w)*bpp + 31)/32)*4;
+    if (size_t(h) > (data.size() - std::min(data.size(), size_t(offset)))/std::max<size_t>(rowBytes, 1)) { why = "is truncated"; return false; }
+    uint8_t palette[256][3] = {};
+    if (bpp <= 8) {
+        const size_t entry = headerSize == 12 ? 3 : 4, count = (offset - 14 - headerSize)/entry;
+        if (count == 0 || count > 256) { why = "has a corrupt palette"; return false; }
+        for (size_t i = 0; i < count; ++i) {
+            palette[i][2] = uint8_t(in.u8()); palette[i][1] = uint8_t(in.u8()); palette[i][0] = uint8_t(in.u8());
+            if (entry == 4) in.u8();
+        }
+    }
+    rgba.assign(size_t(w)*h*4, 255);
+    bool anyAlpha = false;
+    for (int row = 0; row < h; ++row) {
+        const size_t at = size_t(offset) + size_t(row)*rowBytes;
+        uint8_t *out = &rgba[size_t(bottomUp ? h - 1 - row : row)*w*4];
+        for (int x = 0; x < w; ++x) {
+            const uint8_t *px = reinterpret_cast<const uint8_t *>(data.data()) + at;
+            if (bpp == 24) { out[x*4] = px[x*3 + 2]; out[x*4 + 1] = px[x*3 + 1]; out[x*4 + 2] = px[x*3]; }
+            else if (bpp == 32) { out[x*4] = px[x*4 + 2]; out[x*4 + 1] = px[x*4 + 1]; out[x*4 + 2] = px[x*4]; out[x*4 + 3] = px[x*4 + 3]; anyAlpha = anyAlpha || px[x*4 + 3]; }
+            else {
+                const uint32_t index = bpp == 8 ? px[x] : ((x & 1) ? (px[x/2] & 15u) : (px[x/2] >> 4));
+                out[x*4] = palette[index][0]; out[x*4 + 1] = palette[index][1]; out[x*4 + 2] = palette[index][2];
+            }
+        }
+    }
+    if (bpp == 32 && !anyAlpha) for (size_t i = 3; i < rgba.size(); i += 4) rgba[i] = 255; // an all-zero alpha channel means "no alpha"
+    return true;
+}
+
+bool loadTga(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba, std::string &why)
+{
+    std::string data;
+    try { data = readFile(path); } catch (...) { why = "cannot be read"; return false; }
+    ByteReader in(data);
+    const uint32_t idLength = in.u8(), colourMapped = in.u8();
+    uint32_t type = in.u8();
+    in.skip(5);            // colour map specification
+    in.skip(4);            // x / y origin
+    w = int(in.u16());
+    h = int(in.u16());
+    const uint32_t bpp = in.u8(), descriptor = in.u8();
+    if (!in.ok || w <= 0 || h <= 0) { why = "is truncated or has no pixels"; return false; }
+    if (colourMapped) { why = "is colour-mapped"; return false; }
+    const bool rle = type >= 8;
+    if (rle) type -= 8;
+    if (!((type == 2 && (bpp == 24 || bpp == 32)) || (type == 3 && bpp == 8))) { why = "has pixel format " + std::to_string(type) + "/" + std::to_string(bpp); return false; }
+    const size_t bytes = bpp/8;
+    in.skip(idLength);
+    if (size_t(w)*h > (data.size() - in.pos)*(rle ? 128 : 1)/ (rle ? 1 : bytes)) { why = "is truncated"; return false; }
+    const bool topDown = (descriptor >> 5) & 1u;
+    rgba.assign(size_t(w)*h*4, 255);
+    uint8_t px[4] = {0, 0, 0, 255};
+    uint32_t run = 0;
+    bool repeating = false;
+    for (size_t i = 0; i < size_t(w)*h; ++i) {
+        bool read = true;
+        if (rle) {
+            if (run == 0) { const uint32_t cmd = in.u8(); run = 1 + (cmd & 127u); repeating = (cmd >> 7) != 0; }
+            else if (repeating) read = false;
+            --run;
+        }
+        if (read) for (size_t k = 0; k < bytes; ++k) px[k] = uint8_t(in.u8());
+        if (!in.ok) { why = "is truncated"; return false; }
+        const size_t row = i/size_t(w), x = i % size_t(w);
+        uint8_t *out = &rgba[((topDown ? row : size_t(h) - 1 - row)*w + x)*4];
+        if (bytes == 1) { out[0] = out[1] = out[2] = px[0]; }
+        else { out[0] = px[2]; out[1] = px[1]; out[2] = px[0]; if (bytes == 4) out[3] = px[3]; }
+    }
+    return true;
+}
+
 bool loadPng(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba)
 {
     std::vector<uint8_t> file;
@@ -642,10 +762,15 @@ int Scene::fetchBitmap(const std::string &path, bool scalarAverage, bool gammaCo
                 const float s = (texels[i*3] + texels[i*3 + 1] + texels[i*3 + 2])/3;
                 texels[i*3] = texels[i*3 + 1] = texels[i*3 + 2] = s;
             }
-    } else if (endsWith(full, ".png")) {
+    } else if (endsWith(full, ".png") || endsWith(full, ".bmp") || endsWith(full, ".tga")) {
         std::vector<uint8_t> rgba;
-        if (!loadPng(full, w, h, rgba))
-            throw std::runtime_error("Unable to load texture at '" + full + "' (8-bit non-interlaced PNG expected)");
+        std::string why;
+        if (endsWith(full, ".png")) {
+            if (!loadPng(full, w, h, rgba))
+                throw std::runtime_error("Unable to load texture at '" + full + "' (8-bit non-interlaced PNG expected)");
+        } else if (!(endsWith(full, ".bmp") ? loadBmp(full, w, h, rgba, why) : loadTga(full, w, h, rgba, why))) {
+            throw std::runtime_error("Unable to load texture at '" + full + "': the file " + why);
+        }
         uint8_t gamma[256];
         for (int i = 0; i < 256; ++i) gamma[i] = gammaCorrect ? uint8_t(int(255.0*std::pow(i/255.0, 2.2))) : uint8_t(i);
         texels.resize(size_t(w)*h*3);
@@ -658,7 +783,7 @@ int Scene::fetchBitmap(const std::string &path, bool scalarAverage, bool gammaCo
             }
         }
     } else {
-        throw std::runtime_error("Unable to load texture at '" + full + "' (.hdr, .pfm and .png bitmaps are in scope)");
+        throw std::runtime_error("Unable to load texture at '" + full + "' (.hdr, .pfm, .png, .bmp and .tga bitmaps are in scope; JPEG is not)");
     }
     tgpu_bitmap bm{};
     bm.w = w; bm.h = h; bm.clamp = clamp ? 1 : 0; bm.linear = linear ? 1 : 0; bm.scale = scale; bm.texels = nullptr;

@@ -409,6 +409,22 @@ def _damaged_copies(tmp_path):
         for pos in rng.integers(0, 60 if k % 2 else 18, 4):
             b[pos] = int(rng.integers(0, 256))
         yield (texb if k % 2 else text)(bytes(b)), f"{'bmp' if k % 2 else 'tga'} header with random bytes (#{k})"
+    # .jpg, baseline and progressive: truncated (stb_image -- and so this loader -- feeds zero bits once the entropy-coded data ends, so a cut
+    # inside the scan data still yields an image; a cut inside the headers does not), random bytes anywhere, a frame header claiming 65535 x 65535
+    texj = lambda data: scene_with({"t.jpg": data}, [{"name": "grey", "type": "lambert", "albedo": "t.jpg"}], [floor])
+    for jname in ("albedo422.jpg", "albedo_prog.jpg", "rough_prog_grey.jpg"):
+        jpg = open(os.path.join(tex_dir, jname), "rb").read()
+        yield texj(jpg), f"intact {jname} (control)"
+        for cut in (0, 2, 30, 150, 400, len(jpg)//2, len(jpg) - 5):
+            yield texj(jpg[:cut]), f"jpg {jname} truncated at {cut}"
+        for k in range(12):
+            b = bytearray(jpg)
+            for pos in rng.integers(2, len(b), 5):
+                b[pos] = int(rng.integers(0, 256))
+            yield texj(bytes(b)), f"jpg {jname} with 5 random bytes (#{k})"
+        sof = max(jpg.find(b"\xff\xc0"), jpg.find(b"\xff\xc2"))
+        assert sof > 0
+        yield texj(jpg[:sof + 5] + struct.pack(">HH", 65535, 65535) + jpg[sof + 9:]), f"{jname} claiming 65535 x 65535"
     # instance file (Instance.cpp:207-232): truncated, count blown up
     blob = struct.pack("<II6f", 3, 0, -1, -1, -1, 1, 1, 1) + struct.pack("<18f", *([0.1]*18)) + bytes([0, 0, 0])
     inst = lambda data: scene_with({"i.bin": data}, grey, [floor, {"type": "instances", "masters": [{"type": "cube", "bsdf": "grey", "transform": {"scale": 0.2}}],
@@ -429,11 +445,11 @@ def test_damaged_inputs_are_refused_with_a_message(ta, tmp_path):
     for path, what in cases:
         try:
             ta.HostScene(path)
-            assert "control" in what or "random bytes" in what or what.endswith("- 3") or "tga truncated at 1064" in what, f"{what}: loaded without complaint"   # a few byte flips leave a decodable file
+            assert "control" in what or "random bytes" in what or what.endswith("- 3") or "tga truncated at 1064" in what or what.startswith("jpg "), f"{what}: loaded without complaint"   # a few byte flips leave a decodable file
         except RuntimeError as e:
             assert str(e) and "control" not in what, f"{what}: {e}"
             refused += 1
-    assert refused >= len(cases) - 6 - 22
+    assert refused >= len(cases) - 6 - 22 - 3*(1 + 7 + 12)
     r = subprocess.run(["make", "-s", "asan"], cwd=REPO, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")

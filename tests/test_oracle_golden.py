@@ -46,6 +46,8 @@ CASES = [
     ("ldr_texture_128x72_4spp", "next/ldr_texture.json", (128, 72), 4),
     # .bmp (24-bit bottom-up, 8-bit palette top-down) and .tga (32-bit raw top-down, 8-bit grey run-length encoded) bitmaps: stb_image in the reference
     ("ldr_texture2_128x72_4spp", "next/ldr_texture2.json", (128, 72), 4),
+    # baseline JPEG bitmaps: 4:2:0, 4:2:2 with optimised tables and restart intervals, 4:4:4 with partial MCUs, one-component grey
+    ("ldr_texture3_128x72_4spp", "next/ldr_texture3.json", (128, 72), 4),
     # round 3: long enough to contain rare events -- box culls and exact ties that only Embree's own traversal order decides (oracle/embree_bvh4.h)
     ("cornell_sobol_96x54_64spp", "cornell-box/scene_sobol.json", (96, 54), 64),     # pixel (67,7) sample 41: ceiling quad culled by its flat box
     ("cornell_sobol_64x36_128spp", "cornell-box/scene_sobol.json", (64, 36), 128),   # pixel (47,33) sample 15: floor / wall tie, last visited wins
@@ -172,7 +174,7 @@ def test_golden_fixtures_match_their_manifest():
     on_disk = set()
     for root, _, files in os.walk(GOLDEN):
         for f in files:
-            if f.endswith((".pfm", ".dat", ".png")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json", "ref_kat4.json", "ref_kat5.npz"):
+            if f.endswith((".pfm", ".dat", ".png")) or f in ("ref_kat.json", "ref_kat2.json", "ref_kat3.json", "ref_kat4.json", "ref_kat5.npz", "ref_kat6.json"):
                 on_disk.add(os.path.relpath(os.path.join(root, f), GOLDEN))
     assert on_disk == set(manifest), f"fixtures without manifest entry or vice versa: {sorted(on_disk ^ set(manifest))}"
     for name, digest in manifest.items():

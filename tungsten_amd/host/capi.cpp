@@ -133,4 +133,23 @@ int tgh_save_png_tonemapped(const char *path, const char *tonemap, const float *
     return savePng(path, ldr.data(), w, h) ? 0 : -1;
 }
 
+// the loader's LDR decoders on their own (tests/test_ref_kat6.py): RGBA8, top row first.  Returns 0, or -1 with the reason in err.
+int tgh_decode_ldr(const char *path, int *w, int *h, uint8_t *rgba, uint64_t capacity, char *err, int errLen)
+{
+    std::vector<uint8_t> px;
+    std::string why, p(path);
+    auto ends = [&](const char *suffix) { const size_t n = std::strlen(suffix); return p.size() >= n && p.compare(p.size() - n, n, suffix) == 0; };
+    bool ok;
+    if (ends(".png")) { ok = loadPng(p, *w, *h, px); why = "is not a PNG this loader reads"; }
+    else if (ends(".bmp")) ok = loadBmp(p, *w, *h, px, why);
+    else if (ends(".tga")) ok = loadTga(p, *w, *h, px, why);
+    else ok = loadJpeg(p, *w, *h, px, why);
+    if (!ok || px.size() > capacity) {
+        std::snprintf(err, size_t(errLen), "%s", ok ? "buffer too small" : why.c_str());
+        return -1;
+    }
+    std::memcpy(rgba, px.data(), px.size());
+    return 0;
+}
+
 } // extern "C"

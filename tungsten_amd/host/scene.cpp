@@ -572,6 +572,573 @@ bool loadTga(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba
     return true;
 }
 
+// ---- .jpg: baseline (sequential, Huffman, 8-bit) JPEG, decoded to the bytes the reference gets from stb_image --------------------------------------
+// The reference build has no libjpeg, so ImageIO hands .jpg files to stb_image too (io/ImageIO.cpp:340-377,489-490).  A JPEG's pixels depend on the
+// decoder's arithmetic, so this one keeps stb_image's (thirdparty/stbi/stb_image.c; its SSE2 kernels are documented bit-identical to the scalar forms
+// restated here): the integer IDCT derived from jidctint with 12-bit constants and two extra bits between the passes (:1404-1502), chroma upsampling by
+// the 3:1 "JFIF-centred" filters across block boundaries (:2343-2415) driven by the line0 / line1 stepping of load_jpeg_image (:2823-2850), and the
+// reduced-precision YCbCr -> RGB (:2577-2601).  Entropy decoding is the JPEG specification's (canonical Huffman codes, receive-and-extend, restart
+// intervals; for progressive files the spectral-selection / successive-approximation scans of annex G with stb's coefficient handling, :1247-1393,
+// dequantised and transformed once at the end); a marker inside the entropy-coded data ends the bit supply with zero bits, as in stb.
+namespace {
+class JpegDecoder {
+public:
+    explicit JpegDecoder(const std::string &bytes) : _d(bytes) {}
+
+    bool decode(int &w, int &h, std::vector<uint8_t> &rgba, std::string &why)
+    {
+        try {
+            parse();
+            assemble(rgba);
+            w = _width;
+            h = _height;
+            return true;
+        } catch (const char *msg) {
+            why = msg;
+            return false;
+        }
+    }
+
+private:
+    struct Huffman {
+        uint8_t size[257] = {};
+        uint16_t code[256] = {};
+        uint8_t value[256] = {};
+        int count = 0;
+        bool defined = false;
+    };
+    struct Component {
+        int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0;
+        uint32_t dcPred = 0; // two's complement, modulo 2^32: a damaged file can drive the predictor anywhere, and only its low 16 bits are kept
+        int x = 0, y = 0, w2 = 0, h2 = 0;
+        std::vector<uint8_t> data;
+        std::vector<short> coeff; // progressive files: the coefficients of every block (w2/8 x h2/8 blocks), refined scan by scan
+    };
+
+    uint32_t byte() { if (_pos >= _d.size()) throw "is truncated"; return uint8_t(_d[_pos++]); }
+    uint32_t be16() { uint32_t a = byte(); return (a << 8) | byte(); }
+    uint32_t nextMarker()
+    {
+        if (_pendingMarker != 0xFF) { uint32_t m = _pendingMarker; _pendingMarker = 0xFF; return m; }
+        uint32_t x = byte();
+        if (x != 0xFF) return 0xFF; // "no marker"
+        while (x == 0xFF) x = byte();
+        return x;
+    }
+
+    // ---- entropy-coded segment: bits, MSB first; a marker stops the supply (zeros from then on) ----
+    void resetScan()
+    {
+        _bitBuffer = 0; _bitCount = 0; _noMore = false;
+        for (Component &c : _comp) c.dcPred = 0;
+        _pendingMarker = 0xFF;
+        _todo = _restartInterval ? _restartInterval : 0x7fffffff;
+        _eobRun = 0;
+    }
+    void fill()
+    {
+        do {
+            uint32_t b = 0;
+            if (!_noMore) {
+                b = _pos < _d.size() ? uint8_t(_d[_pos++]) : 0;
+                if (b == 0xFF) {
+                    const uint32_t c = _pos < _d.size() ? uint8_t(_d[_pos++]) : 0;
+                    if (c != 0) { _pendingMarker = c; _noMore = true; return; }
+                }
+            }
+            _bitBuffer |= b << (24 - _bitCount);
+            _bitCount += 8;
+        } while (_bitCount <= 24);
+    }
+    int bits(int n)
+    {
+        if (n == 0) return 0;
+        if (_bitCount < n) fill();
+        const uint32_t v = _bitBuffer >> (32 - n);
+        _bitBuffer <<= n;
+        _bitCount -= n;
+        return int(v);
+    }
+    int symbol(const Huffman &h)
+    {
+        if (!h.defined) throw "uses an undefined Huffman table";
+        if (_bitCount < 16) fill();
+        uint32_t code = 0;
+        int k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            code = (code << 1) | (_bitBuffer >> 31);
+            _bitBuffer <<= 1;
+            --_bitCount;
+            while (k < h.count && h.size[k] == len) {
+                if (h.code[k] == code) return h.value[k];
+                ++k;
+            }
+        }
+        throw "has a corrupt Huffman code";
+    }
+    int receiveExtend(int n) // F.2.2.1: the n-bit value, negative range when its first bit is clear
+    {
+        if (n == 0) return 0;
+        const int v = bits(n);
+        return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v;
+    }
+
+    void decodeBlock(Component &c, short *block)
+    {
+        static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        const uint8_t *q = _quant[c.tq];
+        std::memset(block, 0, 64*sizeof(short));
+        const int t = symbol(_dc[c.hd]);
+        if (t > 15) throw "has a corrupt DC code";
+        c.dcPred += uint32_t(receiveExtend(t));
+        block[0] = short(c.dcPred*uint32_t(q[0]));
+        for (int k = 1; k < 64;) {
+            const int rs = symbol(_ac[c.ha]), run = rs >> 4, size = rs & 15;
+            if (size == 0) {
+                if (rs != 0xF0) break; // end of block
+                k += 16;
+            } else {
+                k += run;
+                if (k > 63) throw "has a corrupt coefficient run";
+                const int pos = zigzag[k++];
+                block[pos] = short(receiveExtend(size)*q[pos]); // the table is stored by position, not in zigzag order
+            }
+        }
+    }
+
+    // progressive scans (annex G): a DC scan sets or refines block[0], an AC scan a band [specStart, specEnd] of one component
+    void progressiveDc(Component &c, short *block)
+    {
+        if (_specEnd != 0) throw "mixes DC and AC coefficients in a progressive scan";
+        if (_succHigh == 0) {
+            std::memset(block, 0, 64*sizeof(short));
+            const int t = symbol(_dc[c.hd]);
+            if (t > 15) throw "has a corrupt DC code";
+            c.dcPred += uint32_t(receiveExtend(t));
+            block[0] = short(c.dcPred << _succLow);
+        } else if (bits(1)) {
+            block[0] += short(1 << _succLow);
+        }
+    }
+    void refineBit(short &coefficient, short bit) // one correction bit for a coefficient that is already non-zero
+    {
+        if (bits(1) && (coefficient & bit) == 0) coefficient = short(coefficient > 0 ? coefficient + bit : coefficient - bit);
+    }
+    void progressiveAc(Component &c, short *block)
+    {
+        static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        if (_specStart == 0) throw "mixes DC and AC coefficients in a progressive scan";
+        const Huffman &h = _ac[c.ha];
+        if (_succHigh == 0) { // first pass over the band
+            if (_eobRun) { --_eobRun; return; }
+            int k = _specStart;
+            do {
+                const int rs = symbol(h), run = rs >> 4, size = rs & 15;
+                if (size == 0) {
+                    if (run < 15) { _eobRun = (1 << run) + (run ? bits(run) : 0) - 1; break; }
+                    k += 16;
+                } else {
+                    k += run;
+                    if (k > 63) throw "has a corrupt coefficient run";
+                    block[zigzag[k++]] = short(receiveExtend(size)*(1 << _succLow));
+                }
+            } while (k <= _specEnd);
+            return;
+        }
+        const short bit = short(1 << _succLow); // refinement pass
+        if (_eobRun) {
+            --_eobRun;
+            for (int k = _specStart; k <= _specEnd; ++k) {
+                short &p = block[zigzag[k]];
+                if (p != 0) refineBit(p, bit);
+            }
+            return;
+        }
+        int k = _specStart;
+        do {
+            const int rs = symbol(h);
+            int run = rs >> 4, value = rs & 15;
+            if (value == 0) {
+                if (run < 15) { _eobRun = (1 << run) - 1 + (run ? bits(run) : 0); run = 64; } // the rest of the band: corrections only
+            } else {
+                if (value != 1) throw "has a corrupt refinement code";
+                value = bits(1) ? bit : -bit;
+            }
+            while (k <= _specEnd) { // skip `run` zero coefficients, correcting the non-zero ones on the way; then place the new one
+                short &p = block[zigzag[k++]];
+                if (p != 0) refineBit(p, bit);
+                else if (run == 0) { p = short(value); break; }
+                else --run;
+            }
+        } while (k <= _specEnd);
+    }
+    void finishProgressive() // every block: dequantise (16-bit product, as stb's in-place multiply), then the transform
+    {
+        for (Component &c : _comp) {
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3, coeffW = c.w2/8;
+            for (int j = 0; j < bh; ++j)
+                for (int i = 0; i < bw; ++i) {
+                    short *block = &c.coeff[(size_t(j)*coeffW + i)*64];
+                    for (int k = 0; k < 64; ++k) block[k] = short(block[k]*_quant[c.tq][k]);
+                    idct(&c.data[size_t(c.w2)*j*8 + size_t(i)*8], c.w2, block);
+                }
+        }
+    }
+
+    // stb_image's stbi__idct_block: columns, then rows; 1 << 12 constants, two guard bits between the passes, +128 level shift folded into the rounding
+    static int f2f(double x) { return int(x*4096 + 0.5); }
+    struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
+    static Idct1D idct1D(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+    {
+        Idct1D r;
+        int p1, p2, p3, p4, p5, t0, t1, t2, t3;
+        p2 = s2; p3 = s6;
+        p1 = (p2 + p3)*f2f(0.5411961f);
+        t2 = p1 + p3*f2f(-1.847759065f);
+        t3 = p1 + p2*f2f(0.765366865f);
+        p2 = s0; p3 = s4;
+        t0 = (p2 + p3)*4096;
+        t1 = (p2 - p3)*4096;
+        r.x0 = t0 + t3; r.x3 = t0 - t3; r.x1 = t1 + t2; r.x2 = t1 - t2;
+        t0 = s7; t1 = s5; t2 = s3; t3 = s1;
+        p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+        p5 = (p3 + p4)*f2f(1.175875602f);
+        t0 = t0*f2f(0.298631336f);
+        t1 = t1*f2f(2.053119869f);
+        t2 = t2*f2f(3.072711026f);
+        t3 = t3*f2f(1.501321110f);
+        p1 = p5 + p1*f2f(-0.899976223f);
+        p2 = p5 + p2*f2f(-2.562915447f);
+        p3 = p3*f2f(-1.961570560f);
+        p4 = p4*f2f(-0.390180644f);
+        r.t3 = t3 + p1 + p4; r.t2 = t2 + p2 + p3; r.t1 = t1 + p2 + p4; r.t0 = t0 + p1 + p3;
+        return r;
+    }
+    static uint8_t clampByte(int x) { return uint8_t(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+    static void idct(uint8_t *out, int stride, const short *d)
+    {
+        int val[64];
+        for (int i = 0; i < 8; ++i) {
+            int *v = val + i;
+            const short *c = d + i;
+            if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
+                const int dc = c[0]*4;
+                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+            } else {
+                Idct1D r = idct1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
+                r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
+                v[0] = (r.x0 + r.t3) >> 10; v[56] = (r.x0 - r.t3) >> 10;
+                v[8] = (r.x1 + r.t2) >> 10; v[48] = (r.x1 - r.t2) >> 10;
+                v[16] = (r.x2 + r.t1) >> 10; v[40] = (r.x2 - r.t1) >> 10;
+                v[24] = (r.x3 + r.t0) >> 10; v[32] = (r.x3 - r.t0) >> 10;
+            }
+        }
+        for (int i = 0; i < 8; ++i) {
+            const int *v = val + i*8;
+            uint8_t *o = out + size_t(i)*stride;
+            Idct1D r = idct1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            const int bias = 65536 + (128 << 17);
+            r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
+            o[0] = clampByte((r.x0 + r.t3) >> 17); o[7] = clampByte((r.x0 - r.t3) >> 17);
+            o[1] = clampByte((r.x1 + r.t2) >> 17); o[6] = clampByte((r.x1 - r.t2) >> 17);
+            o[2] = clampByte((r.x2 + r.t1) >> 17); o[5] = clampByte((r.x2 - r.t1) >> 17);
+            o[3] = clampByte((r.x3 + r.t0) >> 17); o[4] = clampByte((r.x3 - r.t0) >> 17);
+        }
+    }
+
+    // ---- segments ----
+    void parse()
+    {
+        if (nextMarker() != 0xD8) throw "is not a JPEG file";
+        bool haveFrame = false;
+        for (;;) {
+            uint32_t m = nextMarker();
+            while (m == 0xFF) { if (_pos >= _d.size()) throw "ends before its image data"; m = nextMarker(); }
+            if (m == 0xD9) break;                                        // EOI
+            if (m == 0xC0 || m == 0xC1 || m == 0xC2) { _progressive = m == 0xC2; frameHeader(); haveFrame = true; continue; }
+            if (m == 0xDA) {                                             // SOS
+                if (!haveFrame) throw "has a scan before its frame header";
+                scan();
+                if (_pendingMarker == 0xFF) {                            // padding up to the next marker
+                    while (_pos < _d.size()) {
+                        const uint32_t x = byte();
+                        if (x == 0xFF) { _pendingMarker = _pos < _d.size() ? byte() : 0xD9; break; }
+                        if (x != 0) throw "has junk before a marker";
+                    }
+                    if (_pendingMarker == 0xFF) break;                   // the file ends without EOI: what was decoded stands
+                }
+                continue;
+            }
+            if (m == 0xDD) { if (be16() != 4) throw "has a corrupt DRI segment"; _restartInterval = int(be16()); continue; }
+            if (m == 0xDB) { quantTables(); continue; }
+            if (m == 0xC4) { huffmanTables(); continue; }
+            if ((m >= 0xE0 && m <= 0xEF) || m == 0xFE) { const uint32_t n = be16(); if (n < 2 || n - 2 > _d.size() - _pos) throw "is truncated"; _pos += n - 2; continue; }
+            throw "uses a JPEG feature outside the baseline process";
+        }
+        if (!haveFrame) throw "has no frame header";
+        if (_progressive) finishProgressive();
+    }
+    void quantTables()
+    {
+        static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        int left = int(be16()) - 2;
+        while (left > 0) {
+            const uint32_t q = byte();
+            if (q >> 4) throw "has 16-bit quantisation tables";
+            if ((q & 15) > 3) throw "has a corrupt DQT segment";
+            for (int i = 0; i < 64; ++i) _quant[q & 15][zigzag[i]] = uint8_t(byte());
+            left -= 65;
+        }
+        if (left != 0) throw "has a corrupt DQT segment";
+    }
+    void huffmanTables()
+    {
+        int left = int(be16()) - 2;
+        while (left > 0) {
+            const uint32_t q = byte();
+            const int tc = int(q >> 4), th = int(q & 15);
+            if (tc > 1 || th > 3) throw "has a corrupt DHT segment";
+            int counts[16], n = 0;
+            for (int i = 0; i < 16; ++i) { counts[i] = int(byte()); n += counts[i]; }
+            if (n > 256) throw "has a corrupt DHT segment";
+            Huffman &h = tc ? _ac[th] : _dc[th];
+            h = Huffman();
+            int k = 0;
+            for (int i = 0; i < 16; ++i) for (int j = 0; j < counts[i]; ++j) h.size[k++] = uint8_t(i + 1);
+            uint32_t code = 0;
+            k = 0;
+            for (int len = 1; len <= 16; ++len) {          // canonical codes, annex C
+                while (k < n && h.size[k] == len) h.code[k++] = uint16_t(code++);
+                if (code > (1u << len)) throw "has corrupt Huffman code lengths";
+                code <<= 1;
+            }
+            for (int i = 0; i < n; ++i) h.value[i] = uint8_t(byte());
+            h.count = n;
+            h.defined = true;
+            left -= 17 + n;
+        }
+        if (left != 0) throw "has a corrupt DHT segment";
+    }
+    void frameHeader()
+    {
+        const uint32_t len = be16();
+        if (len < 11) throw "has a corrupt frame header";
+        if (byte() != 8) throw "is not an 8-bit JPEG";
+        _height = int(be16());
+        _width = int(be16());
+        if (_height == 0 || _width == 0) throw "has no pixels";
+        const int n = int(byte());
+        if (n != 1 && n != 3) throw "has neither one nor three components";
+        if (len != uint32_t(8 + 3*n)) throw "has a corrupt frame header";
+        if ((1 << 30)/_width/n < _height) throw "is too large";
+        _comp.assign(size_t(n), Component());
+        _rgbIds = 0;
+        for (int i = 0; i < n; ++i) {
+            Component &c = _comp[size_t(i)];
+            c.id = int(byte());
+            if (c.id != i + 1 && c.id != i) {
+                if (c.id != "RGB"[i]) throw "has unusual component identifiers";
+                ++_rgbIds;
+            }
+            const uint32_t q = byte();
+            c.h = int(q >> 4); c.v = int(q & 15);
+            if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4) throw "has corrupt sampling factors";
+            c.tq = int(byte());
+            if (c.tq > 3) throw "has a corrupt frame header";
+        }
+        _hMax = _vMax = 1;
+        for (const Component &c : _comp) { _hMax = std::max(_hMax, c.h); _vMax = std::max(_vMax, c.v); }
+        _mcuX = (_width + _hMax*8 - 1)/(_hMax*8);
+        _mcuY = (_height + _vMax*8 - 1)/(_vMax*8);
+        for (Component &c : _comp) {
+            c.x = (_width*c.h + _hMax - 1)/_hMax;
+            c.y = (_height*c.v + _vMax - 1)/_vMax;
+            c.w2 = _mcuX*c.h*8;
+            c.h2 = _mcuY*c.v*8;
+            c.data.assign(size_t(c.w2)*c.h2, 0);
+            if (_progressive) c.coeff.assign(size_t(c.w2/8)*(c.h2/8)*64, 0);
+        }
+    }
+    void scan()
+    {
+        const uint32_t len = be16();
+        const int n = int(byte());
+        if (n < 1 || n > int(_comp.size())) throw "has a corrupt scan header";
+        if (len != uint32_t(6 + 2*n)) throw "has a corrupt scan header";
+        int order[4];
+        for (int i = 0; i < n; ++i) {
+            const int id = int(byte());
+            const uint32_t q = byte();
+            int which = 0;
+            while (which < int(_comp.size()) && _comp[size_t(which)].id != id) ++which;
+            if (which == int(_comp.size())) throw "names an unknown component in a scan";
+            _comp[size_t(which)].hd = int(q >> 4);
+            _comp[size_t(which)].ha = int(q & 15);
+            if (_comp[size_t(which)].hd > 3 || _comp[size_t(which)].ha > 3) throw "has a corrupt scan header";
+            order[i] = which;
+        }
+        _specStart = int(byte());
+        _specEnd = int(byte());
+        const uint32_t approx = byte();
+        _succHigh = int(approx >> 4);
+        _succLow = int(approx & 15);
+        if (_progressive) {
+            if (_specStart > 63 || _specEnd > 63 || _specStart > _specEnd || _succHigh > 13 || _succLow > 13) throw "has a corrupt scan header";
+        } else if (_specStart != 0 || approx != 0) throw "has a corrupt scan header";
+        resetScan();
+        short block[64];
+        auto restartDue = [&]() { // true: the scan goes on; false: it ends here (no restart marker where one is due)
+            if (--_todo > 0) return true;
+            if (_bitCount < 24) fill();
+            if (!(_pendingMarker >= 0xD0 && _pendingMarker <= 0xD7)) return false;
+            resetScan();
+            return true;
+        };
+        if (n == 1) { // one component: its blocks in raster order, without MCU padding
+            Component &c = _comp[size_t(order[0])];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; ++j)
+                for (int i = 0; i < bw; ++i) {
+                    if (_progressive) {
+                        short *stored = &c.coeff[(size_t(j)*(c.w2/8) + i)*64];
+                        if (_specStart == 0) progressiveDc(c, stored); else progressiveAc(c, stored);
+                    } else {
+                        decodeBlock(c, block);
+                        idct(&c.data[size_t(c.w2)*j*8 + size_t(i)*8], c.w2, block);
+                    }
+                    if (!restartDue()) return;
+                }
+            return;
+        }
+        for (int j = 0; j < _mcuY; ++j)
+            for (int i = 0; i < _mcuX; ++i) {
+                for (int k = 0; k < n; ++k) {
+                    Component &c = _comp[size_t(order[k])];
+                    for (int y = 0; y < c.v; ++y)
+                        for (int x = 0; x < c.h; ++x) {
+                            if (_progressive) { // interleaved progressive scans carry DC coefficients only
+                                progressiveDc(c, &c.coeff[(size_t(j*c.v + y)*(c.w2/8) + size_t(i*c.h + x))*64]);
+                            } else {
+                                decodeBlock(c, block);
+                                idct(&c.data[size_t(c.w2)*((j*c.v + y)*8) + size_t(i*c.h + x)*8], c.w2, block);
+                            }
+                        }
+                }
+                if (!restartDue()) return;
+            }
+    }
+
+    // ---- planes -> RGBA: load_jpeg_image's row loop ----
+    void assemble(std::vector<uint8_t> &rgba)
+    {
+        const size_t n = _comp.size();
+        struct Resampler { int hs, vs, wLores, ystep, ypos; const uint8_t *line0, *line1; std::vector<uint8_t> buf; };
+        std::vector<Resampler> rs(n);
+        for (size_t k = 0; k < n; ++k) {
+            Resampler &r = rs[k];
+            r.hs = _hMax/_comp[k].h;
+            r.vs = _vMax/_comp[k].v;
+            r.ystep = r.vs >> 1;
+            r.wLores = (_width + r.hs - 1)/r.hs;
+            r.ypos = 0;
+            r.line0 = r.line1 = _comp[k].data.data();
+            r.buf.assign(size_t(r.wLores)*r.hs + 8, 0);
+        }
+        rgba.assign(size_t(_width)*_height*4, 255);
+        std::vector<const uint8_t *> row(n);
+        for (int j = 0; j < _height; ++j) {
+            for (size_t k = 0; k < n; ++k) {
+                Resampler &r = rs[k];
+                const bool bottom = r.ystep >= (r.vs >> 1);
+                const uint8_t *nearRow = bottom ? r.line1 : r.line0, *farRow = bottom ? r.line0 : r.line1;
+                row[k] = resample(r.buf.data(), nearRow, farRow, r.wLores, r.hs, r.vs);
+                if (++r.ystep >= r.vs) {
+                    r.ystep = 0;
+                    r.line0 = r.line1;
+                    if (++r.ypos < _comp[k].y) r.line1 += _comp[k].w2;
+                }
+            }
+            uint8_t *out = &rgba[size_t(j)*_width*4];
+            if (n == 1) {
+                for (int i = 0; i < _width; ++i) out[i*4] = out[i*4 + 1] = out[i*4 + 2] = row[0][i];
+            } else if (_rgbIds == 3) {
+                for (int i = 0; i < _width; ++i) { out[i*4] = row[0][i]; out[i*4 + 1] = row[1][i]; out[i*4 + 2] = row[2][i]; }
+            } else {
+                // stbi__YCbCr_to_RGB_row: 20 fractional bits, constants rounded to 12 and shifted up, the Cb term of green truncated to 16 bits
+                const int crR = int(1.40200f*4096.0f + 0.5f) << 8, crG = -(int(0.71414f*4096.0f + 0.5f) << 8), cbG = -(int(0.34414f*4096.0f + 0.5f) << 8),
+                          cbB = int(1.77200f*4096.0f + 0.5f) << 8;
+                for (int i = 0; i < _width; ++i) {
+                    const int yFixed = (int(row[0][i]) << 20) + (1 << 19), cr = int(row[2][i]) - 128, cb = int(row[1][i]) - 128;
+                    int r = yFixed + cr*crR;
+                    int g = yFixed + cr*crG + int(uint32_t(cb*cbG) & 0xffff0000u);
+                    int b = yFixed + cb*cbB;
+                    r >>= 20; g >>= 20; b >>= 20;
+                    out[i*4] = clampByte(r); out[i*4 + 1] = clampByte(g); out[i*4 + 2] = clampByte(b);
+                }
+            }
+        }
+    }
+    static const uint8_t *resample(uint8_t *out, const uint8_t *nearRow, const uint8_t *farRow, int w, int hs, int vs)
+    {
+        if (hs == 1 && vs == 1) return nearRow;
+        if (hs == 1 && vs == 2) { // two rows for one: 3:1 towards the nearer source row
+            for (int i = 0; i < w; ++i) out[i] = uint8_t((3*nearRow[i] + farRow[i] + 2) >> 2);
+            return out;
+        }
+        if (hs == 2 && vs == 1) { // two samples for one, ends replicated
+            if (w == 1) { out[0] = out[1] = nearRow[0]; return out; }
+            out[0] = nearRow[0];
+            out[1] = uint8_t((nearRow[0]*3 + nearRow[1] + 2) >> 2);
+            int i = 1;
+            for (; i < w - 1; ++i) {
+                const int n3 = 3*nearRow[i] + 2;
+                out[i*2] = uint8_t((n3 + nearRow[i - 1]) >> 2);
+                out[i*2 + 1] = uint8_t((n3 + nearRow[i + 1]) >> 2);
+            }
+            out[i*2] = uint8_t((nearRow[w - 2]*3 + nearRow[w - 1] + 2) >> 2);
+            out[i*2 + 1] = nearRow[w - 1];
+            return out;
+        }
+        if (hs == 2 && vs == 2) { // 2x2 for one: the vertical 3:1 blend first, then the horizontal one on the sums
+            if (w == 1) { out[0] = out[1] = uint8_t((3*nearRow[0] + farRow[0] + 2) >> 2); return out; }
+            int t1 = 3*nearRow[0] + farRow[0];
+            out[0] = uint8_t((t1 + 2) >> 2);
+            for (int i = 1; i < w; ++i) {
+                const int t0 = t1;
+                t1 = 3*nearRow[i] + farRow[i];
+                out[i*2 - 1] = uint8_t((3*t0 + t1 + 8) >> 4);
+                out[i*2] = uint8_t((3*t1 + t0 + 8) >> 4);
+            }
+            out[w*2 - 1] = uint8_t((t1 + 2) >> 2);
+            return out;
+        }
+        for (int i = 0; i < w; ++i) for (int j = 0; j < hs; ++j) out[i*hs + j] = nearRow[i]; // other ratios: nearest
+        return out;
+    }
+
+    const std::string &_d;
+    size_t _pos = 0;
+    uint32_t _pendingMarker = 0xFF, _bitBuffer = 0;
+    int _bitCount = 0, _todo = 0, _restartInterval = 0, _eobRun = 0, _specStart = 0, _specEnd = 63, _succHigh = 0, _succLow = 0;
+    bool _noMore = false, _progressive = false;
+    int _width = 0, _height = 0, _hMax = 1, _vMax = 1, _mcuX = 0, _mcuY = 0, _rgbIds = 0;
+    uint8_t _quant[4][64] = {};
+    Huffman _dc[4], _ac[4];
+    std::vector<Component> _comp;
+};
+}
+
+bool loadJpeg(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba, std::string &why)
+{
+    std::string data;
+    try { data = readFile(path); } catch (...) { why = "cannot be read"; return false; }
+    JpegDecoder decoder(data);
+    return decoder.decode(w, h, rgba, why);
+}
+
 bool loadPng(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba)
 {
     std::vector<uint8_t> file;
@@ -762,13 +1329,13 @@ int Scene::fetchBitmap(const std::string &path, bool scalarAverage, bool gammaCo
                 const float s = (texels[i*3] + texels[i*3 + 1] + texels[i*3 + 2])/3;
                 texels[i*3] = texels[i*3 + 1] = texels[i*3 + 2] = s;
             }
-    } else if (endsWith(full, ".png") || endsWith(full, ".bmp") || endsWith(full, ".tga")) {
+    } else if (endsWith(full, ".png") || endsWith(full, ".bmp") || endsWith(full, ".tga") || endsWith(full, ".jpg") || endsWith(full, ".jpeg")) {
         std::vector<uint8_t> rgba;
         std::string why;
         if (endsWith(full, ".png")) {
             if (!loadPng(full, w, h, rgba))
                 throw std::runtime_error("Unable to load texture at '" + full + "' (8-bit non-interlaced PNG expected)");
-        } else if (!(endsWith(full, ".bmp") ? loadBmp(full, w, h, rgba, why) : loadTga(full, w, h, rgba, why))) {
+        } else if (!(endsWith(full, ".bmp") ? loadBmp(full, w, h, rgba, why) : endsWith(full, ".tga") ? loadTga(full, w, h, rgba, why) : loadJpeg(full, w, h, rgba, why))) {
             throw std::runtime_error("Unable to load texture at '" + full + "': the file " + why);
         }
         uint8_t gamma[256];
@@ -783,7 +1350,7 @@ int Scene::fetchBitmap(const std::string &path, bool scalarAverage, bool gammaCo
             }
         }
     } else {
-        throw std::runtime_error("Unable to load texture at '" + full + "' (.hdr, .pfm, .png, .bmp and .tga bitmaps are in scope; JPEG is not)");
+        throw std::runtime_error("Unable to load texture at '" + full + "' (.hdr, .pfm, .png, .bmp, .tga and baseline .jpg bitmaps are in scope)");
     }
     tgpu_bitmap bm{};
     bm.w = w; bm.h = h; bm.clamp = clamp ? 1 : 0; bm.linear = linear ? 1 : 0; bm.scale = scale; bm.texels = nullptr;

@@ -192,6 +192,9 @@ bool loadPfm(const std::string &path, int &w, int &h, std::vector<float> &rgb);
 bool savePng(const std::string &path, const uint8_t *rgb, int w, int h);
 // 8-bit, non-interlaced PNG -> RGBA8 (what lodepng_decode_memory(..., LCT_RGBA, 8) returns for such files, io/ImageIO.cpp:386-407)
 bool loadPng(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba);
+bool loadBmp(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba, std::string &why);
+bool loadTga(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba, std::string &why);
+bool loadJpeg(const std::string &path, int &w, int &h, std::vector<uint8_t> &rgba, std::string &why);
 // Camera::tonemap + LDR quantisation (Tonemap.hpp:25-48, Integrator.cpp:56-80)
 void tonemapToLdr(const std::string &op, const float *rgb, int w, int h, std::vector<uint8_t> &ldr);
 

@@ -3747,9 +3747,13 @@ __global__ void __launch_bounds__(256) k_occluded_raw(DScene sc, DState st, uint
 // ..., using exactly the per-path functions of the wavefront kernels (so the bits do not change), then
 // retires it.  Every slot of the lists ends on the free list.
 // =================================================================================================
-template <bool COUNT, bool INST, bool FWD>
+// LEAN: the scene runs the lean shade kernels (no media, no sphere / disk, no forward-scattering surface, no auxiliary buffers: tgpu_upload_scene's
+// generalShading is false) -- the tail then carries the lean shading code only.  The general kernel is 1.9 MB of code of which a lean scene's paths
+// visit a scattered tenth; at one wave per SIMD every instruction-cache miss is exposed (1.6 M misses per launch, profiles/r03_ab_notes.txt).
+template <bool COUNT, bool INST, bool FWD, bool LEAN = false>
 __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uint32_t spread)
 {
+    static_assert(!(LEAN && FWD), "scenes with forward-scattering surfaces shade with the general kernels");
     extern __shared__ uint32_t ldsStack[];
     uint32_t *stack = ldsStack + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -3780,14 +3784,14 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
                 if (INST) st.hitInst[slot] = inst;
                 st.hit[slot] = make_float4(tfar, u, v, __uint_as_float(prim));
                 extRays++;
-                if (sc.nMedia && (st.med[slot] & 0xFFu)) {
+                if (!LEAN && sc.nMedia && (st.med[slot] & 0xFFu)) {
                     volumePath(sc, st, slot);
                     events++;
                     if (stateNee(st.state[slot])) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
                 } else if (prim == PRIM_MISS) {
                     missPath(sc, st, slot);
                 } else {
-                    shadePath<-1, true>(sc, st, slot);
+                    shadePath<-1, !LEAN>(sc, st, slot);
                     events++;
                     if (stateNee(st.state[slot])) shadowPath<COUNT, INST, FWD>(sc, st, stack, slot, tcS, shRays);
                 }
@@ -3799,7 +3803,7 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
                 const bool nanEnd = end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum());
                 if (end == END_ZERO || nanEnd) c = V3(0.0f);
                 uint32_t ref = st.sampleRef[slot];
-                if (st.aov0) aovFinish(sc, st, slot, ref, end == END_CHECKED && !nanEnd);
+                if (!LEAN && st.aov0) aovFinish(sc, st, slot, ref, end == END_CHECKED && !nanEnd);
                 st.results[ref] = mk4(c, 0.0f);
                 ring = ref/st.resultSlice;
                 st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
@@ -4031,5 +4035,6 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shadow<true, true, false>(DScene, DState, int); \
     PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
 #define TG_KERNELS_TAIL(PFX, C, I, F) PFX template __global__ void k_tail<C, I, F>(DScene, DState, int, uint32_t);
+#define TG_KERNELS_TAIL_LEAN(PFX, C, I) PFX template __global__ void k_tail<C, I, false, true>(DScene, DState, int, uint32_t);
 
 } // namespace tg

@@ -38,6 +38,10 @@ TG_KERNELS_TAIL(extern, true, false, false)
 TG_KERNELS_TAIL(extern, true, false, true)
 TG_KERNELS_TAIL(extern, true, true, false)
 TG_KERNELS_TAIL(extern, true, true, true)
+TG_KERNELS_TAIL_LEAN(extern, false, false)
+TG_KERNELS_TAIL_LEAN(extern, false, true)
+TG_KERNELS_TAIL_LEAN(extern, true, false)
+TG_KERNELS_TAIL_LEAN(extern, true, true)
 }
 
 namespace {
@@ -77,6 +81,7 @@ struct tgpu_ctx {
     uint32_t classMask = 0;               // BSDF classes (shade kernels) the uploaded scene can hit
     bool generalGeometry = false;         // instances, spheres or disks: INST instantiation of the traversal kernels
     bool generalShading = false;          // media, spheres or disks (also as lights): general instantiation of the shade kernels
+    bool leanTail = true;                 // scenes with lean shading finish in the lean tail kernel (TGPU_TAIL_LEAN=0: the general one, A/B)
     bool trackRecords = false;            // settings.adaptive_sampling
     uint32_t varW = 0, varH = 0;
     std::vector<uint32_t> vtGlobal;       // local variance tile -> whole-image variance tile
@@ -658,6 +663,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     if (const char *e = getenv("TGPU_EXTEND_P")) ctx->extendPersistent = atoi(e) != 0;
     ctx->instExtendQueue = getenv("TGPU_INST_EXTEND_Q") && atoi(getenv("TGPU_INST_EXTEND_Q")) != 0;
     if (const char *e = getenv("TGPU_SHADOW_Q")) ctx->shadowQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
+    if (const char *e = getenv("TGPU_TAIL_LEAN")) ctx->leanTail = atoi(e) != 0;
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
     ctx->traceSlots = getenv("TGPU_TRACE_SLOTS") != nullptr;
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
@@ -1108,9 +1114,15 @@ static int driveIteration(tgpu_ctx *ctx)
         while (spread > 1 && uint64_t(nCur)*spread > uint64_t(ctx->maxGrid)*256) spread /= 2;
         int grid = gridFor(ctx, uint64_t(nCur)*spread);
         // variants: COUNT (visit counters), INST ("instances" in the scene), FWD (forward-scattering surfaces: shadow walk)
-        const int variant = (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
+        // ... and LEAN: the scene shades with the lean kernels (never together with FWD: forward-scattering surfaces select the general ones)
+        const int variant = (ctx->generalShading || !ctx->leanTail ? 0 : 8) | (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
 #define TG_LAUNCH_TAIL(C, I, F) hipLaunchKernelGGL((k_tail<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, spread)
+#define TG_LAUNCH_TAIL_LEAN(C, I) hipLaunchKernelGGL((k_tail<C, I, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, spread)
         switch (variant) {
+        case 8: TG_LAUNCH_TAIL_LEAN(false, false); break;
+        case 10: TG_LAUNCH_TAIL_LEAN(false, true); break;
+        case 12: TG_LAUNCH_TAIL_LEAN(true, false); break;
+        case 14: TG_LAUNCH_TAIL_LEAN(true, true); break;
         case 0: TG_LAUNCH_TAIL(false, false, false); break;
         case 1: TG_LAUNCH_TAIL(false, false, true); break;
         case 2: TG_LAUNCH_TAIL(false, true, false); break;
@@ -1121,6 +1133,7 @@ static int driveIteration(tgpu_ctx *ctx)
         default: TG_LAUNCH_TAIL(true, true, true); break;
         }
 #undef TG_LAUNCH_TAIL
+#undef TG_LAUNCH_TAIL_LEAN
         // every listed slot ends on the free list: both list sets are empty afterwards
         (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0), 0, 2*TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
         ctx->stats.tail_launches++;

@@ -3837,6 +3837,159 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
 }
 
 // =================================================================================================
+// The tail kernel of scenes with plain geometry and lean shading (no instances / spheres / disks, no media, no forward-scattering surface, no
+// auxiliary buffers -- the benchmark's kind), four lanes per path: lane 0 walks the path, lanes 1 and 2 trace the two NEE rays of the path's
+// PREVIOUS vertex while lane 0 traces the continuation ray, all in one traversal loop.  In k_tail a bounce costs the path's lane three
+// traversals back to back (closest hit, shadow ray, shadow ray), and at the end of a render nothing hides that latency; here it costs the
+// longest of the three.  The arithmetic is the wavefront's: the helpers leave the visibility bits in shD.w as k_shadow_q does, and whoever
+// touches the path next (shadePath, missPathEx, the retire code below) folds the NEE terms in with resolveNeeTerms -- same values, same order.
+// =================================================================================================
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_tail_coop(DScene sc, DState st, int set)
+{
+    extern __shared__ uint32_t ldsStack[];
+    uint32_t *stack = ldsStack + threadIdx.x;
+    const int lane = threadIdx.x & 63, role = lane & 3, leader = lane & ~3;
+    const ListCounts lc = loadListCounts(st, set);
+    const uint32_t total = listTotal(lc, 0);
+    const uint32_t waveIndex = (blockIdx.x*blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x*blockDim.x) >> 6;
+    TraceCounters tc{0, 0};
+    uint32_t extRays = 0, shRays = 0, events = 0;
+    for (uint32_t base = waveIndex*16u; base < total; base += waves*16u) { // wave-uniform trip count: 16 paths per wave and pass
+        const uint32_t q = base + uint32_t(lane >> 2);
+        uint32_t slot = 0, ring = 0xFFFFFFFFu;
+        bool have = false;
+        if (role == 0 && q < total) have = listFetch(st, lc, set, 0, q, slot);
+        have = __shfl(int(have), leader) != 0;
+        slot = __shfl(slot, leader);
+        // alive: the path has a ray to trace; pending: its last vertex's NEE rays are still to be traced (group-uniform)
+        bool alive = have && flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE, pending = false;
+        while (__ballot(alive || pending)) {
+            TravState r;
+            r.node = 0; r.sp = 0; r.bestT = 0.0f; r.bestU = 0.0f; r.bestV = 0.0f; r.bestPrim = PRIM_MISS;
+            bool active = false, hasRay = false, blocked = false;
+            if (role == 0 && alive) { // closestHit's order: quads, cubes, triangles
+                const float4 ro = st.rayO[slot], rd = st.rayD[slot];
+                const V3 O = xyz(ro), D = xyz(rd);
+                float tfar = rd.w, u = 0.0f, v = 0.0f;
+                uint32_t prim = PRIM_MISS;
+                for (uint32_t i = 0; i < sc.nQuads; ++i) {
+                    QuadHit qh;
+                    if (quadIntersect(sc.quads[i], O, D, ro.w, tfar, qh)) {
+                        tfar = qh.t; u = qh.u; v = qh.v;
+                        prim = mkPrim(KIND_QUAD, i);
+                    }
+                }
+                for (uint32_t i = 0; i < sc.nCubes; ++i) {
+                    float t;
+                    bool back;
+                    if (cubeIntersect(sc.cubes[i], O, D, ro.w, tfar, t, back)) {
+                        tfar = t; u = 0.0f; v = 0.0f;
+                        prim = mkPrim(KIND_CUBE, i);
+                    }
+                }
+                travInit(r, sc.rootChild, O, D, ro.w, tfar, prim);
+                r.bestU = u; r.bestV = v;
+                active = sc.nTris != 0;
+            } else if ((role == 1 || role == 2) && pending) { // occluded()'s order: quads (not the end cap), cubes, triangles
+                const float4 rd = ldStream(role == 1 ? &st.shA[slot] : &st.shB[slot]), ro = ldStream(&st.shO[slot]);
+                const uint32_t endCap = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[slot]));
+                if (rd.w >= 0.0f) {
+                    hasRay = true;
+                    const V3 O = xyz(ro), D = xyz(rd);
+                    for (uint32_t i = 0; i < sc.nQuads; ++i) {
+                        QuadHit qh;
+                        if (mkPrim(KIND_QUAD, i) != endCap && quadIntersect(sc.quads[i], O, D, ro.w, rd.w, qh)) blocked = true;
+                    }
+                    for (uint32_t i = 0; i < sc.nCubes; ++i) {
+                        float t;
+                        bool back;
+                        if (cubeIntersect(sc.cubes[i], O, D, ro.w, rd.w, t, back)) blocked = true;
+                    }
+                    if (!blocked && sc.nTris) {
+                        travInit(r, sc.rootChild, O, D, ro.w, rd.w, PRIM_MISS);
+                        active = true;
+                    }
+                }
+            }
+            while (__ballot(active)) {
+                if (active) {
+                    const float4 *n = travItem(sc, r);
+                    const float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                    const int s = travApply<false, COUNT, true, true>(sc, stack, r, tc, q0, q1, q2, q3, role != 0);
+                    if (s != TRAV_MORE) {
+                        active = false;
+                        blocked = blocked || s == TRAV_ANYHIT;
+                    }
+                }
+            }
+            // the NEE rays' answers -> the visibility word of the vertex (k_shadow_q's `complete`)
+            const uint32_t clearBit = hasRay && !blocked ? 1u : 0u;
+            const uint32_t visA = __shfl(clearBit, leader + 1), visB = __shfl(clearBit, leader + 2);
+            const bool rayA = __shfl(int(hasRay), leader + 1) != 0, rayB = __shfl(int(hasRay), leader + 2) != 0;
+            if (hasRay) shRays++;
+            if (role == 0 && pending && (rayA || rayB)) reinterpret_cast<uint32_t *>(&st.shD[slot])[3] = visA | (visB << 1);
+            bool nextAlive = false, nextPending = false;
+            if (role == 0 && alive) {
+                st.hit[slot] = make_float4(r.bestT, r.bestU, r.bestV, __uint_as_float(r.bestPrim));
+                extRays++;
+                if (r.bestPrim == PRIM_MISS) {
+                    missPath(sc, st, slot);
+                } else {
+                    shadePath<-1, false>(sc, st, slot);
+                    events++;
+                }
+                nextAlive = flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE;
+                nextPending = stateNee(st.state[slot]);
+            }
+            alive = __shfl(int(nextAlive), leader) != 0;
+            pending = __shfl(int(nextPending), leader) != 0;
+        }
+        if (role == 0 && have) {
+            const float4 tpw = st.tp[slot];
+            const int end = flagsEnd(__float_as_uint(tpw.w));
+            if (end != END_DEAD) { // retire (k_retire_regenerate's rules); the last vertex's NEE terms come in here
+                V3 c = xyz(st.em[slot]);
+                if (stateNee(st.state[slot])) c = resolveNeeTerms<false>(st, slot, c);
+                const bool nanEnd = end == END_CHECKED && isnanf_(xyz(tpw).sum() + c.sum());
+                if (end == END_ZERO || nanEnd) c = V3(0.0f);
+                const uint32_t ref = st.sampleRef[slot];
+                st.results[ref] = mk4(c, 0.0f);
+                ring = ref/st.resultSlice;
+                st.tp[slot] = make_float4(tpw.x, tpw.y, tpw.z, __uint_as_float(packFlags(0, false, END_DEAD)));
+                st.state[slot] = packState(false, END_DEAD);
+            }
+        }
+        unsigned long long todo = __ballot(ring != 0xFFFFFFFFu);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const uint32_t rr = __shfl(ring, first);
+            const unsigned long long m = __ballot(ring == rr);
+            if (lane == first) atomicAdd(&st.counters[CNT(CNT_JOB_DONE0 + rr)], uint32_t(__builtin_popcountll(m)));
+            todo &= ~m;
+        }
+        queueAppend(role == 0 && have, st.freeQ, &st.counters[CNT(CNT_FREE)], slot);
+    }
+    if (COUNT) {
+        TraceCounters tcE = tc, tcS = tc;
+        if (role != 0) tcE.nodes = tcE.tris = 0;
+        if (role == 0) tcS.nodes = tcS.tris = 0;
+        flushCounters(st.stats, 0, tcE);
+        flushCounters(st.stats, 2, tcS);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        extRays += __shfl_down(extRays, off);
+        shRays += __shfl_down(shRays, off);
+        events += __shfl_down(events, off);
+    }
+    if (lane == 0) {
+        if (shRays) atomicAdd(&st.stats[4], (unsigned long long)shRays);
+        if (events) atomicAdd(&st.stats[5], (unsigned long long)events);
+        if (extRays) atomicAdd(&st.stats[6], (unsigned long long)extRays);
+    }
+}
+
+// =================================================================================================
 // K7 accumulate: OutputBuffer::addSample in sample order (cameras/OutputBuffer.hpp:104-132)
 // =================================================================================================
 #ifdef TG_TU_MAIN
@@ -4036,5 +4189,6 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
 #define TG_KERNELS_TAIL(PFX, C, I, F) PFX template __global__ void k_tail<C, I, F>(DScene, DState, int, uint32_t);
 #define TG_KERNELS_TAIL_LEAN(PFX, C, I) PFX template __global__ void k_tail<C, I, false, true>(DScene, DState, int, uint32_t);
+#define TG_KERNELS_TAIL_COOP(PFX, C) PFX template __global__ void k_tail_coop<C>(DScene, DState, int);
 
 } // namespace tg

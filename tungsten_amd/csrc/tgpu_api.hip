@@ -42,6 +42,8 @@ TG_KERNELS_TAIL_LEAN(extern, false, false)
 TG_KERNELS_TAIL_LEAN(extern, false, true)
 TG_KERNELS_TAIL_LEAN(extern, true, false)
 TG_KERNELS_TAIL_LEAN(extern, true, true)
+TG_KERNELS_TAIL_COOP(extern, false)
+TG_KERNELS_TAIL_COOP(extern, true)
 }
 
 namespace {
@@ -81,6 +83,7 @@ struct tgpu_ctx {
     uint32_t classMask = 0;               // BSDF classes (shade kernels) the uploaded scene can hit
     bool generalGeometry = false;         // instances, spheres or disks: INST instantiation of the traversal kernels
     bool generalShading = false;          // media, spheres or disks (also as lights): general instantiation of the shade kernels
+    bool coopTail = true;                 // ... and, with plain geometry, in its four-lanes-per-path form (TGPU_TAIL_COOP=0: one lane per path, A/B)
     bool leanTail = true;                 // scenes with lean shading finish in the lean tail kernel (TGPU_TAIL_LEAN=0: the general one, A/B)
     bool trackRecords = false;            // settings.adaptive_sampling
     uint32_t varW = 0, varH = 0;
@@ -664,6 +667,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     ctx->instExtendQueue = getenv("TGPU_INST_EXTEND_Q") && atoi(getenv("TGPU_INST_EXTEND_Q")) != 0;
     if (const char *e = getenv("TGPU_SHADOW_Q")) ctx->shadowQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_TAIL_LEAN")) ctx->leanTail = atoi(e) != 0;
+    if (const char *e = getenv("TGPU_TAIL_COOP")) ctx->coopTail = atoi(e) != 0;
     if (const char *e = getenv("TGPU_TAIL_SPREAD")) { uint32_t v = uint32_t(atoi(e)); ctx->tailSpread = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); }
     ctx->traceSlots = getenv("TGPU_TRACE_SLOTS") != nullptr;
     if (const char *e = getenv("TGPU_TAIL_MAX")) ctx->tailMax = strtoull(e, nullptr, 10); // 0 disables the tail kernel (A/B)
@@ -1118,10 +1122,12 @@ static int driveIteration(tgpu_ctx *ctx)
         const int variant = (ctx->generalShading || !ctx->leanTail ? 0 : 8) | (count ? 4 : 0) | (ctx->generalGeometry ? 2 : 0) | (sc.hasForward ? 1 : 0);
 #define TG_LAUNCH_TAIL(C, I, F) hipLaunchKernelGGL((k_tail<C, I, F>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, spread)
 #define TG_LAUNCH_TAIL_LEAN(C, I) hipLaunchKernelGGL((k_tail<C, I, false, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur, spread)
+        // plain geometry on top of that: four lanes per path, the NEE rays traced beside the continuation ray (k_tail_coop)
+        if (ctx->coopTail && (variant == 8 || variant == 12)) grid = gridFor(ctx, uint64_t(nCur)*4);
         switch (variant) {
-        case 8: TG_LAUNCH_TAIL_LEAN(false, false); break;
+        case 8: if (ctx->coopTail) hipLaunchKernelGGL((k_tail_coop<false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur); else TG_LAUNCH_TAIL_LEAN(false, false); break;
         case 10: TG_LAUNCH_TAIL_LEAN(false, true); break;
-        case 12: TG_LAUNCH_TAIL_LEAN(true, false); break;
+        case 12: if (ctx->coopTail) hipLaunchKernelGGL((k_tail_coop<true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur); else TG_LAUNCH_TAIL_LEAN(true, false); break;
         case 14: TG_LAUNCH_TAIL_LEAN(true, true); break;
         case 0: TG_LAUNCH_TAIL(false, false, false); break;
         case 1: TG_LAUNCH_TAIL(false, false, true); break;

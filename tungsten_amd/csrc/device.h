@@ -1523,10 +1523,12 @@ TG_DEV bool nestedSample(const SC &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 // KNOWN: the BSDF type when the caller knows it at compile time (the per-class shade kernels), -1 otherwise.  The nested types never have a class
 // of their own, so a kernel that knows its type carries none of their code -- stated here rather than left to __builtin_assume on d.type, which
 // stops propagating at the first real call (the children of the nested BSDFs are calls, see above).
-template <int KNOWN = -1>
+// NESTED = false: the caller never brings a BSDF made of other BSDFs (types from TGPU_BSDF_MIXED on) -- their code, out-of-line calls into the
+// single-layer reflectors, stays out of the kernel (k_volume: a kernel with call sites pays for them whether they are taken or not).
+template <int KNOWN = -1, bool NESTED = true>
 TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
-    if (KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (NESTED && KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularEval(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
@@ -1555,10 +1557,10 @@ TG_DEV V3 bsdfEval(const DScene &sc, const tgpu_bsdf &d, const Event &e)
     return V3(0.0f);
 }
 
-template <int KNOWN = -1>
+template <int KNOWN = -1, bool NESTED = true>
 TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
 {
-    if (KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
+    if (NESTED && KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticPdf(sc, d, e.wi, e.wo, e.requestedLobe, e.uvx, e.uvy);
     if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularPdf(d, e.wi, e.wo, e.requestedLobe);
@@ -1591,10 +1593,10 @@ TG_DEV float bsdfPdf(const DScene &sc, const tgpu_bsdf &d, const Event &e)
     return 0.0f;
 }
 
-template <int KNOWN = -1>
+template <int KNOWN = -1, bool NESTED = true>
 TG_DEV bool bsdfSample(const DScene &sc, const tgpu_bsdf &d, Event &e, Sampler &s)
 {
-    if (KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedSample(sc, d, e, s);
+    if (NESTED && KNOWN < 0 && d.type >= TGPU_BSDF_MIXED) return nestedSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_ROUGH_DIELECTRIC) return dielectricSample(sc, d, e, s);
     if (d.type == TGPU_BSDF_PLASTIC || d.type == TGPU_BSDF_ROUGH_PLASTIC) return plasticSample(sc, d, e, s);
     if (d.type >= TGPU_BSDF_MIRROR && d.type <= TGPU_BSDF_CONDUCTOR) return specularSample(sc, d, e, s);

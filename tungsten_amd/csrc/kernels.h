@@ -53,7 +53,8 @@ struct JobRing {
     uint32_t n;
 };
 
-enum { END_ALIVE = 0, END_RAW = 1, END_ZERO = 2, END_CHECKED = 3, END_DEAD = 4 /* slot idle: no sample */ };
+enum { END_ALIVE = 0, END_RAW = 1, END_ZERO = 2, END_CHECKED = 3, END_DEAD = 4 /* slot idle: no sample */,
+       END_DEFERRED = 0x7F /* only in the end-state bytes between k_volume and k_volume_nested: the entry's surface step is still to run */ };
 // flags word (bits of tp.w): [15:0] bounce, [16] wasSpecular, [27:24] end state
 TG_DEV uint32_t packFlags(int bounce, bool wasSpecular, int end) { return uint32_t(bounce) | (wasSpecular ? 1u << 16 : 0u) | (uint32_t(end) << 24); }
 TG_DEV int flagsBounce(uint32_t f) { return int(f & 0xFFFFu); }
@@ -1326,6 +1327,15 @@ TG_DEV void flushCounters(unsigned long long *stats, int slot, const TraceCounte
     }
 }
 
+TG_DEV uint32_t hitBsdfType(const DScene &sc, uint32_t prim) // tgpu_bsdf::type of the primitive's BSDF
+{
+    uint32_t kind = primKind(prim), idx = primIndex(prim);
+    if (kind == KIND_TRI) return sc.triClass[idx];
+    if (kind == KIND_QUAD) return uint32_t(sc.bsdfs[sc.quads[idx].bsdf].type);
+    if (kind == KIND_SPHERE) return uint32_t(sc.bsdfs[sc.spheres[idx].bsdf].type);
+    if (kind == KIND_DISK) return uint32_t(sc.bsdfs[sc.disks[idx].bsdf].type);
+    return uint32_t(sc.bsdfs[sc.cubes[idx].bsdf].type);
+}
 TG_DEV uint32_t hitClass(const DScene &sc, uint32_t prim)
 {
     if (prim == PRIM_MISS) return 0xFFu;
@@ -2456,7 +2466,7 @@ TG_DEV V3 neeTransmittance(const DScene &sc, int medium, float farT, bool startO
     return transEval(sc, m, V3(m.sigma_t)*farT, startOnSurface, true);
 }
 
-template <int CLASS, bool MEDIA>
+template <int CLASS, bool MEDIA, bool NESTED = true>
 TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium = false); // returns the path's end state
 TG_DEV void missPath(const DScene &sc, const DState &st, uint32_t path);
 
@@ -2510,6 +2520,9 @@ TG_DEV void closeVertex(const DState &st, uint32_t path, bool nee, int end, floa
 // TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect (:323-381, :402-414, :470-481) and the loop
 // tail of traceSample (PathTracer.cpp:108-126).  The NEE rays go through the ordinary shadow kernel: their
 // transmittance is known here (the segment length is the light's distance) and folded into the contributions.
+// NESTED = false (k_volume): a path that leaves the medium onto a BSDF made of other BSDFs is left for k_volume_nested (END_DEFERRED); the surface
+// code compiled in here then has no out-of-line calls.
+template <bool NESTED = true>
 TG_DEV int volumePath(const DScene &sc, const DState &st, uint32_t path) // returns the path's end state
 {
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
@@ -2592,7 +2605,8 @@ TG_DEV int volumePath(const DScene &sc, const DState &st, uint32_t path) // retu
             float tpSumUnused;
             return missPathEx(sc, st, path, emUnused, tpSumUnused);
         }
-        return shadePath<-1, true>(sc, st, path, true);
+        if (!NESTED && hitBsdfType(sc, __float_as_uint(hw.w)) >= uint32_t(TGPU_BSDF_MIXED)) return END_DEFERRED;
+        return shadePath<-1, true, NESTED>(sc, st, path, true);
     }
 
     // ---- handleVolume ----
@@ -2733,7 +2747,8 @@ TG_DEV int volumePath(const DScene &sc, const DState &st, uint32_t path) // retu
 // CLASS >= 0: the caller guarantees the hit BSDF's type (the per-class shade kernels), which lets the compiler drop the
 // code of the other BSDFs; MEDIA = false is the lean instantiation: no medium bookkeeping, only environment and quad
 // lights (the launcher picks the general one for scenes with media or sphere / disk lights).
-template <int CLASS, bool MEDIA>
+// NESTED = false: the caller has checked that the hit BSDF is not made of other BSDFs (volumePath<false>).
+template <int CLASS, bool MEDIA, bool NESTED>
 TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool afterMedium)
 {
     const int maxBounces = sc.settings.max_bounces, minBounces = sc.settings.min_bounces;
@@ -2847,7 +2862,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
                             consistent = geometricBackside == shadingBackside;
                         }
                         ev.requestedLobe = AllButSpecular;
-                        V3 f = consistent ? bsdfEval<CLASS>(sc, bsdf, ev) : V3(0.0f);
+                        V3 f = consistent ? bsdfEval<CLASS, NESTED>(sc, bsdf, ev) : V3(0.0f);
                         if (!f.isZero()) {
                             // attenuatedEmission (TraceBase.cpp:144-174) up to the shadow test
                             V3 E(0.0f);
@@ -2879,7 +2894,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
                             if (lit && shadowPasses && (!E.isZero() || aovOpen)) {
                                 if (!E.isZero()) { // (e == 0 returns before f*e/pdf, TraceBase.cpp:276-279)
                                     V3 lightF = f*E/ls.pdf;
-                                    const float mis = powerHeuristic(ls.pdf, bsdfPdf<CLASS>(sc, bsdf, ev));
+                                    const float mis = powerHeuristic(ls.pdf, bsdfPdf<CLASS, NESTED>(sc, bsdf, ev));
                                     lightF *= mis;
                                     L = lightF;
                                     misL = mis;
@@ -2894,7 +2909,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
                 // ---- bsdfSample (TraceBase.cpp:287-321) ----
                 {
                     ev.requestedLobe = AllButSpecular;
-                    if (bsdfSample<CLASS>(sc, bsdf, ev, smp) && !ev.weight.isZero()) {
+                    if (bsdfSample<CLASS, NESTED>(sc, bsdf, ev, smp) && !ev.weight.isZero()) {
                         V3 wo = ev.frame.toGlobal(ev.wo);
                         bool consistent = true;
                         if (sc.settings.enable_consistency_checks) {
@@ -2947,7 +2962,7 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
 
         // continuation (TraceBase.cpp:546-565)
         ev.requestedLobe = AllLobes;
-        bool sampled = !passThrough && bsdfSample<CLASS>(sc, bsdf, ev, smp);
+        bool sampled = !passThrough && bsdfSample<CLASS, NESTED>(sc, bsdf, ev, smp);
         V3 wo(0.0f);
         bool alive = sampled;
         if (passThrough) { // wo = ray.dir(); weight = transparency/transparencyScalar; sampledLobe = ForwardLobe
@@ -3072,7 +3087,16 @@ static __global__ void __launch_bounds__(256, 2) k_volume(DScene sc, DState st, 
     const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + TG_CLASS_VOLUME)];
     const uint32_t *list = st.lists[set][1 + TG_CLASS_VOLUME];
     uint8_t *endFlag = st.endFlag[set] + listBase(st, set, 1 + TG_CLASS_VOLUME);
-    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) endFlag[q] = uint8_t(volumePath(sc, st, list[q]));
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x) endFlag[q] = uint8_t(volumePath<false>(sc, st, list[q]));
+}
+// ... and the entries k_volume left behind: paths that left their medium onto a BSDF made of other BSDFs (launched only for scenes that have both)
+static __global__ void __launch_bounds__(256, 2) k_volume_nested(DScene sc, DState st, int set)
+{
+    const uint32_t count = st.counters[CNT(CNT_LIST0 + set*TG_LISTS + 1 + TG_CLASS_VOLUME)];
+    const uint32_t *list = st.lists[set][1 + TG_CLASS_VOLUME];
+    uint8_t *endFlag = st.endFlag[set] + listBase(st, set, 1 + TG_CLASS_VOLUME);
+    for (uint32_t q = blockIdx.x*blockDim.x + threadIdx.x; q < count; q += gridDim.x*blockDim.x)
+        if (endFlag[q] == END_DEFERRED) endFlag[q] = uint8_t(shadePath<-1, true>(sc, st, list[q], true));
 }
 #endif
 

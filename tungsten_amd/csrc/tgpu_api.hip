@@ -83,6 +83,7 @@ struct tgpu_ctx {
     uint32_t classMask = 0;               // BSDF classes (shade kernels) the uploaded scene can hit
     bool generalGeometry = false;         // instances, spheres or disks: INST instantiation of the traversal kernels
     bool generalShading = false;          // media, spheres or disks (also as lights): general instantiation of the shade kernels
+    bool nestedBsdfs = false;             // the scene has a BSDF made of other BSDFs (mixed, rough_coat, transparency, thinsheet): with media, k_volume_nested runs
     bool coopTail = true;                 // ... and, with plain geometry, in its four-lanes-per-path form (TGPU_TAIL_COOP=0: one lane per path, A/B)
     bool leanTail = true;                 // scenes with lean shading finish in the lean tail kernel (TGPU_TAIL_LEAN=0: the general one, A/B)
     bool trackRecords = false;            // settings.adaptive_sampling
@@ -757,6 +758,8 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     ctx->generalShading = s->n_media != 0 || s->n_spheres || s->n_disks;
     for (uint32_t i = 0; i < s->n_lights; ++i) if (s->lights[i].kind == TGPU_LIGHT_SPHERE || s->lights[i].kind == TGPU_LIGHT_DISK) ctx->generalShading = true;
     ctx->classMask = 0;
+    ctx->nestedBsdfs = false;
+    for (uint32_t i = 0; i < s->n_bsdfs; ++i) if (s->bsdfs[i].type >= TGPU_BSDF_MIXED) ctx->nestedBsdfs = true;
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) ctx->classMask |= 1u << std::min<uint32_t>(uint32_t(s->bsdfs[i].type), uint32_t(TG_CLASS_OTHER));
     for (uint32_t i = 0; i < s->n_bsdfs; ++i) { // every BSDF with a ForwardLobe lets shadow rays through
         const int t = s->bsdfs[i].type;
@@ -1197,6 +1200,7 @@ static int driveIteration(tgpu_ctx *ctx)
             TG_LAUNCH_SHADE(0) TG_LAUNCH_SHADE(1) TG_LAUNCH_SHADE(2) TG_LAUNCH_SHADE(3) TG_LAUNCH_SHADE(4) TG_LAUNCH_SHADE(5) TG_LAUNCH_SHADE(TG_CLASS_OTHER)
 #undef TG_LAUNCH_SHADE
             if (sc.nMedia) { ctx->stats.shade_launches++; hipLaunchKernelGGL(k_volume, dim3(grid), dim3(256), 0, stream, sc, st, out); }
+            if (sc.nMedia && ctx->nestedBsdfs) { ctx->stats.shade_launches++; hipLaunchKernelGGL(k_volume_nested, dim3(grid), dim3(256), 0, stream, sc, st, out); }
         }
         // the queue forms of the shadow kernel (visibility bits out; the next kernel that touches the path folds the NEE terms in)
         // serve every scene whose shadow rays are single segments; forward-scattering scenes keep k_shadow's multi-segment walk

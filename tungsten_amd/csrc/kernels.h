@@ -3868,7 +3868,8 @@ __global__ void __launch_bounds__(256) k_tail(DScene sc, DState st, int set, uin
 // longest of the three.  The arithmetic is the wavefront's: the helpers leave the visibility bits in shD.w as k_shadow_q does, and whoever
 // touches the path next (shadePath, missPathEx, the retire code below) folds the NEE terms in with resolveNeeTerms -- same values, same order.
 // =================================================================================================
-template <bool COUNT>
+// NESTED = false: the scene has no BSDF made of other BSDFs -- their code and its out-of-line calls stay out (bsdfEval's NESTED, device.h).
+template <bool COUNT, bool NESTED>
 __global__ void __launch_bounds__(256) k_tail_coop(DScene sc, DState st, int set)
 {
     extern __shared__ uint32_t ldsStack[];
@@ -3960,7 +3961,7 @@ __global__ void __launch_bounds__(256) k_tail_coop(DScene sc, DState st, int set
                 if (r.bestPrim == PRIM_MISS) {
                     missPath(sc, st, slot);
                 } else {
-                    shadePath<-1, false>(sc, st, slot);
+                    shadePath<-1, false, NESTED>(sc, st, slot);
                     events++;
                 }
                 nextAlive = flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE;
@@ -4213,6 +4214,6 @@ static __global__ void k_eval_math(int kind, const float *a, const float *b, uin
     PFX template __global__ void k_shadow<true, true, true>(DScene, DState, int);
 #define TG_KERNELS_TAIL(PFX, C, I, F) PFX template __global__ void k_tail<C, I, F>(DScene, DState, int, uint32_t);
 #define TG_KERNELS_TAIL_LEAN(PFX, C, I) PFX template __global__ void k_tail<C, I, false, true>(DScene, DState, int, uint32_t);
-#define TG_KERNELS_TAIL_COOP(PFX, C) PFX template __global__ void k_tail_coop<C>(DScene, DState, int);
+#define TG_KERNELS_TAIL_COOP(PFX, C, N) PFX template __global__ void k_tail_coop<C, N>(DScene, DState, int);
 
 } // namespace tg

@@ -42,8 +42,10 @@ TG_KERNELS_TAIL_LEAN(extern, false, false)
 TG_KERNELS_TAIL_LEAN(extern, false, true)
 TG_KERNELS_TAIL_LEAN(extern, true, false)
 TG_KERNELS_TAIL_LEAN(extern, true, true)
-TG_KERNELS_TAIL_COOP(extern, false)
-TG_KERNELS_TAIL_COOP(extern, true)
+TG_KERNELS_TAIL_COOP(extern, false, false)
+TG_KERNELS_TAIL_COOP(extern, false, true)
+TG_KERNELS_TAIL_COOP(extern, true, false)
+TG_KERNELS_TAIL_COOP(extern, true, true)
 }
 
 namespace {
@@ -1128,9 +1130,11 @@ static int driveIteration(tgpu_ctx *ctx)
         // plain geometry on top of that: four lanes per path, the NEE rays traced beside the continuation ray (k_tail_coop)
         if (ctx->coopTail && (variant == 8 || variant == 12)) grid = gridFor(ctx, uint64_t(nCur)*4);
         switch (variant) {
-        case 8: if (ctx->coopTail) hipLaunchKernelGGL((k_tail_coop<false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur); else TG_LAUNCH_TAIL_LEAN(false, false); break;
+#define TG_LAUNCH_TAIL_COOP(C) { if (ctx->nestedBsdfs) hipLaunchKernelGGL((k_tail_coop<C, true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur); \
+                                 else hipLaunchKernelGGL((k_tail_coop<C, false>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur); }
+        case 8: if (ctx->coopTail) TG_LAUNCH_TAIL_COOP(false) else TG_LAUNCH_TAIL_LEAN(false, false); break;
         case 10: TG_LAUNCH_TAIL_LEAN(false, true); break;
-        case 12: if (ctx->coopTail) hipLaunchKernelGGL((k_tail_coop<true>), dim3(grid), dim3(256), ctx->ldsBytes, stream, sc, st, cur); else TG_LAUNCH_TAIL_LEAN(true, false); break;
+        case 12: if (ctx->coopTail) TG_LAUNCH_TAIL_COOP(true) else TG_LAUNCH_TAIL_LEAN(true, false); break;
         case 14: TG_LAUNCH_TAIL_LEAN(true, true); break;
         case 0: TG_LAUNCH_TAIL(false, false, false); break;
         case 1: TG_LAUNCH_TAIL(false, false, true); break;
@@ -1143,6 +1147,7 @@ static int driveIteration(tgpu_ctx *ctx)
         }
 #undef TG_LAUNCH_TAIL
 #undef TG_LAUNCH_TAIL_LEAN
+#undef TG_LAUNCH_TAIL_COOP
         // every listed slot ends on the free list: both list sets are empty afterwards
         (void)hipMemsetAsync(st.counters + CNT(CNT_LIST0), 0, 2*TG_LISTS*TG_CNT_STRIDE*sizeof(uint32_t), stream);
         ctx->stats.tail_launches++;

@@ -3053,8 +3053,9 @@ TG_DEV int shadePath(const DScene &sc, const DState &st, uint32_t path, bool aft
             const uint32_t fwdBits = fwdScene ? (4u | (uint32_t(mediumL + 1) << 8) | (uint32_t(mediumB + 1) << 16)) : 0u;
             st.shE[path] = mk4u(tpVertex, (hasPostAdd ? 1u : 0u) | fwdBits);
             const float bounceBits = __uint_as_float(uint32_t(neeBounce));
-            if (hasPostAdd) st.shF[path] = mk4(postAdd, bounceBits);
-            else if (fwdScene) st.shF[path] = mk4(V3(0.0f), bounceBits);
+            // (always all eight sectors of the NEE record, the unused emitter term too: a whole-line write needs no merge with the line's old
+            // contents on its way to HBM; +0.6 %, profiles/r03_ab_notes.txt)
+            st.shF[path] = mk4(hasPostAdd ? postAdd : V3(0.0f), bounceBits);
         }
         st.em[path] = mk4u(em, smp.scramble);
     }

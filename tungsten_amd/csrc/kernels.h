@@ -3890,7 +3890,13 @@ __global__ void __launch_bounds__(256) k_tail_coop(DScene sc, DState st, int set
         slot = __shfl(slot, leader);
         // alive: the path has a ray to trace; pending: its last vertex's NEE rays are still to be traced (group-uniform)
         bool alive = have && flagsEnd(__float_as_uint(st.tp[slot].w)) == END_ALIVE, pending = false;
+        uint32_t vertex = 0; // COUNT: when (10 ns ticks since this lane started) the slowest path reached its n-th vertex -> stats[8 + n], as in k_tail
+        const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
         while (__ballot(alive || pending)) {
+            if (COUNT && role == 0 && alive) {
+                atomicMax(&st.stats[8 + min(vertex, 127u)], wall_clock64() - t0);
+                ++vertex;
+            }
             TravState r;
             r.node = 0; r.sp = 0; r.bestT = 0.0f; r.bestU = 0.0f; r.bestV = 0.0f; r.bestPrim = PRIM_MISS;
             bool active = false, hasRay = false, blocked = false;

@@ -83,7 +83,18 @@ def gather_framebuffers(local_rgbs, shards, world, rank, sub, dist=None):
         if rank == 0:
             for r in range(world):
                 image[idx[r*sub + j]] = gathered[r][: sizes[r*sub + j]]
-    return image.cpu().numpy().reshape(res_y, res_x, 3) if rank == 0 else None
+    if rank != 0:
+        return None
+    if image.device.type == "cpu":
+        return image.numpy().reshape(res_y, res_x, 3)
+    # one device-to-host copy of the image into a page-locked buffer kept between renders (a pageable destination costs several ms for these
+    # 11 MB -- a tenth of an 8-rank render); the caller gets a view of that buffer, valid until the next gather of the same image size
+    key = ("host", res_x, res_y)
+    if key not in _INDEX_CACHE:
+        _INDEX_CACHE[key] = torch.empty((res_y*res_x, 3), dtype=torch.float32, pin_memory=True)
+    host = _INDEX_CACHE[key]
+    host.copy_(image)
+    return host.numpy().reshape(res_y, res_x, 3)
 
 
 def exchange_records(table, dist, device=None):

@@ -448,6 +448,24 @@ def test_a_320_spp_render_matches_the_oracle(ta, oracle_py, gpu_ctx):
     assert_bit_exact(got, ref, "c2 64x36x320spp")
 
 
+def test_more_passes_in_flight_than_the_result_ring_has_slices(ta, oracle_py, gpu_ctx):
+    """80 passes of 2 spp enqueued at once on a small image: more jobs than the result ring has slices (32).  The pool runs out of admitted samples while
+    the ring is still full; the core must then finish the jobs in flight (tail kernel) and go on -- it used to drain the pool one bounce per iteration
+    until the slowest path of the oldest job had ended (116 instead of 52 ms for a 20-pass request on an 8-rank shard when the ring had 16 slices).
+    The image is the oracle's either way."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(64, 36))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(160, spp_step=2)
+    st = gpu_ctx.stats()
+    got = gpu_ctx.download()
+    ref = oracle_py.Oracle(hs, **oracle_py.GPU).render_shard(shard, 160, spp_step=2)
+    assert_bit_exact(got, ref, "c2 64x36, 80 passes of 2 spp")
+    assert st["tail_launches"] >= 2, st          # the ring filled up at least once before the end
+    assert st["extend_launches"] < 80, st        # ... and nobody waited a path's length in iterations per ring of jobs
+
+
 def test_output_buffers_and_adaptive_passes_past_256(ta, oracle_py, gpu_ctx):
     """The auxiliary buffers and an adaptive pass at sample indices >= 256 (per-tile sample offsets past the first Sobol' block)."""
     hs = ta.HostScene(scene_path("materialtest/materialtest.json"), resolution=(64, 36), output_buffers=["depth", ("normal", True, False), "albedo", ("visibility", False, True)])

@@ -31,12 +31,17 @@ namespace tg {
 enum { CNT_LIST0 = 0 /* 2 x TG_LISTS list lengths */, CNT_HEAD_EXT = 2*TG_LISTS, CNT_HEAD_SHADOW = CNT_HEAD_EXT + 1,
        CNT_REGEN = CNT_HEAD_EXT + 2 /* samples claimed this iteration */,
        CNT_FREE = CNT_HEAD_EXT + 3 /* persistent: length of the free-slot list */,
-       CNT_JOB_DONE0 = CNT_HEAD_EXT + 4 /* TG_RING persistent per-job retire counters */, CNT_TOTAL = 40 };
+       CNT_JOB_DONE0 = CNT_HEAD_EXT + 4 /* TG_RING persistent per-job retire counters */ };
 // Result-ring slices (= jobs that may be in flight).  A job can only be folded into the framebuffer
 // once its slowest path has ended (~max_bounces iterations after its last sample started), and during
-// that time the pool keeps starting samples of later jobs: the ring must hold ~26 x pool size samples.
-#define TG_RING 16
-static_assert(CNT_JOB_DONE0 + TG_RING <= CNT_TOTAL, "counter block too small");
+// that time the pool keeps starting samples of later jobs: to never run dry the ring must hold ~26 x pool size samples.
+// 32 slices of 16 spp do for a whole 1280x720 image (the benchmark: 30 jobs); a small shard (an 8-rank run: 1/8 of the pixels per job)
+// gets by as long as everything it was asked for fits into the ring -- when it does not, the launcher finishes the jobs in flight
+// with the tail kernel instead of draining the pool one iteration per bounce (tgpu_api.hip, driveIteration).  With 16 slices a 20-pass
+// request stalled exactly like that: 116 instead of 52 ms for an 8-rank shard, 7 % on the whole image (profiles/r03_ab_notes.txt).
+#define TG_RING 32
+static_assert(TG_RING <= 32, "tgpu_ctx::ringFree is a 32-bit mask");
+enum { CNT_TOTAL = CNT_JOB_DONE0 + TG_RING };
 // Every counter lives on its own 128-byte line: the hot ones (dequeue heads, list lengths) are hit by
 // atomics from every CU, and an L2 channel serialises the requests to one line (~88 atomics/us).
 #define TG_CNT_STRIDE 32
@@ -323,9 +328,8 @@ TG_DEV void cameraRay(const tgpu_camera &cam, uint32_t px, uint32_t py, float xi
 // (PathTraceIntegrator.cpp:143-147, PathTracer.cpp:23-31).
 TG_DEV void startSample(const DScene &sc, const DState &st, const JobRing &jobs, unsigned long long g, uint32_t slot)
 {
-    uint32_t j = 0;
-    for (uint32_t t = 1; t < jobs.n; ++t)
-        if (g >= jobs.start[t]) j = t;
+    uint32_t j = jobs.n ? jobs.n - 1u : 0u; // start[] increases and new samples belong to the latest jobs: search from the end
+    while (j > 0u && g < jobs.start[j]) --j;
     uint32_t e = uint32_t(g - jobs.start[j]);
     uint32_t s, k, sampleIndex;
     if (jobs.adaptive[j]) {

@@ -23,6 +23,7 @@
 #include <vector>
 
 using namespace tg;
+static constexpr uint32_t TG_RING_ALL = TG_RING >= 32 ? 0xFFFFFFFFu : ((1u << (TG_RING & 31)) - 1u); // every slice of the result ring free
 
 // instantiated in tu_*.hip
 namespace tg {
@@ -107,7 +108,7 @@ struct tgpu_ctx {
     uint32_t tailSpread = 2;  // lanes per path in the tail kernel (power of two; TGPU_TAIL_SPREAD)
     uint64_t aliveCount = 0, hostExtendRays = 0;
     int curQ = 0;
-    uint32_t ringFree = (1u << TG_RING) - 1u;
+    uint32_t ringFree = TG_RING_ALL;
     int numCUs = 256;
     int maxGrid = 2048;
     int extendQueue = 4;        // rays per lane of the extend kernel's queue form: 4 or 8; TGPU_EXTEND_Q=0: one ray per lane and claim (A/B)
@@ -511,7 +512,7 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     ctx->aliveCount = 0;
     for (int l = 0; l < TG_LISTS; ++l) ctx->listCount[l] = 0;
     ctx->curQ = 0;
-    ctx->ringFree = (1u << TG_RING) - 1u;
+    ctx->ringFree = TG_RING_ALL;
     ctx->sc = DScene{};
     ctx->st = DState{};
     DScene &sc = ctx->sc;
@@ -1114,7 +1115,9 @@ static int driveIteration(tgpu_ctx *ctx)
     bool tail = false;
     if (nCur > 0 && ctx->aliveCount > 0 && ctx->aliveCount <= ctx->tailMax && ctx->sampleBase == limit) {
         std::lock_guard<std::mutex> lk(ctx->mtx);
-        tail = ctx->pending.empty();
+        // ... or nothing that could be admitted: every slice of the result ring is taken, and none comes back before the slowest path of the
+        // oldest job has ended -- finish the jobs in flight now instead of draining the pool one bounce per iteration
+        tail = ctx->pending.empty() || ctx->ringFree == 0u || ctx->active.size() >= TG_RING;
     }
     if (tail) {
         Timer t(ctx, &ctx->stats.other_ms);
@@ -1361,7 +1364,7 @@ static void workerMain(tgpu_ctx *ctx)
                 ctx->pending.clear();
                 ctx->active.clear();
                 ctx->nCur = 0;
-                ctx->ringFree = (1u << TG_RING) - 1u;
+                ctx->ringFree = TG_RING_ALL;
                 ctx->sampleBase = ctx->globalCursor;
                 resetPool(ctx);
                 if (rc == TGPU_ERR_ABORTED) ctx->error = "render aborted";

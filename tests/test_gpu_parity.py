@@ -448,6 +448,25 @@ def test_a_320_spp_render_matches_the_oracle(ta, oracle_py, gpu_ctx):
     assert_bit_exact(got, ref, "c2 64x36x320spp")
 
 
+def test_upload_knobs_apply_to_one_upload_only(ta, gpu_ctx, monkeypatch):
+    """The TGPU_* A/B knobs are read by tgpu_upload_scene and hold for that upload.  They used to stick to the context: one upload with TGPU_TAIL_MAX=0
+    (several tests above do that on the shared context) left every later render of the session without its tail kernel."""
+    hs = ta.HostScene(scene_path("materialtest/c2.json"), resolution=(64, 36))
+    shard = ta.Shard(hs.res_x, hs.res_y)
+    monkeypatch.setenv("TGPU_TAIL_MAX", "0")
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(8, spp_step=8)
+    without = gpu_ctx.download()[0]
+    assert gpu_ctx.stats()["tail_launches"] == 0
+    monkeypatch.delenv("TGPU_TAIL_MAX")
+    gpu_ctx.upload(hs, shard)
+    gpu_ctx.reset_stats()
+    gpu_ctx.render(8, spp_step=8)
+    assert gpu_ctx.stats()["tail_launches"] >= 1
+    assert np.array_equal(gpu_ctx.download()[0].view(np.uint32), without.view(np.uint32))
+
+
 def test_more_passes_in_flight_than_the_result_ring_has_slices(ta, oracle_py, gpu_ctx):
     """80 passes of 2 spp enqueued at once on a small image: more jobs than the result ring has slices (32).  The pool runs out of admitted samples while
     the ring is still full; the core must then finish the jobs in flight (tail kernel) and go on -- it used to drain the pool one bounce per iteration

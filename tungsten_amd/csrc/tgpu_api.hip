@@ -666,6 +666,10 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
     sc.nInstSets = s->n_instance_sets;
 
     sc.stackEntries = 3*maxDepth4 + 2; // at most 3 pushes per level
+    // the A/B knobs apply to THIS upload: each starts from its default again (they used to stick to the context, so one upload with
+    // TGPU_TAIL_MAX=0 left every later render of that context without its tail kernel)
+    ctx->extendQueue = 4; ctx->extendPersistent = true; ctx->shadowQueue = 4;
+    ctx->leanTail = true; ctx->coopTail = true; ctx->tailSpread = 2; ctx->tailMax = 65536;
     if (const char *e = getenv("TGPU_EXTEND_Q")) ctx->extendQueue = atoi(e) >= 8 ? 8 : (atoi(e) ? 4 : 0);
     if (const char *e = getenv("TGPU_EXTEND_P")) ctx->extendPersistent = atoi(e) != 0;
     ctx->instExtendQueue = getenv("TGPU_INST_EXTEND_Q") && atoi(getenv("TGPU_INST_EXTEND_Q")) != 0;

@@ -379,7 +379,11 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *scene,
  * and folding them into the running per-pixel mean in the order
  * OutputBuffer::addSample would (OutputBuffer.hpp:104-132).  Asynchronous with
  * respect to the host up to internal queue-drain checks; `stream` is a
- * hipStream_t (NULL = the context's own stream).                             */
+ * hipStream_t (NULL = the context's own stream).  Any number of passes may be
+ * enqueued before tgpu_wait: the path pool stays full across them (one end-of-
+ * render drain for all).  Up to 32 passes are in flight at a time (a pass holds
+ * a slice of the sample ring until its slowest path has ended); with more, the
+ * ones in flight are finished first.                                           */
 int tgpu_render_pass(tgpu_ctx *ctx, uint32_t spp_begin, uint32_t spp_count, void *stream);
 
 /* Adaptive pass (PathTraceIntegrator::generateWork/renderTile with adaptive_sampling, PathTraceIntegrator.cpp:110-156):

@@ -787,64 +787,54 @@ private:
         }
     }
 
-    // stb_image's stbi__idct_block: columns, then rows; 1 << 12 constants, two guard bits between the passes, +128 level shift folded into the rounding
-    static int f2f(double x) { return int(x*4096 + 0.5); }
-    struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
-    static Idct1D idct1D(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+    // The 8x8 inverse DCT with stb_image's numbers (stbi__idct_block, :1404-1502: the jidctint factorisation with 12-bit constants, columns first with two
+    // guard bits kept, then rows with the +128 level shift folded into the rounding term).  One dimension splits into the half fed by the even inputs
+    // and the half fed by the odd ones: output k is their sum, output 7 - k their difference.  Integer arithmetic throughout, so only the constants
+    // (rounded as stb rounds them, the negative ones included) and the two rounding terms decide the bytes -- tests/test_ref_kat6.py compares them all.
+    static int fixed12(double x) { return int(x*4096 + 0.5); }
+    static void oneDimension(const int in[8], int evenHalf[4], int oddHalf[4])
     {
-        Idct1D r;
-        int p1, p2, p3, p4, p5, t0, t1, t2, t3;
-        p2 = s2; p3 = s6;
-        p1 = (p2 + p3)*f2f(0.5411961f);
-        t2 = p1 + p3*f2f(-1.847759065f);
-        t3 = p1 + p2*f2f(0.765366865f);
-        p2 = s0; p3 = s4;
-        t0 = (p2 + p3)*4096;
-        t1 = (p2 - p3)*4096;
-        r.x0 = t0 + t3; r.x3 = t0 - t3; r.x1 = t1 + t2; r.x2 = t1 - t2;
-        t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-        p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-        p5 = (p3 + p4)*f2f(1.175875602f);
-        t0 = t0*f2f(0.298631336f);
-        t1 = t1*f2f(2.053119869f);
-        t2 = t2*f2f(3.072711026f);
-        t3 = t3*f2f(1.501321110f);
-        p1 = p5 + p1*f2f(-0.899976223f);
-        p2 = p5 + p2*f2f(-2.562915447f);
-        p3 = p3*f2f(-1.961570560f);
-        p4 = p4*f2f(-0.390180644f);
-        r.t3 = t3 + p1 + p4; r.t2 = t2 + p2 + p3; r.t1 = t1 + p2 + p4; r.t0 = t0 + p1 + p3;
-        return r;
+        const int rotation = (in[2] + in[6])*fixed12(0.5411961f);
+        const int outer = rotation + in[2]*fixed12(0.765366865f), inner = rotation + in[6]*fixed12(-1.847759065f);
+        const int sum04 = (in[0] + in[4])*4096, diff04 = (in[0] - in[4])*4096;
+        evenHalf[0] = sum04 + outer; evenHalf[1] = diff04 + inner; evenHalf[2] = diff04 - inner; evenHalf[3] = sum04 - outer;
+        const int pair73 = in[7] + in[3], pair51 = in[5] + in[1], pair71 = in[7] + in[1], pair53 = in[5] + in[3];
+        const int common = (pair73 + pair51)*fixed12(1.175875602f);
+        const int via71 = common + pair71*fixed12(-0.899976223f), via53 = common + pair53*fixed12(-2.562915447f);
+        const int via73 = pair73*fixed12(-1.961570560f), via51 = pair51*fixed12(-0.390180644f);
+        oddHalf[0] = in[1]*fixed12(1.501321110f) + via71 + via51;
+        oddHalf[1] = in[3]*fixed12(3.072711026f) + via53 + via73;
+        oddHalf[2] = in[5]*fixed12(2.053119869f) + via53 + via51;
+        oddHalf[3] = in[7]*fixed12(0.298631336f) + via71 + via73;
     }
     static uint8_t clampByte(int x) { return uint8_t(x < 0 ? 0 : (x > 255 ? 255 : x)); }
-    static void idct(uint8_t *out, int stride, const short *d)
+    static void idct(uint8_t *out, int stride, const short *coeff)
     {
-        int val[64];
-        for (int i = 0; i < 8; ++i) {
-            int *v = val + i;
-            const short *c = d + i;
-            if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-                const int dc = c[0]*4;
-                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
-            } else {
-                Idct1D r = idct1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
-                r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
-                v[0] = (r.x0 + r.t3) >> 10; v[56] = (r.x0 - r.t3) >> 10;
-                v[8] = (r.x1 + r.t2) >> 10; v[48] = (r.x1 - r.t2) >> 10;
-                v[16] = (r.x2 + r.t1) >> 10; v[40] = (r.x2 - r.t1) >> 10;
-                v[24] = (r.x3 + r.t0) >> 10; v[32] = (r.x3 - r.t0) >> 10;
+        int columns[64]; // after the column pass, scaled by 4
+        for (int x = 0; x < 8; ++x) {
+            int in[8];
+            bool onlyDc = true;
+            for (int k = 0; k < 8; ++k) { in[k] = coeff[x + 8*k]; onlyDc = onlyDc && (k == 0 || in[k] == 0); }
+            if (onlyDc) { // stb's shortcut: a column of one value
+                for (int k = 0; k < 8; ++k) columns[x + 8*k] = in[0]*4;
+                continue;
+            }
+            int even[4], odd[4];
+            oneDimension(in, even, odd);
+            for (int k = 0; k < 4; ++k) {
+                columns[x + 8*k] = (even[k] + 512 + odd[k]) >> 10;
+                columns[x + 8*(7 - k)] = (even[k] + 512 - odd[k]) >> 10;
             }
         }
-        for (int i = 0; i < 8; ++i) {
-            const int *v = val + i*8;
-            uint8_t *o = out + size_t(i)*stride;
-            Idct1D r = idct1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            const int bias = 65536 + (128 << 17);
-            r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
-            o[0] = clampByte((r.x0 + r.t3) >> 17); o[7] = clampByte((r.x0 - r.t3) >> 17);
-            o[1] = clampByte((r.x1 + r.t2) >> 17); o[6] = clampByte((r.x1 - r.t2) >> 17);
-            o[2] = clampByte((r.x2 + r.t1) >> 17); o[5] = clampByte((r.x2 - r.t1) >> 17);
-            o[3] = clampByte((r.x3 + r.t0) >> 17); o[4] = clampByte((r.x3 - r.t0) >> 17);
+        const int rounding = 65536 + (128 << 17); // half an output unit plus the level shift
+        for (int y = 0; y < 8; ++y) {
+            int even[4], odd[4];
+            oneDimension(columns + 8*y, even, odd);
+            uint8_t *row = out + size_t(y)*stride;
+            for (int k = 0; k < 4; ++k) {
+                row[k] = clampByte((even[k] + rounding + odd[k]) >> 17);
+                row[7 - k] = clampByte((even[k] + rounding - odd[k]) >> 17);
+            }
         }
     }
 
@@ -1088,31 +1078,23 @@ private:
             for (int i = 0; i < w; ++i) out[i] = uint8_t((3*nearRow[i] + farRow[i] + 2) >> 2);
             return out;
         }
-        if (hs == 2 && vs == 1) { // two samples for one, ends replicated
+        if (hs == 2 && vs == 1) { // two samples for one along the row: each is 3:1 between its source sample and the neighbour on its side, the ends stand
             if (w == 1) { out[0] = out[1] = nearRow[0]; return out; }
-            out[0] = nearRow[0];
-            out[1] = uint8_t((nearRow[0]*3 + nearRow[1] + 2) >> 2);
-            int i = 1;
-            for (; i < w - 1; ++i) {
-                const int n3 = 3*nearRow[i] + 2;
-                out[i*2] = uint8_t((n3 + nearRow[i - 1]) >> 2);
-                out[i*2 + 1] = uint8_t((n3 + nearRow[i + 1]) >> 2);
+            for (int i = 0; i < w; ++i) {
+                const int centre = 3*nearRow[i] + 2;
+                out[2*i] = i == 0 ? nearRow[0] : uint8_t((centre + nearRow[i - 1]) >> 2);
+                out[2*i + 1] = i == w - 1 ? nearRow[w - 1] : uint8_t((centre + nearRow[i + 1]) >> 2);
             }
-            out[i*2] = uint8_t((nearRow[w - 2]*3 + nearRow[w - 1] + 2) >> 2);
-            out[i*2 + 1] = nearRow[w - 1];
+            out[2*(w - 1)] = uint8_t((3*nearRow[w - 2] + nearRow[w - 1] + 2) >> 2); // stb weights the last pair the other way round (stb_image.c:2382); kept, the bytes are the contract
             return out;
         }
-        if (hs == 2 && vs == 2) { // 2x2 for one: the vertical 3:1 blend first, then the horizontal one on the sums
-            if (w == 1) { out[0] = out[1] = uint8_t((3*nearRow[0] + farRow[0] + 2) >> 2); return out; }
-            int t1 = 3*nearRow[0] + farRow[0];
-            out[0] = uint8_t((t1 + 2) >> 2);
-            for (int i = 1; i < w; ++i) {
-                const int t0 = t1;
-                t1 = 3*nearRow[i] + farRow[i];
-                out[i*2 - 1] = uint8_t((3*t0 + t1 + 8) >> 4);
-                out[i*2] = uint8_t((3*t1 + t0 + 8) >> 4);
+        if (hs == 2 && vs == 2) { // 2x2 for one: the vertical 3:1 blend of the two source rows first (kept at 4x), then the horizontal one on those sums
+            auto column = [&](int i) { return 3*nearRow[i] + farRow[i]; };
+            for (int i = 0; i < w; ++i) {
+                const int here = column(i);
+                out[2*i] = i == 0 ? uint8_t((here + 2) >> 2) : uint8_t((3*here + column(i - 1) + 8) >> 4);
+                out[2*i + 1] = i == w - 1 ? uint8_t((here + 2) >> 2) : uint8_t((3*here + column(i + 1) + 8) >> 4);
             }
-            out[w*2 - 1] = uint8_t((t1 + 2) >> 2);
             return out;
         }
         for (int i = 0; i < w; ++i) for (int j = 0; j < hs; ++j) out[i*hs + j] = nearRow[i]; // other ratios: nearest

@@ -60,6 +60,7 @@ FIXTURES = [
     ("ldr_texture2_128x72_4spp", "next/ldr_texture2.json", (128, 72), 4),   # .bmp / .tga bitmaps: the reference's stb_image route
     ("ldr_texture3_128x72_4spp", "next/ldr_texture3.json", (128, 72), 4),   # baseline .jpg bitmaps (4:2:0, 4:2:2 + restart intervals, 4:4:4, grey): stb_image again
     ("fog_nested_96x54_16spp", "next/fog_nested.json", (96, 54), 16),   # BSDFs made of BSDFs (mixed wall, rough_coat box) reached from inside a camera medium
+    ("ldr_texture4_128x72_4spp", "next/ldr_texture4.json", (128, 72), 4),   # progressive .jpg bitmaps (4:2:0, 4:4:4 with partial blocks, grey with restart markers)
     ("tonemap_linear_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "linear", "keep_png": True}),
     ("tonemap_gamma_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "gamma", "keep_png": True}),
     ("tonemap_reinhard_48x27_4spp", "materialtest/c2.json", (48, 27), 4, False, {"tonemap": "reinhard", "keep_png": True}),

@@ -61,6 +61,7 @@ def assert_bit_exact(got, ref, what):
     ("next/ldr_texture2.json", (128, 72), 8, 8), # the same through .bmp / .tga files
     ("next/ldr_texture3.json", (128, 72), 8, 8), # and through .jpg files (4:2:0, 4:2:2 + restart markers, 4:4:4, grey)
     ("next/fog_nested.json", (96, 54), 16, 8),   # a mixed wall and a rough_coat box inside a camera medium: k_volume leaves those surface steps to k_volume_nested
+    ("next/ldr_texture4.json", (128, 72), 8, 8), # progressive .jpg textures
     # the fork's remaining transmittance models in the Cornell box's camera medium
     ("next/trans_erlang.json", (96, 54), 8, 8),
     ("next/trans_davis.json", (96, 54), 8, 8),

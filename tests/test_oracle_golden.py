@@ -49,6 +49,7 @@ CASES = [
     # baseline JPEG bitmaps: 4:2:0, 4:2:2 with optimised tables and restart intervals, 4:4:4 with partial MCUs, one-component grey
     ("ldr_texture3_128x72_4spp", "next/ldr_texture3.json", (128, 72), 4),
     ("fog_nested_96x54_16spp", "next/fog_nested.json", (96, 54), 16),      # nested BSDFs hit by paths that run inside a medium (k_volume_nested's case)
+    ("ldr_texture4_128x72_4spp", "next/ldr_texture4.json", (128, 72), 4),  # the same through progressive JPEG files
     # round 3: long enough to contain rare events -- box culls and exact ties that only Embree's own traversal order decides (oracle/embree_bvh4.h)
     ("cornell_sobol_96x54_64spp", "cornell-box/scene_sobol.json", (96, 54), 64),     # pixel (67,7) sample 41: ceiling quad culled by its flat box
     ("cornell_sobol_64x36_128spp", "cornell-box/scene_sobol.json", (64, 36), 128),   # pixel (47,33) sample 15: floor / wall tie, last visited wins

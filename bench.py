@@ -111,7 +111,15 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # TGPU_BENCH_FORCE_DIST=1: a ONE-rank process group, so that a one-GPU box rehearses the RCCL calls of the N > 1 run (communicator set-up,
+    # barrier, gather of the framebuffers, the MAX all-reduce of the time) -- tests/test_gpu_dist.py
+    force_dist = world == 1 and os.environ.get("TGPU_BENCH_FORCE_DIST", "0") == "1"
+    if force_dist and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # nccl == RCCL on ROCm.  TGPU_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (the ranks

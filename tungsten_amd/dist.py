@@ -19,12 +19,13 @@ def gather_framebuffer(local_rgb, shard, world, rank, dist=None, device=None):
     """Gather shard-ordered rgb tensors (torch, on `device`) to rank 0 and assemble the image.
 
     local_rgb: torch tensor (n_local, 3) float32.  Returns an (H, W, 3) numpy image on rank 0,
-    None elsewhere.  With world == 1 no collective is issued.
+    None elsewhere.  With world == 1 and no process group no collective is issued (a one-rank group still goes through the
+    collective: the RCCL rehearsal of a one-GPU box).
     """
     import torch
 
     res_x, res_y = shard.res_x, shard.res_y
-    if world == 1:
+    if world == 1 and dist is None:
         return shard.scatter(local_rgb.detach().cpu().numpy())
     sizes = shard_sizes(res_x, res_y, world)
     n_max = max(sizes)
@@ -67,12 +68,12 @@ def gather_framebuffers(local_rgbs, shards, world, rank, sub, dist=None):
 
     res_x, res_y = shards[0].res_x, shards[0].res_y
     nccl = dist is not None and dist.get_backend() == "nccl"
-    where = local_rgbs[0].device if (world == 1 or nccl) else torch.device("cpu")
+    where = local_rgbs[0].device if (dist is None or nccl) else torch.device("cpu")
     idx, sizes = _shard_indices(res_x, res_y, world*sub, where)
     image = torch.zeros((res_y*res_x, 3), dtype=torch.float32, device=where) if rank == 0 else None
     for j in range(sub):
         local = local_rgbs[j]
-        if world == 1:
+        if dist is None: # one rank, no process group (a one-rank group takes the collective below: tests/test_gpu_dist.py)
             image[idx[j]] = local.detach()
             continue
         n_max = max(sizes[r*sub + j] for r in range(world))

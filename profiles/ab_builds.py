@@ -12,6 +12,8 @@ for n in names:
     c=Context(0, lib=load_core(os.path.abspath(f'build_tmp/ab/lib_{n}.so')))
     c.upload(s,sh); c.render(16,spp_step=16)
     ctxs[n]=c
+imgs={n:c.download()[0] for n,c in ctxs.items()}
+for n in names[1:]: print(n, 'image identical to', names[0], ':', bool(np.array_equal(imgs[names[0]].view(np.uint32), imgs[n].view(np.uint32))), flush=True)
 steps=int(os.environ.get('AB_STEPS','8'))
 res={n:[] for n in names}
 for rnd in range(int(os.environ.get('AB_ROUNDS','5'))):

@@ -140,10 +140,11 @@ struct DScene {
     tgpu_env env;          // pointers are device pointers
     int32_t envConstant;   // emission texture is constant
     const uint32_t *sobol; // 1024 x 32
-    // guide tables for the env CDF inversion: entry g = index of the last CDF element <= g/N, so the
-    // std::upper_bound of Distribution2D::warp becomes one table read + a short forward scan
-    const uint16_t *envGuideMarginal;    // dist_h entries
-    const uint16_t *envGuideConditional; // dist_h x dist_w entries
+    // guide records for the env CDF inversion (EnvGuide below): bucket g names the last CDF element <= g/N and carries the CDF / pdf values the
+    // forward scan from there reads first, so the std::upper_bound of Distribution2D::warp is ONE 32-byte read in the common case
+    const struct EnvGuide *envGuideMarginal;    // dist_h records
+    const struct EnvGuide *envGuideConditional; // dist_h x dist_w records
+    int32_t envGuideSlack;                      // 1: a bucket of slack absorbs the rounding of value*N (N not a power of two)
     const DInstSet *instSets; uint32_t nInstSets;
     // participating media (media/HomogeneousMedium.cpp) and the table of fmath::exp_ps (thirdparty/fmath/fmath.hpp:90-127)
     const tgpu_medium *media; uint32_t nMedia;
@@ -321,14 +322,35 @@ TG_DEV float envPdf(const DScene &sc, float ux, float uy) // BitmapTexture.cpp:4
     return sc.env.pdf[size_t(row)*w + column]*sc.env.marginal_pdf[row]*w*h;
 }
 
-// (std::upper_bound(a, a + n, value) - a) - 1 using a guide table with `buckets` entries, guide[g] = index of the
-// last element <= g/buckets.  One bucket of slack absorbs the rounding of value*buckets.
-TG_DEV int upperBoundGuided(const float *a, int n, const uint16_t *guide, int buckets, float value)
+// One bucket of the guide table of a CDF `a` (n entries) with its pdf `p`: idx = (std::upper_bound(a, a + n, g/buckets) - a) - 1, the last
+// element <= the bucket's lower end, followed by what a forward scan from idx reads first: a[idx], a[idx + 1], a[idx + 2] and p[idx], p[idx + 1].
+// With as many buckets as CDF elements a uniform value crosses half an element on average, so the scan usually ends inside the record; the
+// dependent chain guide -> a[i + 1] -> a[i + 2] -> ... -> a[i], p[i] of the plain table (one round trip each) becomes a single read.
+struct alignas(32) EnvGuide { uint32_t idx; float a0, a1, a2, p0, p1, pad0, pad1; };
+
+// (std::upper_bound(a, a + n, value) - a) - 1 through the guide records; also hands back a[i] and p[i] of the element found, the values
+// Distribution2D::warp reads next -- from the record when the scan ended inside it, from the tables otherwise (same bits either way).
+// slack: value*buckets may round up to the next integer when buckets is not a power of two, so such tables start one bucket early.
+TG_DEV int upperBoundGuided(const float *a, const float *p, int n, const EnvGuide *guide, int buckets, int slack, float value, float &ai, float &pi)
 {
     int g = int(value*float(buckets));
-    g = min(max(g - 1, 0), buckets - 1);
-    int i = int(guide[g]);
-    while (i + 1 < n && !(value < a[i + 1])) ++i;
+    g = min(max(g - slack, 0), buckets - 1);
+    const float4 *rec = reinterpret_cast<const float4 *>(guide + g);
+    const float4 r0 = rec[0], r1 = rec[1]; // idx a0 a1 a2 | p0 p1 - -
+    int i = int(__float_as_uint(r0.x));
+    ai = r0.y;
+    pi = r1.x;
+    if (i + 1 < n && !(value < r0.z)) {
+        ++i;
+        ai = r0.z;
+        pi = r1.y;
+        if (i + 1 < n && !(value < r0.w)) {
+            ++i;
+            while (i + 1 < n && !(value < a[i + 1])) ++i;
+            ai = a[i];
+            pi = p[i];
+        }
+    }
     return i;
 }
 
@@ -367,16 +389,24 @@ TG_DEV bool envSampleDirect(const DScene &sc, Sampler &s, LightSample &out) // I
     float uvx = s.next1D(), uvy = s.next1D();
     int w = sc.env.dist_w, h = sc.env.dist_h; // Distribution2D::warp (sampling/Distribution2D.hpp:66-76)
     const float *mc = sc.env.marginal_cdf;
-    int row = upperBoundGuided(mc, h + 1, sc.envGuideMarginal, h, uvy);
-    uvy = clampf((uvy - mc[row])/sc.env.marginal_pdf[row], 0.0f, 1.0f);
+    float cdfAt, pdfAt; // mc[row], marginal_pdf[row]; then rs[column], pdf[row][column]
+    int row = upperBoundGuided(mc, sc.env.marginal_pdf, h + 1, sc.envGuideMarginal, h, sc.envGuideSlack & 1, uvy, cdfAt, pdfAt);
+    const float pdfRow = pdfAt;
+    uvy = clampf((uvy - cdfAt)/pdfAt, 0.0f, 1.0f);
     const float *rs = sc.env.cdf + size_t(row)*(w + 1);
-    int column = upperBoundGuided(rs, w + 1, sc.envGuideConditional + size_t(row)*w, w, uvx);
-    uvx = clampf((uvx - rs[column])/sc.env.pdf[size_t(row)*w + column], 0.0f, 1.0f);
+    int column = upperBoundGuided(rs, sc.env.pdf + size_t(row)*w, w + 1, sc.envGuideConditional + size_t(row)*w, w, (sc.envGuideSlack >> 1) & 1, uvx, cdfAt, pdfAt);
+    uvx = clampf((uvx - cdfAt)/pdfAt, 0.0f, 1.0f);
     float ux = (uvx + column)/w; // BitmapTexture::sample (:433-439)
     float uy = 1.0f - (uvy + row)/h;
     float sinTheta;
     out.d = uvToDirection(sc, ux, uy, sinTheta);
-    out.pdf = INV_PI*INV_TWO_PI*envPdf(sc, ux, uy)/sinTheta;
+    // envPdf(sc, ux, uy): the texel it derives from (ux, uy) is nearly always the cell just sampled, whose two pdf values are in registers;
+    // only a lane whose rounding lands in a neighbouring cell reads the tables again
+    int pr = int((1.0f - uy)*h), pc = int(ux*w);
+    pr = min(max(pr, 0), h - 1);
+    pc = min(max(pc, 0), w - 1);
+    const float texPdf = (pr == row && pc == column) ? pdfAt*pdfRow*w*h : sc.env.pdf[size_t(pr)*w + pc]*sc.env.marginal_pdf[pr]*w*h;
+    out.pdf = INV_PI*INV_TWO_PI*texPdf/sinTheta;
     out.dist = TG_INF;
     return out.pdf != 0.0f;
 }

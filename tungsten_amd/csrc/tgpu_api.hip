@@ -855,20 +855,29 @@ int tgpu_upload_scene(tgpu_ctx *ctx, const tgpu_scene_desc *s, const tgpu_shard_
             if ((rc = upload(ctx, ctx->allocs, s->env.marginal_pdf, h, &c))) return rc;
             if ((rc = upload(ctx, ctx->allocs, s->env.marginal_cdf, h + 1, &d))) return rc;
             sc.env.pdf = a; sc.env.cdf = b; sc.env.marginal_pdf = c; sc.env.marginal_cdf = d;
-            // guide tables (device.h: upperBoundGuided)
-            if (w > 65535 || h > 65535) { fail(ctx, "environment map larger than 65535 texels per side"); return TGPU_ERR_UNSUPPORTED; }
-            auto lastLE = [](const float *arr, size_t n, float v) { // (upper_bound - begin) - 1
-                return uint16_t((std::upper_bound(arr, arr + n, v) - arr) - 1);
+            // guide records (device.h: EnvGuide, upperBoundGuided)
+            auto guideOf = [](const float *cdf, const float *pdf, const float *pdfEnd, size_t n, size_t buckets, size_t g) { // cdf: n entries
+                EnvGuide e{};
+                const size_t i = size_t((std::upper_bound(cdf, cdf + n, float(g)/float(buckets)) - cdf) - 1);
+                e.idx = uint32_t(i);
+                e.a0 = cdf[i];
+                e.a1 = i + 1 < n ? cdf[i + 1] : 0.0f;
+                e.a2 = i + 2 < n ? cdf[i + 2] : 0.0f;
+                e.p0 = pdf + i < pdfEnd ? pdf[i] : 0.0f; // what the scan would read at p[i]: the next row's first element past a row's end, as in the plain tables
+                e.p1 = pdf + i + 1 < pdfEnd ? pdf[i + 1] : 0.0f;
+                return e;
             };
-            std::vector<uint16_t> gm(h), gc(w*h);
-            for (size_t g = 0; g < h; ++g) gm[g] = lastLE(s->env.marginal_cdf, h + 1, float(g)/float(h));
+            std::vector<EnvGuide> gm(h), gc(w*h);
+            for (size_t g = 0; g < h; ++g) gm[g] = guideOf(s->env.marginal_cdf, s->env.marginal_pdf, s->env.marginal_pdf + h, h + 1, h, g);
             for (size_t r = 0; r < h; ++r)
-                for (size_t g = 0; g < w; ++g) gc[r*w + g] = lastLE(s->env.cdf + r*(w + 1), w + 1, float(g)/float(w));
-            uint16_t *dgm, *dgc;
+                for (size_t g = 0; g < w; ++g) gc[r*w + g] = guideOf(s->env.cdf + r*(w + 1), s->env.pdf + r*w, s->env.pdf + w*h, w + 1, w, g);
+            EnvGuide *dgm, *dgc;
             if ((rc = upload(ctx, ctx->allocs, gm.data(), gm.size(), &dgm))) return rc;
             if ((rc = upload(ctx, ctx->allocs, gc.data(), gc.size(), &dgc))) return rc;
             sc.envGuideMarginal = dgm;
             sc.envGuideConditional = dgc;
+            // value*N is exact when N is a power of two: int(value*N) is then the bucket that holds value and no slack is needed
+            sc.envGuideSlack = ((h & (h - 1)) ? 1 : 0) | ((w & (w - 1)) ? 2 : 0);
         }
     }
     uint32_t *dSobol;

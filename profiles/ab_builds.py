@@ -15,12 +15,13 @@ for n in names:
 imgs={n:c.download()[0] for n,c in ctxs.items()}
 for n in names[1:]: print(n, 'image identical to', names[0], ':', bool(np.array_equal(imgs[names[0]].view(np.uint32), imgs[n].view(np.uint32))), flush=True)
 steps=int(os.environ.get('AB_STEPS','8'))
+BASE=int(os.environ.get('AB_BASE','16'))  # first sample index of the timed passes (>= 256: the second Sobol' block)
 res={n:[] for n in names}
 for rnd in range(int(os.environ.get('AB_ROUNDS','5'))):
     for n in names:
         c=ctxs[n]
         t=time.perf_counter()
-        for i in range(steps): c.render_pass(16+16*i,16)
+        for i in range(steps): c.render_pass(BASE+16*i,16)
         c.wait(); dt=time.perf_counter()-t
         res[n].append(1280*720*16*steps/dt/1e6)
 for n in names:
@@ -28,6 +29,6 @@ for n in names:
 if os.environ.get('AB_PROF'):
     for n in names:
         c=ctxs[n]; c.set_profiling(2); c.reset_stats()
-        for i in range(steps): c.render_pass(16+16*i,16)
+        for i in range(steps): c.render_pass(BASE+16*i,16)
         c.wait(); st=c.stats(); c.set_profiling(0)
         print(n, {k: round(st[k]/steps,2) for k in ('extend_ms','shadow_ms','shade_ms','other_ms')}, 'launches', st['extend_launches'], flush=True)

@@ -13,11 +13,16 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(os.path.dirname(here), "gpurun_out", "prof")
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(here, f"{tag}_bench.json"))
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges a call's files INTO gpurun_out/, so earlier collections' files (other process ids) stay next to the new ones:
+    only the most recent file of a kind belongs to this collection."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(int)
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for f in [newest(os.path.join(d, "*", "*counter_collection.csv")) for d in sorted(glob.glob(os.path.join(src, "pmc_*"))) if os.path.isdir(d)]:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void tg::", "").replace("tg::", "")
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -148,11 +148,13 @@ struct DState {
     uint32_t *jobVtIndex;       // TG_RING x nVt: SampleRecord::sampleIndex of the pass
 };
 
-// Streaming accesses to the path state: non-temporal, so that the 4 MB L2 of each XCD keeps the BVH
-// and triangle data the traversal re-reads instead of state that is touched once per iteration.
+// Accesses of the traversal kernels to the path state.  Until round 3 they were non-temporal ("keep the 4 MB L2 of each XCD for the BVH"): that
+// dates from the one-array-per-field layout, where every access had a line of its own.  With records (section 4 of DESIGN.md) a kernel reads
+// three or four sectors of ONE line, and a non-temporal load does not leave the line behind for the next sector's load: plain accesses are
+// 5-6 % faster in both traversal kernels (profiles/r03_ab_notes.txt; in the shade step the hint costs a factor of three).
 typedef float tg_f4 __attribute__((ext_vector_type(4)));
 #ifndef TG_STATE_NT
-#define TG_STATE_NT 3 /* bit 0: loads, bit 1: stores (A/B switch, profiles/r01_ab_notes.txt) */
+#define TG_STATE_NT 0 /* bit 0: loads, bit 1: stores non-temporal (A/B switch) */
 #endif
 TG_DEV float4 ldStream(const float4 *p)
 {

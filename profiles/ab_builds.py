@@ -5,7 +5,7 @@ import torch
 import tungsten_amd as ta
 from tungsten_amd._core import load_core, Context
 names = sys.argv[1:] or [os.path.basename(p)[4:-3] for p in sorted(glob.glob('build_tmp/ab/lib_*.so'))]
-s=ta.HostScene('assets/materialtest/c2.json')
+s=ta.HostScene(os.environ.get('AB_SCENE','assets/materialtest/c2.json'))
 sh=ta.Shard(s.res_x,s.res_y)
 ctxs={}
 for n in names:
@@ -23,7 +23,7 @@ for rnd in range(int(os.environ.get('AB_ROUNDS','5'))):
         t=time.perf_counter()
         for i in range(steps): c.render_pass(BASE+16*i,16)
         c.wait(); dt=time.perf_counter()-t
-        res[n].append(1280*720*16*steps/dt/1e6)
+        res[n].append(s.res_x*s.res_y*16*steps/dt/1e6)
 for n in names:
     r=np.array(res[n]); print(f'{n:12s} median {np.median(r):7.1f}  min {r.min():7.1f} max {r.max():7.1f} Msamples/s', flush=True)
 if os.environ.get('AB_PROF'):

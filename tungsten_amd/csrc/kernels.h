@@ -154,41 +154,43 @@ struct DState {
 // 5-6 % faster in both traversal kernels (profiles/r03_ab_notes.txt; in the shade step the hint costs a factor of three).
 typedef float tg_f4 __attribute__((ext_vector_type(4)));
 #ifndef TG_STATE_NT
-#define TG_STATE_NT 0 /* bit 0: loads, bit 1: stores non-temporal (A/B switch) */
+#define TG_STATE_NT 0 /* flat scenes: bit 0: loads, bit 1: stores non-temporal (A/B switch) */
 #endif
+// Scenes with "instances" keep the hint in their traversal kernels: their working set (top-level tree, instance entries, the masters' trees) is what the
+// L2 is for, and the plain form costs k_shadow_iq 7.5 % and k_extend<general> 1.2 % on config 4 (profiles/r03_ab_notes.txt).
+#ifndef TG_STATE_NT_INST
+#define TG_STATE_NT_INST 3
+#endif
+template <int MODE = TG_STATE_NT>
 TG_DEV float4 ldStream(const float4 *p)
 {
-#if TG_STATE_NT & 1
-    tg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const tg_f4 *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
+    if (MODE & 1) {
+        tg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const tg_f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
     return *p;
-#endif
 }
+template <int MODE = TG_STATE_NT>
 TG_DEV uint32_t ldStream(const uint32_t *p)
 {
-#if TG_STATE_NT & 1
-    return __builtin_nontemporal_load(p);
-#else
+    if (MODE & 1) return __builtin_nontemporal_load(p);
     return *p;
-#endif
 }
+template <int MODE = TG_STATE_NT>
 TG_DEV void stStream(float4 *p, const float4 &v)
 {
-#if TG_STATE_NT & 2
-    tg_f4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<tg_f4 *>(p));
-#else
-    *p = v;
-#endif
+    if (MODE & 2) {
+        tg_f4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<tg_f4 *>(p));
+    } else {
+        *p = v;
+    }
 }
+template <int MODE = TG_STATE_NT>
 TG_DEV void stStream(uint32_t *p, uint32_t v)
 {
-#if TG_STATE_NT & 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
+    if (MODE & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 TG_DEV float4 mk4(const V3 &v, float w) { return make_float4(v.x, v.y, v.z, w); }
 TG_DEV float4 mk4u(const V3 &v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
@@ -1395,20 +1397,20 @@ __global__ void __launch_bounds__(256, (INST ? TG_EXTEND_INST_WAVES : TG_EXTEND_
                 else have = listFetch(st, lc, set, 0, idx, path);
             }
             if (have) {
-                bool dead = !RAW && flagsEnd(__float_as_uint(ldStream(&st.tp[path]).w)) == END_DEAD;
+                bool dead = !RAW && flagsEnd(__float_as_uint(ldStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&st.tp[path]).w)) == END_DEAD;
                 if (dead) {
                     cls = 0xFDu;
                 } else {
-                    float4 ro = ldStream(&st.rayO[path]), rd = ldStream(&st.rayD[path]);
+                    float4 ro = ldStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&st.rayO[path]), rd = ldStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&st.rayD[path]);
                     V3 O = xyz(ro), D = xyz(rd);
                     float tfar = rd.w, u = 0.0f, v = 0.0f;
                     uint32_t inst;
                     uint32_t prim = closestHit<COUNT, INST>(sc, stack, O, D, ro.w, tfar, u, v, inst, tc);
                     if (INST) {
                         if (RAW) { if (inst != INST_NONE) prim = mkPrim(KIND_ENV, inst & 0xFFFFFFu); } // ray-level ABI: kind 3 = instance index
-                        else stStream(&st.hitInst[path], inst);
+                        else stStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&st.hitInst[path], inst);
                     }
-                    stStream(&st.hit[path], make_float4(tfar, u, v, __uint_as_float(prim)));
+                    stStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&st.hit[path], make_float4(tfar, u, v, __uint_as_float(prim)));
                     if (!RAW) {
                         cls = hitClass(sc, prim);
                         if (sc.nMedia && (st.med[path] & 0xFFu)) cls = TG_CLASS_VOLUME;
@@ -1436,10 +1438,10 @@ __global__ void __launch_bounds__(256, (INST ? TG_EXTEND_INST_WAVES : TG_EXTEND_
                 if (lane == 0) wbase = atomicAdd(ctr, n);
                 wbase = __shfl(wbase, 0);
                 const unsigned long long below = (1ull << lane) - 1ull;
-                if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p0);
-                if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p1);
-                if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p2);
-                if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p3);
+                if ((m0 >> lane) & 1ull) stStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p0);
+                if ((m1 >> lane) & 1ull) stStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p1);
+                if ((m2 >> lane) & 1ull) stStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p2);
+                if ((m3 >> lane) & 1ull) stStream<INST ? TG_STATE_NT_INST : TG_STATE_NT>(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p3);
             }
         }
     }
@@ -3487,9 +3489,9 @@ __global__ void __launch_bounds__(256, TG_INSTQ_WAVES) k_extend_iq(DScene sc, DS
     bool pre = false, haveNext = false;
     float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
     auto fetchRay = [&]() {
-        nro = ldStream(&st.rayO[pSlot]);
-        nrd = ldStream(&st.rayD[pSlot]);
-        nflags = ldStream(reinterpret_cast<const uint32_t *>(&st.tp[pSlot]) + 3);
+        nro = ldStream<TG_STATE_NT_INST>(&st.rayO[pSlot]);
+        nrd = ldStream<TG_STATE_NT_INST>(&st.rayD[pSlot]);
+        nflags = ldStream<TG_STATE_NT_INST>(reinterpret_cast<const uint32_t *>(&st.tp[pSlot]) + 3);
     };
     pre = claim(true, pSlot);
     if (pre) fetchRay();
@@ -3526,8 +3528,8 @@ __global__ void __launch_bounds__(256, TG_INSTQ_WAVES) k_extend_iq(DScene sc, DS
         bool wantEntry = false;
         if (waiting) {
             if (fin) { // retire the ray of slot vs
-                stStream(&st.hit[vs], make_float4(r.farT, r.u, r.v, __uint_as_float(r.prim)));
-                stStream(&st.hitInst[vs], r.prim == PRIM_MISS ? INST_NONE : r.inst);
+                stStream<TG_STATE_NT_INST>(&st.hit[vs], make_float4(r.farT, r.u, r.v, __uint_as_float(r.prim)));
+                stStream<TG_STATE_NT_INST>(&st.hitInst[vs], r.prim == PRIM_MISS ? INST_NONE : r.inst);
                 fin = false;
             }
             if (pre) {
@@ -3578,10 +3580,10 @@ static __global__ void __launch_bounds__(256) k_classify(DScene sc, DState st, i
             p[q] = 0;
             uint32_t cls = 0xFEu;
             if (base + lane + 64u*q < count && listFetch(st, lc, set, 0, base + lane + 64u*q, p[q])) {
-                if (flagsEnd(__float_as_uint(ldStream(&st.tp[p[q]]).w)) == END_DEAD) {
+                if (flagsEnd(__float_as_uint(ldStream<TG_STATE_NT_INST>(&st.tp[p[q]]).w)) == END_DEAD) {
                     cls = 0xFDu;
                 } else {
-                    cls = hitClass(sc, __float_as_uint(ldStream(&st.hit[p[q]]).w));
+                    cls = hitClass(sc, __float_as_uint(ldStream<TG_STATE_NT_INST>(&st.hit[p[q]]).w));
                     if (sc.nMedia && (st.med[p[q]] & 0xFFu)) cls = TG_CLASS_VOLUME;
                 }
             }
@@ -3602,10 +3604,10 @@ static __global__ void __launch_bounds__(256) k_classify(DScene sc, DState st, i
             if (lane == 0) wbase = atomicAdd(ctr, nn);
             wbase = __shfl(wbase, 0);
             const unsigned long long below = (1ull << lane) - 1ull;
-            if ((m0 >> lane) & 1ull) stStream(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p[0]);
-            if ((m1 >> lane) & 1ull) stStream(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p[1]);
-            if ((m2 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p[2]);
-            if ((m3 >> lane) & 1ull) stStream(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p[3]);
+            if ((m0 >> lane) & 1ull) stStream<TG_STATE_NT_INST>(&dst[wbase + uint32_t(__builtin_popcountll(m0 & below))], p[0]);
+            if ((m1 >> lane) & 1ull) stStream<TG_STATE_NT_INST>(&dst[wbase + n0 + uint32_t(__builtin_popcountll(m1 & below))], p[1]);
+            if ((m2 >> lane) & 1ull) stStream<TG_STATE_NT_INST>(&dst[wbase + n0 + n1 + uint32_t(__builtin_popcountll(m2 & below))], p[2]);
+            if ((m3 >> lane) & 1ull) stStream<TG_STATE_NT_INST>(&dst[wbase + n0 + n1 + n2 + uint32_t(__builtin_popcountll(m3 & below))], p[3]);
         }
     }
 }
@@ -3655,10 +3657,10 @@ __global__ void __launch_bounds__(256, TG_INSTQ_WAVES) k_shadow_iq(DScene sc, DS
     bool pre = false, haveNext = false, closestMode = false;
     float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
     auto fetchRay = [&]() {
-        nrd = ldStream(pWhich ? &st.shB[pSlot] : &st.shA[pSlot]);
-        nro = ldStream(&st.shO[pSlot]);
-        ncap = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]));
-        nHasB = ldStream(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]) + 1);
+        nrd = ldStream<TG_STATE_NT_INST>(pWhich ? &st.shB[pSlot] : &st.shA[pSlot]);
+        nro = ldStream<TG_STATE_NT_INST>(&st.shO[pSlot]);
+        ncap = ldStream<TG_STATE_NT_INST>(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]));
+        nHasB = ldStream<TG_STATE_NT_INST>(reinterpret_cast<const uint32_t *>(&st.shX[pSlot]) + 1);
     };
     pre = claim(true, pSlot);
     if (pre) fetchRay();
@@ -3670,7 +3672,7 @@ __global__ void __launch_bounds__(256, TG_INSTQ_WAVES) k_shadow_iq(DScene sc, DS
         if (unoccluded) vis |= 1u << cw;
         if (last) {
             if (vis & 4u) {
-                stStream(reinterpret_cast<uint32_t *>(&st.shD[vs]) + 3, vis & 3u);
+                stStream<TG_STATE_NT_INST>(reinterpret_cast<uint32_t *>(&st.shD[vs]) + 3, vis & 3u);
                 verts++;
             }
             vis = 0;
